@@ -1,0 +1,12 @@
+import numpy as np
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def normwise(a, b):
+    """max|a-b| / max|b| -- the parity metric of SURVEY.md section 7 (hard part 3)"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    den = np.max(np.abs(b))
+    return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
