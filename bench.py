@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Msamples/s filtered on the 1-D batch path (BASELINE.json config 2:
+4096 channels x 2^20 fp32 samples per GPU, half_window=32, poly_order=4, all four boundary modes),
+with the HBM-roofline fraction of the dominant kernel and the reference's CPU path timed beside it.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of savgol_apply_batch_f32 over the whole resident batch in EACH of the four boundary
+modes (4 launches of the centre kernel + the tiny polynomial edge kernel).  Inputs are generated in HBM
+before the timed region.  Channels are independent: with N GPUs every rank owns its own 4096 channels
+(weak scaling, no data-path collective); rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+N, M, D = 32, 4, 0
+
+
+def cpu_baseline(length, budget_s=12.0):
+    """The reference's own savgol_apply (oracle/_ref, gcc -O2, 1 thread -- the reference has no threading)
+    on a bounded sample of the same workload: as many 2^20-sample channels of config 2 as fit in ~12 s."""
+    import ctypes as C
+    from oracle import sgo
+    x = sgo.synth_f32(0, 1, length)[0]
+    y = np.empty_like(x)
+    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libsavgol_ref.so")
+    if os.path.exists(ref_lib):
+        from tests.golden import make_golden as mg
+        L = mg.load()
+        cfg = mg.Cfg(N, M, D, 1.0, 0)
+        f = L.savgol_create(C.byref(cfg))
+        run = lambda: L.savgol_apply(f, mg.fptr(x), mg.fptr(y), length)
+        kind = "reference"
+    else:
+        f = sgo.Filter(N, M, D)
+        run = lambda: f.apply(x)
+        kind = "port"
+    run()
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        run(); n_done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    return {"value": round(n_done * length / el / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
+            "sample": f"{n_done} channels x {length} fp32 samples of config 2 (n={N}, m={M}, POLYNOMIAL), "
+                      f"savgol_apply back to back for {el:.1f} s, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
+    ap.add_argument("--length", type=int, default=1 << 20)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    sg = load_package()
+    assert sg.lib().savgol_hip_set_device(local) == 0, sg.last_error()
+
+    ch, length = args.channels, args.length
+    x = torch.empty((ch, length), dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    sg.synth(x, channel0=rank * ch)                       # generated in HBM, never crosses PCIe
+    filters = [sg.Filter(N, M, D, 1.0, mode) for mode in range(4)]
+    torch.cuda.synchronize()
+
+    def step(events=None):
+        for f in filters:
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            f.apply_batch(x, y, ch, length)
+            if events is not None:
+                e1.record(); events.append((e0, e1))
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # parity spot check of what was just timed (last mode run = CONSTANT), against the CPU oracle
+    checked = None
+    if rank == 0:
+        from oracle import sgo
+        sample = [0, ch // 2, ch - 1]
+        got = y[sample].cpu().numpy()
+        ref = sgo.Filter(N, M, D, 1.0, 3).apply_f64(x[sample].cpu().numpy().astype(np.float64))
+        checked = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+        assert checked < 1e-6, f"parity lost: normwise error {checked}"
+
+    if rank == 0:
+        launches_ms = [a.elapsed_time(b) for a, b in events]
+        avg_ms = float(np.mean(launches_ms))
+        alg_bytes = 8.0 * ch * length                      # 4 B read + 4 B written per sample
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        samples = 4.0 * ch * length * args.steps * world
+        out = {
+            "metric": "Msamples/s filtered (1D batch, hw=32, poly=4) + % HBM roofline",
+            "value": round(samples / elapsed / 1e6, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config 2: {ch} channels x {length} fp32 samples per GPU, half_window={N}, "
+                                   f"poly_order={M}, derivative={D}, one pass per boundary mode "
+                                   "(POLYNOMIAL, REFLECT, PERIODIC, CONSTANT) per step",
+                       "channels_per_gpu": ch, "length": length, "sharding": "channels, no collective"},
+            "roofline": {"bound": "hbm", "kernel": f"sg1d_center_kernel<float,{N}>",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
+                         "launches_timed": len(launches_ms)},
+            "parity_normwise_vs_fp64_oracle": checked,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(length)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

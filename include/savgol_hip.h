@@ -1,0 +1,123 @@
+/*
+ * savgol_hip.h -- device-side C ABI of the MI355X Savitzky-Golay library (libsavgol_hip.so).
+ *
+ * The reference API (savgolFilter.h, savgol_stream.h, savgol2d.h) is one signal / one stream /
+ * one image at a time, fp32, host pointers.  The workloads this library is built for -- thousands
+ * of channels resident in HBM, tens of thousands of concurrent streams, image stacks, fp64 --
+ * cannot be expressed through it, so this header ADDS entry points next to the drop-in ones.
+ * Everything here is plain C: raw device pointers, sizes, an opaque `void *stream`
+ * (a hipStream_t; NULL = the default stream).  No torch / C++ types cross this boundary.
+ *
+ * Each function names the reference routine whose arithmetic it performs.  All of them return
+ * 0 on success and -1 on error unless stated otherwise; savgol_hip_last_error() has the text.
+ * Launches are asynchronous on `stream`; nothing here allocates, frees or synchronises on the
+ * hot path (weight tables are uploaded once per distinct filter and cached), so the batch calls
+ * can be captured into a hipGraph.
+ */
+#ifndef SAVGOL_HIP_H
+#define SAVGOL_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "savgolFilter.h"
+#include "savgol2d.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- runtime ------------- */
+int         savgol_hip_device_count(void);          /* usable HIP devices (0 = none)       */
+int         savgol_hip_set_device(int ordinal);     /* device used by THIS thread's calls  */
+int         savgol_hip_get_device(void);
+int         savgol_hip_synchronize(void *stream);
+const char *savgol_hip_last_error(void);            /* thread-local, never NULL            */
+const char *savgol_hip_version(void);
+
+/* ---------------------------------------------------------------- 1-D batch ----------- *
+ * channels independent signals, row-major: sample i of channel c at base[c*ld + i].
+ * Arithmetic of savgol_apply (reference src/savgolFilter.c:743-804): centre taps on the
+ * interior, filter->config.boundary on the first/last n samples (POLYNOMIAL rows incl. the
+ * reference's reversed leading edge; REFLECT / PERIODIC / CONSTANT by index remap).
+ * d_in and d_out must not overlap.  length >= 2n+1.
+ * f32: fp32 tables, fp32 FMA accumulation (within 1e-6 normwise of the fp64 oracle).
+ * f64: the same fp32 tables promoted exactly to double, double accumulation, the reference's
+ *      float 1/dt_scale promoted -- there is no fp64 path in the reference.   */
+int savgol_apply_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out,
+                           size_t channels, size_t length, size_t in_ld, size_t out_ld,
+                           void *stream);
+int savgol_apply_batch_f64(const SavgolFilter *filter, const double *d_in, double *d_out,
+                           size_t channels, size_t length, size_t in_ld, size_t out_ld,
+                           void *stream);
+/* savgol_apply_valid (:821-850) per channel: writes length-2n samples at d_out[c*out_ld + 0..] */
+int savgol_apply_valid_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out,
+                                 size_t channels, size_t length, size_t in_ld, size_t out_ld,
+                                 void *stream);
+int savgol_apply_valid_batch_f64(const SavgolFilter *filter, const double *d_in, double *d_out,
+                                 size_t channels, size_t length, size_t in_ld, size_t out_ld,
+                                 void *stream);
+/* savgol_apply_strided (:877-934) on device memory: element i of channel c is the float at
+ * (char*)base + c*channel_pitch + i*stride + offset (bytes).  Edges are always POLYNOMIAL.     */
+int savgol_apply_strided_batch_f32(const SavgolFilter *filter,
+                                   const void *d_in, size_t in_stride, size_t in_offset, size_t in_channel_pitch,
+                                   void *d_out, size_t out_stride, size_t out_offset, size_t out_channel_pitch,
+                                   size_t channels, size_t count, void *stream);
+
+/* ---------------------------------------------------------------- stream bank --------- *
+ * `streams` independent SavgolStream-equivalents advancing in lock step, state in HBM as a
+ * structure of arrays (ring[slot][stream]).  Arithmetic of src/savgol_stream.c: single fp32
+ * accumulator, taps in order, separate multiply and add -- outputs are bit-identical to the
+ * reference's savgol_stream_push / _push_full / _flush / _flush_leading for every stream.
+ * Output rows are [row][stream] with pitch `streams`.                                        */
+typedef struct SavgolStreamBank SavgolStreamBank;
+
+SavgolStreamBank *savgol_streambank_create(const SavgolConfig *config, size_t streams);
+void   savgol_streambank_destroy(SavgolStreamBank *bank);
+int    savgol_streambank_reset(SavgolStreamBank *bank, void *stream);
+/* one tick = one sample per stream.  Returns 1 when d_out[0..streams) holds centre outputs,
+ * 0 while the windows are still filling (d_out untouched), -1 on error.                       */
+int    savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream);
+/* with edges: returns the number of output rows written (0, 1, or up to n+1 on the tick that
+ * fills the windows, truncated to max_rows), -1 on error.                                     */
+int    savgol_streambank_push_full(SavgolStreamBank *bank, const float *d_samples,
+                                   float *d_out, int max_rows, void *stream);
+/* `ticks` pushes in one launch (ring kept on chip in between): d_samples[t*streams + s],
+ * d_out[t*streams + s] is written for every tick t that has a centre output.  Returns the
+ * number of ticks that produced output (they are the last ones), -1 on error.                 */
+int    savgol_streambank_push_block(SavgolStreamBank *bank, const float *d_samples, size_t ticks,
+                                    float *d_out, void *stream);
+/* trailing / leading edge rows, up to n of them; -1 on bad arguments, 0 if never filled       */
+int    savgol_streambank_flush(SavgolStreamBank *bank, float *d_out, int max_rows, void *stream);
+int    savgol_streambank_flush_leading(SavgolStreamBank *bank, float *d_out, int max_rows, void *stream);
+bool   savgol_streambank_ready(const SavgolStreamBank *bank);
+size_t savgol_streambank_latency(const SavgolStreamBank *bank);
+size_t savgol_streambank_streams(const SavgolStreamBank *bank);
+size_t savgol_streambank_samples_received(const SavgolStreamBank *bank);   /* per stream */
+size_t savgol_streambank_samples_output(const SavgolStreamBank *bank);     /* per stream */
+/* checkpoint / resume: the whole state as one blob (synchronous) */
+size_t savgol_streambank_state_bytes(const SavgolStreamBank *bank);
+int    savgol_streambank_save(const SavgolStreamBank *bank, void *host_blob, void *stream);
+int    savgol_streambank_load(SavgolStreamBank *bank, const void *host_blob, void *stream);
+
+/* ---------------------------------------------------------------- 2-D batch ----------- *
+ * `images` frames, image k at base + k*image_pitch (elements), row pitch in elements.
+ * Arithmetic of savgol2d_apply / savgol2d_apply_valid (src/savgol2d.c:356-456).
+ * method: 0 = auto, 1 = direct dense window, 2 = exact low-rank separable passes.            */
+int savgol2d_apply_batch_f32(const Savgol2DFilter *filter,
+                             const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,
+                             float *d_out, int out_stride, size_t out_image_pitch,
+                             size_t images, Savgol2DBoundary boundary, int method, void *stream);
+
+/* ---------------------------------------------------------------- bench utilities ----- *
+ * Synthetic workload of SURVEY.md section 8(d), generated in HBM (never crosses PCIe):
+ * x[c][i] = sin(2 pi f_c i) + 0.5 sin(2 pi 7.3 f_c i + phi_c) + 0.1 u(c,i).                  */
+int savgol_hip_synth_f32(float *d_dst, size_t channel0, size_t channels, size_t length, size_t ld,
+                         uint64_t seed, void *stream);
+int savgol_hip_synth_f64(double *d_dst, size_t channel0, size_t channels, size_t length, size_t ld,
+                         uint64_t seed, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAVGOL_HIP_H */

@@ -1,0 +1,219 @@
+"""savgol_amd -- Python mirror (ctypes) of the C ABI of libsavgol_hip.so.
+
+The product is the shared library: host C/C++ that keeps the reference's savgolFilter.h /
+savgol_stream.h / savgol2d.h API, and hand-written gfx950 HIP kernels for the hot path.  This module
+only binds it: same function names, same argument meaning and error behaviour as the C headers in
+../include (which cite the reference lines they replace).  There is no Python or CPU compute path
+in here -- if the library is missing, importing `lib()` fails loudly.
+
+Host-pointer calls take numpy arrays; device-pointer calls take anything with `.data_ptr()`
+(torch tensors: torch is used for device memory / streams only) or a raw integer address.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsavgol_hip.so")
+
+SAVGOL_MAX_HALF_WINDOW = 32
+SAVGOL_MAX_WINDOW = 65
+SAVGOL_MAX_POLY_ORDER = 10
+SAVGOL_MAX_DERIVATIVE = 4
+SAVGOL_BOUNDARY_POLYNOMIAL, SAVGOL_BOUNDARY_REFLECT, SAVGOL_BOUNDARY_PERIODIC, SAVGOL_BOUNDARY_CONSTANT = 0, 1, 2, 3
+SAVGOL2D_BOUNDARY_VALID, SAVGOL2D_BOUNDARY_CONSTANT, SAVGOL2D_BOUNDARY_REFLECT = 0, 1, 2
+
+
+class SavgolConfig(C.Structure):
+    _fields_ = [("half_window", C.c_uint8), ("poly_order", C.c_uint8), ("derivative", C.c_uint8),
+                ("time_step", C.c_float), ("boundary", C.c_int)]
+
+
+class SavgolFilter(C.Structure):
+    _fields_ = [("config", SavgolConfig), ("window_size", C.c_int), ("dt_scale", C.c_float),
+                ("center_weights", C.c_float * SAVGOL_MAX_WINDOW),
+                ("edge_weights", (C.c_float * SAVGOL_MAX_WINDOW) * SAVGOL_MAX_HALF_WINDOW)]
+
+
+class SavgolStream(C.Structure):
+    _fields_ = [("filter", C.POINTER(SavgolFilter)), ("buffer", C.c_float * SAVGOL_MAX_WINDOW),
+                ("write_pos", C.c_int), ("samples_received", C.c_size_t), ("samples_output", C.c_size_t),
+                ("owns_filter", C.c_bool), ("dt_inv", C.c_float)]
+
+
+class Savgol2DConfig(C.Structure):
+    _fields_ = [("half_window_x", C.c_uint8), ("half_window_y", C.c_uint8), ("poly_order", C.c_uint8),
+                ("deriv_x", C.c_uint8), ("deriv_y", C.c_uint8), ("delta_x", C.c_float), ("delta_y", C.c_float)]
+
+
+class Savgol2DFilter(C.Structure):
+    _fields_ = [("config", Savgol2DConfig), ("window_width", C.c_int), ("window_height", C.c_int),
+                ("window_area", C.c_int), ("num_terms", C.c_int), ("scale", C.c_float),
+                ("weights", C.POINTER(C.c_float))]
+
+
+_fp, _dp, _vp, _sz = C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p, C.c_size_t
+_F, _F2, _S = C.POINTER(SavgolFilter), C.POINTER(Savgol2DFilter), C.POINTER(SavgolStream)
+
+# name -> (restype, argtypes); everything include/*.h declares
+SIGNATURES = {
+    # savgolFilter.h
+    "savgol_create": (_F, [C.POINTER(SavgolConfig)]),
+    "savgol_destroy": (None, [_F]),
+    "savgol_apply": (C.c_int, [_F, _fp, _fp, _sz]),
+    "savgol_apply_strided": (C.c_int, [_F, _vp, _sz, _sz, _vp, _sz, _sz, _sz]),
+    "savgol_apply_valid": (_sz, [_F, _fp, _sz, _fp]),
+    # savgol_hip.h: runtime
+    "savgol_hip_device_count": (C.c_int, []),
+    "savgol_hip_set_device": (C.c_int, [C.c_int]),
+    "savgol_hip_get_device": (C.c_int, []),
+    "savgol_hip_synchronize": (C.c_int, [_vp]),
+    "savgol_hip_last_error": (C.c_char_p, []),
+    "savgol_hip_version": (C.c_char_p, []),
+    # savgol_hip.h: 1-D batch
+    "savgol_apply_batch_f32": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "savgol_apply_batch_f64": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "savgol_apply_valid_batch_f32": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "savgol_apply_valid_batch_f64": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "savgol_apply_strided_batch_f32": (C.c_int, [_F, _vp, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
+    # savgol_hip.h: bench utilities
+    "savgol_hip_synth_f32": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_uint64, _vp]),
+    "savgol_hip_synth_f64": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_uint64, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded C ABI.  Raises if libsavgol_hip.so was not built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {_HERE} -j8` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().savgol_hip_last_error().decode()
+
+
+def device_count():
+    return lib().savgol_hip_device_count()
+
+
+def _addr(x):
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return int(x)
+
+
+def _stream(stream):
+    """None -> torch's current stream if torch has a GPU, else the default stream."""
+    if stream is not None:
+        return getattr(stream, "cuda_stream", stream)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.current_stream().cuda_stream
+    except Exception:
+        pass
+    return None
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+class Filter:
+    """RAII wrapper around savgol_create / savgol_destroy with the apply entry points as methods."""
+
+    def __init__(self, half_window, poly_order, derivative=0, time_step=1.0, boundary=SAVGOL_BOUNDARY_POLYNOMIAL):
+        cfg = SavgolConfig(half_window, poly_order, derivative, time_step, boundary)
+        self.ptr = lib().savgol_create(C.byref(cfg))
+        if not self.ptr:
+            raise ValueError("savgol_create rejected the configuration")
+        self.n = half_window
+        self.ws = 2 * half_window + 1
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            lib().savgol_destroy(self.ptr)
+            self.ptr = None
+
+    __del__ = close
+
+    # tables, as numpy copies
+    @property
+    def center_weights(self):
+        return np.array(self.ptr.contents.center_weights[:self.ws], dtype=np.float32)
+
+    @property
+    def edge_weights(self):
+        ew = self.ptr.contents.edge_weights
+        return np.array([list(ew[e][:self.ws]) for e in range(self.n)], dtype=np.float32).reshape(self.n, self.ws)
+
+    @property
+    def dt_scale(self):
+        return np.float32(self.ptr.contents.dt_scale)
+
+    # ---- host-pointer drop-in calls (numpy in, numpy out) ----
+    def apply(self, x, out=None):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x) if out is None else out
+        rc = lib().savgol_apply(self.ptr, _f(x), _f(y), x.size)
+        if rc != 0:
+            raise RuntimeError(f"savgol_apply returned {rc}: {last_error()}")
+        return y
+
+    def apply_valid(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty(max(x.size - 2 * self.n, 1), np.float32)
+        got = lib().savgol_apply_valid(self.ptr, _f(x), x.size, _f(y))
+        return y[:got]
+
+    def apply_strided(self, src, in_stride, in_offset, dst, out_stride, out_offset, count):
+        return lib().savgol_apply_strided(self.ptr, src.ctypes.data, in_stride, in_offset,
+                                          dst.ctypes.data, out_stride, out_offset, count)
+
+    # ---- device-pointer batch calls (torch tensors or raw addresses) ----
+    def apply_batch(self, d_in, d_out, channels, length, in_ld=None, out_ld=None, dtype="f32", valid=False, stream=None):
+        name = f"savgol_apply_{'valid_' if valid else ''}batch_{dtype}"
+        rc = getattr(lib(), name)(self.ptr, _addr(d_in), _addr(d_out), channels, length,
+                                  length if in_ld is None else in_ld,
+                                  (length - 2 * self.n if valid else length) if out_ld is None else out_ld,
+                                  _stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"{name} returned {rc}: {last_error()}")
+
+    def apply_tensor(self, x, valid=False, stream=None):
+        """x: contiguous 2-D torch tensor [channels, length] (float32 or float64) on the GPU."""
+        import torch
+        assert x.is_cuda and x.dim() == 2 and x.is_contiguous()
+        dtype = {torch.float32: "f32", torch.float64: "f64"}[x.dtype]
+        ch, length = x.shape
+        out_len = length - 2 * self.n if valid else length
+        y = torch.empty((ch, out_len), dtype=x.dtype, device=x.device)
+        self.apply_batch(x, y, ch, length, length, out_len, dtype=dtype, valid=valid, stream=stream)
+        return y
+
+
+def synth(tensor, channel0=0, seed=0x5A17601A, stream=None):
+    """Fill a contiguous [channels, length] GPU tensor with the SURVEY 8(d) synthetic workload."""
+    import torch
+    ch, length = tensor.shape
+    fn = {torch.float32: lib().savgol_hip_synth_f32, torch.float64: lib().savgol_hip_synth_f64}[tensor.dtype]
+    rc = fn(tensor.data_ptr(), channel0, ch, length, tensor.stride(0), seed, _stream(stream))
+    if rc != 0:
+        raise RuntimeError(f"savgol_hip_synth returned {rc}: {last_error()}")
+    return tensor

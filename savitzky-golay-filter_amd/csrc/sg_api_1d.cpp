@@ -1,0 +1,288 @@
+// sg_api_1d.cpp -- host side of the 1-D path: the five drop-in entry points of savgolFilter.h and
+// the device-pointer batch entry points of savgol_hip.h.  All arithmetic on samples happens in the
+// HIP kernels (sg_k1d.hpp); this file validates, picks tile geometry and enqueues.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "sg_k1d_host.hpp"
+#include "sg_runtime.hpp"
+
+using sg::DeviceCtx;
+
+// ------------------------------------------------------------------------------------------------
+// lifecycle (host only) -- reference savgol_create / savgol_destroy, src/savgolFilter.c:688-728
+// ------------------------------------------------------------------------------------------------
+extern "C" SavgolFilter *savgol_create(const SavgolConfig *config)
+{
+    if (!config) return nullptr;
+    const int n = config->half_window, m = config->poly_order, d = config->derivative;
+    // same order of checks and the same messages as validate_config (:639-677)
+    if (n == 0 || n > SAVGOL_MAX_HALF_WINDOW) {
+        fprintf(stderr, "savgol: half_window must be in [1, %d], got %d\n", SAVGOL_MAX_HALF_WINDOW, n);
+        return nullptr;
+    }
+    const int ws = 2 * n + 1;
+    if (m >= ws) {
+        fprintf(stderr, "savgol: poly_order must be < window_size (%d), got %d\n", ws, m);
+        return nullptr;
+    }
+    if (d > SAVGOL_MAX_DERIVATIVE) {
+        fprintf(stderr, "savgol: derivative must be ≤ %d, got %d\n", SAVGOL_MAX_DERIVATIVE, d);
+        return nullptr;
+    }
+    if (d > m) {
+        fprintf(stderr, "savgol: derivative (%d) cannot exceed poly_order (%d)\n", d, m);
+        return nullptr;
+    }
+    if (!(config->time_step > 0.0f)) {
+        fprintf(stderr, "savgol: time_step must be > 0, got %f\n", config->time_step);
+        return nullptr;
+    }
+    if (!sg_weights_valid(n, m, d, config->time_step)) {
+        fprintf(stderr, "savgol: half_window %d with poly_order %d exceeds the factorial table (2n+m+1 must be < 76)\n", n, m);
+        return nullptr;
+    }
+    SavgolFilter *f = static_cast<SavgolFilter *>(calloc(1, sizeof(SavgolFilter)));
+    if (!f) {
+        fprintf(stderr, "savgol: failed to allocate filter context\n");
+        return nullptr;
+    }
+    f->config = *config;
+    sg_weights_fill(f);
+    return f;
+}
+
+extern "C" void savgol_destroy(SavgolFilter *filter) { free(filter); }
+
+// ------------------------------------------------------------------------------------------------
+// enqueue one batch
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+enum Variant { FULL = 0, VALID = 1, FULL_POLY_EDGES = 2 /* strided: polynomial edges whatever the mode */ };
+
+inline float dt_inverse(const SavgolFilter *f)      // reference :759
+{
+    return (f->dt_scale != 0.0f) ? (1.0f / f->dt_scale) : 1.0f;
+}
+
+bool filter_sane(const SavgolFilter *f, const char *who)
+{
+    const int n = f->config.half_window;
+    if (n < 1 || n > SAVGOL_MAX_HALF_WINDOW || f->window_size != 2 * n + 1) {
+        sg_set_error("%s: filter struct is not a valid SavgolFilter (half_window %d, window_size %d)", who, n,
+                     f->window_size);
+        return false;
+    }
+    return true;
+}
+
+template <typename T>
+int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_out, size_t channels, size_t length,
+                  size_t in_ld, size_t out_ld, Variant variant, hipStream_t st)
+{
+    if (!f || !d_in || !d_out) { sg_set_error("%s: NULL pointer", who); return -1; }
+    if (!filter_sane(f, who)) return -1;
+    const int n = f->config.half_window, ws = f->window_size;
+    if (length < (size_t)ws) { sg_set_error("%s: data length (%zu) < window size (%d)", who, length, ws); return -1; }
+    if (length > (size_t)1 << 30) { sg_set_error("%s: data length %zu exceeds 2^30 samples per channel", who, length); return -1; }
+    const size_t out_len = (variant == VALID) ? length - 2 * (size_t)n : length;
+    if (in_ld < length || out_ld < out_len) { sg_set_error("%s: row pitch smaller than the row", who); return -1; }
+    if (channels == 0) return 0;
+
+    DeviceCtx *ctx = sg::ctx_get();
+    if (!ctx) return -1;
+
+    constexpr int E = 16 / (int)sizeof(T);
+    constexpr unsigned TW = 64u * 8u * E;
+    const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
+    const bool poly = (mode == SAVGOL_BOUNDARY_POLYNOMIAL);
+
+    sg::Job1D job;
+    memset(&job, 0, sizeof(job));
+    job.in_ld = (long long)in_ld;
+    job.out_ld = (long long)out_ld;
+    job.length = (unsigned)length;
+    job.tiles_per_channel = (unsigned)((length + TW - 1) / TW);
+    job.dt_inv = dt_inverse(f);
+    // which samples the centre kernel stores: the interior when edge rows / VALID take the rest
+    const bool interior_only = (variant == VALID) || poly;
+    job.store_lo = interior_only ? (unsigned)n : 0u;
+    job.store_hi = interior_only ? (unsigned)(length - n) : (unsigned)length;
+    job.out_shift = (variant == VALID) ? (unsigned)n : 0u;
+    job.flags = ((unsigned)mode & sg::JOB_MODE_MASK);
+    if (mode < 0 || mode > 255) job.flags = 255u;                       // unknown mode: zero padding (reference :478-480)
+    if (job.dt_inv != 1.0f) job.flags |= sg::JOB_SCALE;
+    if (((uintptr_t)d_in % 16 == 0) && (in_ld % E == 0)) job.flags |= sg::JOB_VEC_IN;
+    if (((uintptr_t)d_out % 16 == 0) && (out_ld % E == 0) && (job.out_shift % E == 0)) job.flags |= sg::JOB_VEC_OUT;
+
+    sg::Taps taps;
+    memset(&taps, 0, sizeof(taps));
+    memcpy(taps.w, f->center_weights, sizeof(float) * ws);
+
+    const float *d_edges = nullptr;
+    if (poly && variant != VALID) {
+        // rows packed [n][ws]
+        float packed[SAVGOL_MAX_HALF_WINDOW * SAVGOL_MAX_WINDOW];
+        for (int e = 0; e < n; ++e) memcpy(packed + e * ws, f->edge_weights[e], sizeof(float) * ws);
+        d_edges = sg::ctx_table(ctx, packed, sizeof(float) * n * ws, 0x1d00u + (unsigned)n);
+        if (!d_edges) return -1;
+    }
+
+    // split so that a launch indexes < 2^31 tiles
+    const size_t max_ch = (size_t)0x7fffffffu / job.tiles_per_channel;
+    for (size_t c0 = 0; c0 < channels; c0 += max_ch) {
+        const size_t nc = (channels - c0 < max_ch) ? channels - c0 : max_ch;
+        job.in = d_in + c0 * in_ld;
+        job.out = d_out + c0 * out_ld;
+        job.total_tiles = (unsigned)(nc * job.tiles_per_channel);
+        unsigned blocks = (job.total_tiles + 3u) / 4u;
+        const unsigned resident = (unsigned)ctx->cu_count * 4u;          // 4 blocks of 4 waves per CU (LDS bound)
+        if (blocks > resident) blocks = resident;
+        blocks = (blocks + 7u) & ~7u;                                    // the XCD remap wants a multiple of 8
+        if (sg::launch_center<T>(n, job, taps, blocks, st) != 0) return -1;
+    }
+    if (d_edges) {
+        const int rc = sg::launch_edges<T>(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_edges,
+                                           job.dt_inv, job.dt_inv != 1.0f, channels, st);
+        if (rc != 0) { sg_set_error("%s: edge kernel launch failed", who); return -1; }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int savgol_apply_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out, size_t channels, size_t length,
+                           size_t in_ld, size_t out_ld, void *stream)
+{
+    return enqueue_batch<float>("savgol_apply_batch_f32", filter, d_in, d_out, channels, length, in_ld, out_ld, FULL,
+                                static_cast<hipStream_t>(stream));
+}
+
+int savgol_apply_batch_f64(const SavgolFilter *filter, const double *d_in, double *d_out, size_t channels, size_t length,
+                           size_t in_ld, size_t out_ld, void *stream)
+{
+    return enqueue_batch<double>("savgol_apply_batch_f64", filter, d_in, d_out, channels, length, in_ld, out_ld, FULL,
+                                 static_cast<hipStream_t>(stream));
+}
+
+int savgol_apply_valid_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out, size_t channels,
+                                 size_t length, size_t in_ld, size_t out_ld, void *stream)
+{
+    return enqueue_batch<float>("savgol_apply_valid_batch_f32", filter, d_in, d_out, channels, length, in_ld, out_ld,
+                                VALID, static_cast<hipStream_t>(stream));
+}
+
+int savgol_apply_valid_batch_f64(const SavgolFilter *filter, const double *d_in, double *d_out, size_t channels,
+                                 size_t length, size_t in_ld, size_t out_ld, void *stream)
+{
+    return enqueue_batch<double>("savgol_apply_valid_batch_f64", filter, d_in, d_out, channels, length, in_ld, out_ld,
+                                 VALID, static_cast<hipStream_t>(stream));
+}
+
+int savgol_apply_strided_batch_f32(const SavgolFilter *filter, const void *d_in, size_t in_stride, size_t in_offset,
+                                   size_t in_channel_pitch, void *d_out, size_t out_stride, size_t out_offset,
+                                   size_t out_channel_pitch, size_t channels, size_t count, void *stream)
+{
+    const char *who = "savgol_apply_strided_batch_f32";
+    if (!filter || !d_in || !d_out) { sg_set_error("%s: NULL pointer", who); return -1; }
+    if (!filter_sane(filter, who)) return -1;
+    if (count < (size_t)filter->window_size) { sg_set_error("%s: count < window size", who); return -1; }
+    if (channels == 0) return 0;
+    DeviceCtx *ctx = sg::ctx_get();
+    if (!ctx) return -1;
+    // gather the field into dense rows, filter, scatter back (the arena stays locked meanwhile)
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const size_t ld = (count + 3) & ~(size_t)3;
+    float *dense = static_cast<float *>(sg::ctx_arena(ctx, 2 * channels * ld * sizeof(float)));
+    if (!dense) return -1;
+    float *result = dense + channels * ld;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (sg_launch_gather_f32(d_in, in_stride, in_offset, in_channel_pitch, dense, ld, channels, count, st) != 0) {
+        sg_set_error("%s: gather launch failed", who);
+        return -1;
+    }
+    if (enqueue_batch<float>(who, filter, dense, result, channels, count, ld, ld, FULL_POLY_EDGES, st) != 0) return -1;
+    if (sg_launch_scatter_f32(result, ld, d_out, out_stride, out_offset, out_channel_pitch, channels, count, st) != 0) {
+        sg_set_error("%s: scatter launch failed", who);
+        return -1;
+    }
+    // the arena may be reused by the next call: finish before releasing the lock
+    return sg::hip_ok(hipStreamSynchronize(st), who) ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// drop-in host-pointer entry points (reference src/savgolFilter.c:743-934): stage through HBM.
+// ------------------------------------------------------------------------------------------------
+int savgol_apply(const SavgolFilter *filter, const float *input, float *output, size_t length)
+{
+    if (!filter || !input || !output) {
+        fprintf(stderr, "savgol_apply: NULL pointer\n");
+        return -1;
+    }
+    if (length < (size_t)filter->window_size) {
+        fprintf(stderr, "savgol_apply: data length (%lu) < window size (%d)\n", (unsigned long)length, filter->window_size);
+        return -1;
+    }
+    DeviceCtx *ctx = sg::ctx_get();
+    if (!ctx) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const size_t ld = (length + 3) & ~(size_t)3;
+    float *d_in = static_cast<float *>(sg::ctx_arena(ctx, 2 * ld * sizeof(float)));
+    if (!d_in) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
+    float *d_out = d_in + ld;
+    bool ok = sg::hip_ok(hipMemcpyAsync(d_in, input, length * sizeof(float), hipMemcpyHostToDevice, nullptr), "H2D copy");
+    ok = ok && savgol_apply_batch_f32(filter, d_in, d_out, 1, length, ld, ld, nullptr) == 0;
+    ok = ok && sg::hip_ok(hipMemcpy(output, d_out, length * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");
+    if (!ok) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
+    return 0;
+}
+
+size_t savgol_apply_valid(const SavgolFilter *filter, const float *input, size_t input_length, float *output)
+{
+    if (!filter || !input || !output) return 0;
+    if (input_length < (size_t)filter->window_size) return 0;
+    DeviceCtx *ctx = sg::ctx_get();
+    if (!ctx) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const size_t out_len = input_length - 2 * (size_t)filter->config.half_window;
+    const size_t ld = (input_length + 3) & ~(size_t)3;
+    float *d_in = static_cast<float *>(sg::ctx_arena(ctx, 2 * ld * sizeof(float)));
+    if (!d_in) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
+    float *d_out = d_in + ld;
+    bool ok = sg::hip_ok(hipMemcpyAsync(d_in, input, input_length * sizeof(float), hipMemcpyHostToDevice, nullptr), "H2D copy");
+    ok = ok && savgol_apply_valid_batch_f32(filter, d_in, d_out, 1, input_length, ld, ld, nullptr) == 0;
+    ok = ok && sg::hip_ok(hipMemcpy(output, d_out, out_len * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");
+    if (!ok) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
+    return out_len;
+}
+
+int savgol_apply_strided(const SavgolFilter *filter, const void *input, size_t in_stride, size_t in_offset, void *output,
+                         size_t out_stride, size_t out_offset, size_t count)
+{
+    if (!filter || !input || !output) return -1;
+    if (count < (size_t)filter->window_size) return -1;
+    DeviceCtx *ctx = sg::ctx_get();
+    if (!ctx) { fprintf(stderr, "savgol_apply_strided: %s\n", savgol_hip_last_error()); return -1; }
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    // the float fields are picked on the host (pure data movement), the arithmetic runs on the GPU
+    const size_t ld = (count + 3) & ~(size_t)3;
+    float *stage = static_cast<float *>(sg::ctx_pinned(ctx, ld * sizeof(float)));
+    float *d_in = static_cast<float *>(sg::ctx_arena(ctx, 2 * ld * sizeof(float)));
+    if (!stage || !d_in) { fprintf(stderr, "savgol_apply_strided: %s\n", savgol_hip_last_error()); return -1; }
+    float *d_out = d_in + ld;
+    const char *ib = static_cast<const char *>(input) + in_offset;
+    for (size_t i = 0; i < count; ++i) memcpy(&stage[i], ib + i * in_stride, sizeof(float));
+    bool ok = sg::hip_ok(hipMemcpy(d_in, stage, count * sizeof(float), hipMemcpyHostToDevice), "H2D copy");
+    ok = ok && enqueue_batch<float>("savgol_apply_strided", filter, d_in, d_out, 1, count, ld, ld, FULL_POLY_EDGES, nullptr) == 0;
+    ok = ok && sg::hip_ok(hipMemcpy(stage, d_out, count * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");
+    if (!ok) { fprintf(stderr, "savgol_apply_strided: %s\n", savgol_hip_last_error()); return -1; }
+    char *ob = static_cast<char *>(output) + out_offset;
+    for (size_t i = 0; i < count; ++i) memcpy(ob + i * out_stride, &stage[i], sizeof(float));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,254 @@
+// sg_k1d.hpp -- the 1-D sliding-window convolution kernel for gfx950 (CDNA4), templated on the
+// sample type and on the half window N (compile-time so that every tap index is a literal).
+//
+// Reference loop replaced: savgol_apply centre loop, src/savgolFilter.c:763-766 (+ the index
+// remaps of get_padded_sample :442-482 for the non-polynomial boundary modes, + savgol_apply_valid
+// :843-847 through the store window).  The POLYNOMIAL edge rows are a separate tiny kernel
+// (sg1d_edges_kernel below; reference :773-784).
+//
+// Mapping (one 64-lane wave = one tile, waves never talk to each other, no s_barrier):
+//   * a tile is 64*R consecutive outputs of one channel, R = 128 B / sizeof(T) (32 fp32, 16 fp64);
+//   * the wave copies tile + halo from HBM into its private LDS slab with coalesced 16-B loads
+//     (next tile's loads are issued before this tile's arithmetic: register prefetch);
+//   * lane l then owns outputs [l*R, l*R+R): it walks its R+2N inputs once with ds_read_b128 and
+//     feeds each input into every accumulator it touches ("input stationary"): R accumulators in
+//     VGPRs, the 2N+1 taps in SGPRs (they arrive as a by-value kernel argument), one v_fmac per
+//     tap per output, no shuffles, no LDS traffic inside the inner product;
+//   * results go back through the slab so that the global stores are coalesced 16-B rows.
+// The slab is padded by 16 B every 128 B, which makes the lane stride 144 B = 36 banks: the
+// per-lane b128 reads, the per-lane b128 result writes and the row-wise accesses are all
+// bank-conflict free (MI355X_MICROARCH.md, LDS table).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sg_k1d_host.hpp"
+
+namespace sg {
+
+template <typename T> struct V16;
+template <> struct V16<float>  { typedef float4  type; static constexpr int E = 4; };
+template <> struct V16<double> { typedef double2 type; static constexpr int E = 2; };
+
+__device__ __forceinline__ float  vget(const float4 &v, int e)  { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+__device__ __forceinline__ double vget(const double2 &v, int e) { return e == 0 ? v.x : v.y; }
+__device__ __forceinline__ void   vset(float4 &v, int e, float x)  { if (e == 0) v.x = x; else if (e == 1) v.y = x; else if (e == 2) v.z = x; else v.w = x; }
+__device__ __forceinline__ void   vset(double2 &v, int e, double x) { if (e == 0) v.x = x; else v.y = x; }
+
+__device__ __forceinline__ float  fma_t(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// lanes of one wave exchanging data through LDS: order the compiler's memory ops, nothing else
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// index remap of the padded boundary modes (reference get_padded_sample, savgolFilter.c:452-476)
+__device__ __forceinline__ int remap_index(int i, int L, int mode, bool &zero)
+{
+    zero = false;
+    if (mode == SAVGOL_BOUNDARY_REFLECT) {
+        if (i < 0) { i = -i - 1; if (i >= L) i = L - 1; }
+        else       { i = 2 * L - i - 1; if (i < 0) i = 0; }
+    } else if (mode == SAVGOL_BOUNDARY_PERIODIC) {
+        i = ((i % L) + L) % L;
+    } else if (mode == SAVGOL_BOUNDARY_CONSTANT) {
+        i = (i < 0) ? 0 : L - 1;
+    } else {
+        zero = true; i = 0;
+    }
+    return i;
+}
+
+template <typename T, int N>
+struct K1D {
+    typedef typename V16<T>::type VT;
+    static constexpr int E    = V16<T>::E;
+    static constexpr int R    = 8 * E;                       // outputs per lane
+    static constexpr int TW   = 64 * R;                      // outputs per tile
+    static constexpr int NA   = (N + E - 1) / E * E;         // halo rounded to whole vectors
+    static constexpr int OFF  = NA - N;
+    static constexpr int HV   = NA / E;                      // halo vectors per side
+    static constexpr int SV   = 512 + 2 * HV;                // vectors in a slab
+    static constexpr int SL   = SV * E;                      // elements in a slab
+    static constexpr int WQ   = (NA + R + N + E - 1) / E;    // vectors a lane reads
+    static constexpr int SLAB = 16 * (SV + (SV + 7) / 8);    // bytes, padded
+    static constexpr int WAVES = 4;
+    static_assert(2 * HV <= 64, "halo must fit one extra vector per lane");
+    static_assert(WQ <= SV - 8 * 63, "lane 63's window must stay inside the slab");
+};
+
+__device__ __forceinline__ int slab_vec_off(int v) { return 16 * (v + (v >> 3)); }
+
+template <typename T, int N>
+__global__ __launch_bounds__(256, 4) void sg1d_center_kernel(const Job1D job, const Taps taps)
+{
+    typedef K1D<T, N> K;
+    typedef typename K::VT VT;
+    constexpr int E = K::E, R = K::R, TW = K::TW, NA = K::NA, OFF = K::OFF, HV = K::HV;
+
+    __shared__ __attribute__((aligned(16))) char smem[K::WAVES * K::SLAB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, lives in an SGPR
+    char *slab = smem + wave * K::SLAB;
+
+    // blocks that share an XCD (blockIdx % 8, observed round-robin placement) get neighbouring
+    // tiles, so halos re-read by the next tile are L2 hits; placement affects speed only.
+    const unsigned nblk = gridDim.x;
+    const unsigned blk  = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const unsigned nwaves = nblk * K::WAVES;
+
+    const T *__restrict__ gin  = static_cast<const T *>(job.in);
+    T *__restrict__       gout = static_cast<T *>(job.out);
+    const int L = (int)job.length;
+    const int mode = (int)(job.flags & JOB_MODE_MASK);
+
+    VT p0, p1, p2, p3, p4, p5, p6, p7, p8;       // next tile, in flight while this one is computed
+    unsigned tile = blk * K::WAVES + wave;
+
+    auto tile_is_fast = [&](int ts) -> bool {
+        return (job.flags & JOB_VEC_IN) && ts - NA >= 0 && ts + TW + NA <= L;
+    };
+    auto prefetch = [&](unsigned t) {
+        const unsigned c = t / job.tiles_per_channel;
+        const int ts = (int)(t - c * job.tiles_per_channel) * TW;
+        if (tile_is_fast(ts)) {
+            const VT *src = reinterpret_cast<const VT *>(gin + (long long)c * job.in_ld + (ts - NA));
+            p0 = src[lane];       p1 = src[lane + 64];  p2 = src[lane + 128]; p3 = src[lane + 192];
+            p4 = src[lane + 256]; p5 = src[lane + 320]; p6 = src[lane + 384]; p7 = src[lane + 448];
+            if (lane < 2 * HV) p8 = src[512 + lane];
+        }
+    };
+
+    if (tile < job.total_tiles) prefetch(tile);
+
+    while (tile < job.total_tiles) {
+        const unsigned c = tile / job.tiles_per_channel;
+        const int ts = (int)(tile - c * job.tiles_per_channel) * TW;
+        const T *__restrict__ row = gin + (long long)c * job.in_ld;
+
+        // ---- stage tile + halo into the slab ----
+        if (tile_is_fast(ts)) {
+            VT *dst = reinterpret_cast<VT *>(slab + slab_vec_off(lane));     // +64 vectors = +72 slots
+            dst[0] = p0;   dst[72] = p1;  dst[144] = p2; dst[216] = p3;
+            dst[288] = p4; dst[360] = p5; dst[432] = p6; dst[504] = p7;
+            if (lane < 2 * HV) dst[576] = p8;
+        } else {
+            // channel ends / short or unaligned rows: element-wise, with the boundary remap
+            for (int e = lane; e < K::SL; e += 64) {
+                int g = ts - NA + e;
+                bool zero = false;
+                if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
+                const T x = zero ? T(0) : row[g];
+                *reinterpret_cast<T *>(slab + slab_vec_off(e / E) + (e % E) * (int)sizeof(T)) = x;
+            }
+        }
+        const unsigned next = tile + nwaves;
+        if (next < job.total_tiles) prefetch(next);
+        wave_lds_sync();
+
+        // ---- the convolution: lane owns outputs [lane*R, lane*R + R) of the tile ----
+        T acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = T(0);
+        const char *win = slab + 16 * (lane * 9);
+#pragma unroll
+        for (int q = 0; q < K::WQ; ++q) {
+            const VT v = *reinterpret_cast<const VT *>(win + 16 * (q + (q >> 3)));
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const T x = vget(v, e);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int k = q * E + e - r - OFF;             // literal after unrolling
+                    if (k >= 0 && k <= 2 * N) acc[r] = fma_t((T)taps.w[k], x, acc[r]);
+                }
+            }
+        }
+        if (job.flags & JOB_SCALE) {
+            const T s = (T)job.dt_inv;
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] *= s;
+        }
+        wave_lds_sync();                                   // all window reads done before overwrite
+
+        // ---- results back through the slab, then coalesced rows to HBM ----
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            VT o;
+#pragma unroll
+            for (int e = 0; e < E; ++e) vset(o, e, acc[s * E + e]);
+            *reinterpret_cast<VT *>(slab + 16 * (lane * 9 + s)) = o;
+        }
+        wave_lds_sync();
+        T *__restrict__ orow = gout + (long long)c * job.out_ld - (long long)job.out_shift;
+        const bool whole = (job.flags & JOB_VEC_OUT) && ts >= (int)job.store_lo && ts + TW <= (int)job.store_hi;
+        if (whole) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int p = lane + 64 * s;
+                const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off(p));
+                *reinterpret_cast<VT *>(orow + ts + p * E) = o;
+            }
+        } else {
+            for (int e = lane; e < TW; e += 64) {
+                const int g = ts + e;
+                if (g >= (int)job.store_lo && g < (int)job.store_hi)
+                    orow[g] = *reinterpret_cast<const T *>(slab + slab_vec_off(e / E) + (e % E) * (int)sizeof(T));
+            }
+        }
+        wave_lds_sync();                                   // slab is free for the next tile
+        tile = next;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// POLYNOMIAL edge rows (reference savgolFilter.c:773-784): for each channel end, n outputs, each
+// its own 2n+1-tap row of edge_weights.  One wave per (channel, end); lanes hold the taps
+// (lane l: taps l and l+64), the dot product is a wavefront butterfly reduction.
+//   leading : out[e]       = s * sum_k ew[e][k] * in[2n - k]        (reversed data: the reference's
+//                                                                    odd-derivative sign quirk included)
+//   trailing: out[L-1-e]   = s * sum_k ew[e][k] * in[L - ws + k]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void sg1d_edges_kernel(const T *__restrict__ in, T *__restrict__ out,
+                                                        long long in_ld, long long out_ld, long long L,
+                                                        int n, const float *__restrict__ ew,
+                                                        float dt_inv, int apply_scale)
+{
+    const int lane = threadIdx.x;
+    const long long c = blockIdx.x;
+    const bool trailing = blockIdx.y != 0;
+    const int ws = 2 * n + 1;
+    const T *row = in + c * in_ld;
+    T *orow = out + c * out_ld;
+
+    const int k0 = lane, k1 = lane + 64;
+    T x0 = T(0), x1 = T(0);
+    if (k0 < ws) x0 = row[trailing ? (L - ws + k0) : (long long)(2 * n - k0)];
+    if (k1 < ws) x1 = row[trailing ? (L - ws + k1) : (long long)(2 * n - k1)];
+
+    for (int e = 0; e < n; ++e) {
+        const float *w = ew + e * ws;
+        T p = T(0);
+        if (k0 < ws) p = (T)w[k0] * x0;
+        if (k1 < ws) p = fma_t((T)w[k1], x1, p);
+        p = wave_sum(p);
+        if (apply_scale) p *= (T)dt_inv;
+        if (lane == 0) orow[trailing ? (L - 1 - e) : (long long)e] = p;
+    }
+}
+
+}  // namespace sg

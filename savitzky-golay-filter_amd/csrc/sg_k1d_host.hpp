@@ -1,0 +1,91 @@
+// sg_k1d_host.hpp -- what the host side needs to know about the 1-D kernels: the by-value kernel
+// arguments and the launchers exported by the kernel objects.  No device code in here.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include "sg_internal.h"
+
+namespace sg {
+
+struct Taps { float w[SAVGOL_MAX_WINDOW]; };       // by-value kernarg -> s_load -> SGPRs
+
+struct Job1D {
+    const void *in;
+    void       *out;
+    long long   in_ld, out_ld;          // elements between channels
+    unsigned    length;                 // samples per channel (< 2^31, as in the reference's int indexing)
+    unsigned    tiles_per_channel;
+    unsigned    total_tiles;            // channels * tiles_per_channel (< 2^31, the host splits bigger jobs)
+    unsigned    store_lo, store_hi;     // sample indices g whose result is stored ...
+    unsigned    out_shift;              // ... at out[c*out_ld + g - out_shift]
+    float       dt_inv;
+    unsigned    flags;                  // FLAG_* below; boundary mode in the low byte
+};
+enum : unsigned {
+    JOB_MODE_MASK  = 0xffu,             // SavgolBoundaryMode value; 0/unknown: out-of-range reads are 0
+    JOB_SCALE      = 1u << 8,           // multiply by dt_inv (dt_inv != 1)
+    JOB_VEC_IN     = 1u << 9,           // input rows are 16-B aligned
+    JOB_VEC_OUT    = 1u << 10,          // output rows (after out_shift) are 16-B aligned
+};
+
+}  // namespace sg
+
+extern "C" {
+// one object per (type, half-window group), see the Makefile; each returns 1 if it owns n
+int sg1d_launch_f32_g0(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f32_g1(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f32_g2(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f32_g3(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f64_g0(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f64_g1(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f64_g2(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f64_g3(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+
+int sg1d_launch_edges_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
+                          const float *d_edges, float dt_inv, int apply_scale, size_t channels, void *st);
+int sg1d_launch_edges_f64(const double *in, double *out, long long in_ld, long long out_ld, long long L, int n,
+                          const float *d_edges, float dt_inv, int apply_scale, size_t channels, void *st);
+int sg_launch_gather_f32(const void *base, size_t stride, size_t offset, size_t pitch, float *dst, size_t dst_ld,
+                         size_t channels, size_t count, void *st);
+int sg_launch_scatter_f32(const float *src, size_t src_ld, void *base, size_t stride, size_t offset, size_t pitch,
+                          size_t channels, size_t count, void *st);
+}
+
+namespace sg {
+
+template <typename T> int launch_center(int n, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st);
+template <> inline int launch_center<float>(int n, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st)
+{
+    const int hit = sg1d_launch_f32_g0(n, &job, &taps, grid, st) || sg1d_launch_f32_g1(n, &job, &taps, grid, st) ||
+                    sg1d_launch_f32_g2(n, &job, &taps, grid, st) || sg1d_launch_f32_g3(n, &job, &taps, grid, st);
+    if (!hit) { sg_set_error("no fp32 kernel for half_window %d", n); return -1; }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sg_set_error("1-D kernel launch failed: %s", hipGetErrorString(e)); return -1; }
+    return 0;
+}
+template <> inline int launch_center<double>(int n, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st)
+{
+    const int hit = sg1d_launch_f64_g0(n, &job, &taps, grid, st) || sg1d_launch_f64_g1(n, &job, &taps, grid, st) ||
+                    sg1d_launch_f64_g2(n, &job, &taps, grid, st) || sg1d_launch_f64_g3(n, &job, &taps, grid, st);
+    if (!hit) { sg_set_error("no fp64 kernel for half_window %d", n); return -1; }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sg_set_error("1-D kernel launch failed: %s", hipGetErrorString(e)); return -1; }
+    return 0;
+}
+
+template <typename T>
+int launch_edges(const T *in, T *out, long long in_ld, long long out_ld, long long L, int n, const float *d_edges,
+                 float dt_inv, int apply_scale, size_t channels, hipStream_t st);
+template <> inline int launch_edges<float>(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
+                                           const float *d_edges, float dt_inv, int apply_scale, size_t channels, hipStream_t st)
+{
+    return sg1d_launch_edges_f32(in, out, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale, channels, st);
+}
+template <> inline int launch_edges<double>(const double *in, double *out, long long in_ld, long long out_ld, long long L, int n,
+                                            const float *d_edges, float dt_inv, int apply_scale, size_t channels, hipStream_t st)
+{
+    return sg1d_launch_edges_f64(in, out, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale, channels, st);
+}
+
+}  // namespace sg

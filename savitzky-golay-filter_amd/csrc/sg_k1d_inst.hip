@@ -1,0 +1,31 @@
+// sg_k1d_inst.hip -- instantiates sg1d_center_kernel<SG_T, N> for N in [SG_NLO, SG_NHI] and exports
+// one launcher for that group.  Compiled several times by the Makefile (one object per group) so
+// the 64 heavily unrolled instantiations build in parallel.
+#include "sg_k1d.hpp"
+
+#if !defined(SG_T) || !defined(SG_NLO) || !defined(SG_NHI) || !defined(SG_FN)
+#error "compile with -DSG_T=float|double -DSG_NLO=.. -DSG_NHI=.. -DSG_FN=symbol"
+#endif
+
+namespace sg {
+
+template <typename T, int N, int HI>
+struct Dispatch1D {
+    static int go(int n, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st)
+    {
+        if (n == N) {
+            hipLaunchKernelGGL((sg1d_center_kernel<T, N>), dim3(grid), dim3(256), 0, st, job, taps);
+            return 1;
+        }
+        if constexpr (N < HI) return Dispatch1D<T, N + 1, HI>::go(n, job, taps, grid, st);
+        else return 0;
+    }
+};
+
+}  // namespace sg
+
+// returns 1 if this group owns half window n (kernel enqueued), 0 otherwise
+extern "C" int SG_FN(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream)
+{
+    return sg::Dispatch1D<SG_T, SG_NLO, SG_NHI>::go(n, *job, *taps, grid, static_cast<hipStream_t>(stream));
+}

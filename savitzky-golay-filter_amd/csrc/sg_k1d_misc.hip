@@ -1,0 +1,147 @@
+// sg_k1d_misc.hip -- the small 1-D kernels around sg1d_center_kernel: POLYNOMIAL edge rows,
+// array-of-structs gather/scatter for the strided entry point, and the synthetic-signal generator
+// used by bench.py and the full-size tests.
+#include "sg_k1d.hpp"
+
+namespace sg {
+
+// element i of channel c is the float at base + c*pitch + i*stride + offset (bytes); any alignment
+__global__ __launch_bounds__(256) void sg_gather_f32_kernel(const char *__restrict__ base, size_t stride, size_t offset,
+                                                            size_t pitch, float *__restrict__ dst, size_t dst_ld,
+                                                            size_t count)
+{
+    const size_t c = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        float v;
+        __builtin_memcpy(&v, base + c * pitch + i * stride + offset, sizeof(float));
+        dst[c * dst_ld + i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_scatter_f32_kernel(const float *__restrict__ src, size_t src_ld,
+                                                             char *__restrict__ base, size_t stride, size_t offset,
+                                                             size_t pitch, size_t count)
+{
+    const size_t c = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = src[c * src_ld + i];
+        __builtin_memcpy(base + c * pitch + i * stride + offset, &v, sizeof(float));
+    }
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// x[c][i] = sin(2 pi f_c i) + 0.5 sin(2 pi 7.3 f_c i + phi_c) + 0.1 u(c,i), evaluated in
+// fp64 and rounded once to T.  Counter based: every value depends only on (seed, c, i).
+template <typename T>
+__global__ __launch_bounds__(256) void sg_synth_kernel(T *__restrict__ dst, size_t channel0, size_t length, size_t ld,
+                                                       uint64_t seed)
+{
+    const size_t c = blockIdx.y;
+    const uint64_t cg = channel0 + c;
+    const double two_pi = 6.283185307179586476925286766559;
+    const double f = (double)(1 + (cg % 97)) / 4096.0;
+    const double phi = two_pi * (double)(cg % 13) / 13.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < length; i += (size_t)gridDim.x * blockDim.x) {
+        const double u = (double)(mix64(seed ^ (cg << 32) ^ (uint64_t)i) >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+        const double t = (double)i;
+        dst[c * ld + i] = (T)(sin(two_pi * f * t) + 0.5 * sin(two_pi * 7.3 * f * t + phi) + 0.1 * u);
+    }
+}
+
+template <typename T>
+static int enqueue_edges(const T *in, T *out, long long in_ld, long long out_ld, long long L, int n,
+                        const float *d_edges, float dt_inv, int apply_scale, size_t channels, hipStream_t st)
+{
+    size_t done = 0;
+    while (done < channels) {                       // gridDim.x limit
+        const size_t chunk = (channels - done) < 1048576 ? (channels - done) : 1048576;
+        hipLaunchKernelGGL((sg1d_edges_kernel<T>), dim3((unsigned)chunk, 2), dim3(64), 0, st,
+                           in + done * in_ld, out + done * out_ld, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale);
+        done += chunk;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <typename T>
+static int enqueue_synth(T *dst, size_t channel0, size_t channels, size_t length, size_t ld, uint64_t seed, hipStream_t st)
+{
+    unsigned gx = (unsigned)((length + 255) / 256);
+    if (gx > 4096) gx = 4096;
+    size_t done = 0;
+    while (done < channels) {
+        const size_t chunk = (channels - done) < 65535 ? (channels - done) : 65535;
+        hipLaunchKernelGGL((sg_synth_kernel<T>), dim3(gx, (unsigned)chunk), dim3(256), 0, st,
+                           dst + done * ld, channel0 + done, length, ld, seed);
+        done += chunk;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace sg
+
+extern "C" {
+
+int sg1d_launch_edges_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
+                          const float *d_edges, float dt_inv, int apply_scale, size_t channels, void *st)
+{
+    return sg::enqueue_edges<float>(in, out, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale, channels,
+                                   static_cast<hipStream_t>(st));
+}
+
+int sg1d_launch_edges_f64(const double *in, double *out, long long in_ld, long long out_ld, long long L, int n,
+                          const float *d_edges, float dt_inv, int apply_scale, size_t channels, void *st)
+{
+    return sg::enqueue_edges<double>(in, out, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale, channels,
+                                    static_cast<hipStream_t>(st));
+}
+
+int sg_launch_gather_f32(const void *base, size_t stride, size_t offset, size_t pitch, float *dst, size_t dst_ld,
+                         size_t channels, size_t count, void *st)
+{
+    unsigned gx = (unsigned)((count + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    for (size_t done = 0; done < channels; done += 65535) {
+        const size_t chunk = (channels - done) < 65535 ? (channels - done) : 65535;
+        hipLaunchKernelGGL(sg::sg_gather_f32_kernel, dim3(gx, (unsigned)chunk), dim3(256), 0, static_cast<hipStream_t>(st),
+                           static_cast<const char *>(base) + done * pitch, stride, offset, pitch, dst + done * dst_ld,
+                           dst_ld, count);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int sg_launch_scatter_f32(const float *src, size_t src_ld, void *base, size_t stride, size_t offset, size_t pitch,
+                          size_t channels, size_t count, void *st)
+{
+    unsigned gx = (unsigned)((count + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    for (size_t done = 0; done < channels; done += 65535) {
+        const size_t chunk = (channels - done) < 65535 ? (channels - done) : 65535;
+        hipLaunchKernelGGL(sg::sg_scatter_f32_kernel, dim3(gx, (unsigned)chunk), dim3(256), 0, static_cast<hipStream_t>(st),
+                           src + done * src_ld, src_ld, static_cast<char *>(base) + done * pitch, stride, offset, pitch,
+                           count);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int savgol_hip_synth_f32(float *d_dst, size_t channel0, size_t channels, size_t length, size_t ld, uint64_t seed, void *st)
+{
+    if (!d_dst || ld < length) { sg_set_error("savgol_hip_synth_f32: bad arguments"); return -1; }
+    if (channels == 0 || length == 0) return 0;
+    return sg::enqueue_synth<float>(d_dst, channel0, channels, length, ld, seed, static_cast<hipStream_t>(st));
+}
+
+int savgol_hip_synth_f64(double *d_dst, size_t channel0, size_t channels, size_t length, size_t ld, uint64_t seed, void *st)
+{
+    if (!d_dst || ld < length) { sg_set_error("savgol_hip_synth_f64: bad arguments"); return -1; }
+    if (channels == 0 || length == 0) return 0;
+    return sg::enqueue_synth<double>(d_dst, channel0, channels, length, ld, seed, static_cast<hipStream_t>(st));
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+// sg_runtime.cpp -- device contexts, weight-table cache, error text, runtime queries of savgol_hip.h.
+#include "sg_runtime.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace sg {
+
+static thread_local char tl_error[512] = "";
+static thread_local int  tl_device = -1;
+
+static std::mutex  g_mu;
+static DeviceCtx  *g_ctx[64] = {nullptr};
+
+bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    sg_set_error("%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return false;
+}
+
+DeviceCtx *ctx_get()
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        sg_set_error("no usable HIP device (this library has no CPU fallback)");
+        return nullptr;
+    }
+    int dev = tl_device;
+    if (dev < 0) {
+        if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
+    } else if (!hip_ok(hipSetDevice(dev), "hipSetDevice")) {
+        return nullptr;
+    }
+    if (dev < 0 || dev >= 64) { sg_set_error("device ordinal %d out of range", dev); return nullptr; }
+
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_ctx[dev]) {
+        hipDeviceProp_t prop;
+        if (!hip_ok(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) return nullptr;
+        DeviceCtx *c = new DeviceCtx();
+        c->ordinal = dev;
+        c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        g_ctx[dev] = c;
+    }
+    return g_ctx[dev];
+}
+
+static uint64_t fnv1a(const void *p, size_t n, uint64_t h)
+{
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+const float *ctx_table(DeviceCtx *ctx, const void *host, size_t bytes, uint64_t salt)
+{
+    const uint64_t key = fnv1a(host, bytes, 0xcbf29ce484222325ull ^ salt);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    for (const TableEntry &t : ctx->tables)
+        if (t.key == key && t.bytes == bytes) return t.dev;
+    if (ctx->tables.size() >= 256) {               // bounded: drop the oldest half
+        if (!hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize")) return nullptr;
+        for (size_t i = 0; i < 128; ++i) (void)hipFree(ctx->tables[i].dev);
+        ctx->tables.erase(ctx->tables.begin(), ctx->tables.begin() + 128);
+    }
+    float *dev = nullptr;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&dev), bytes), "hipMalloc(weight table)")) return nullptr;
+    if (!hip_ok(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(weight table)")) {
+        (void)hipFree(dev);
+        return nullptr;
+    }
+    ctx->tables.push_back(TableEntry{key, bytes, dev});
+    return dev;
+}
+
+void *ctx_arena(DeviceCtx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->arena_bytes) return ctx->arena;
+    if (ctx->arena) { (void)hipFree(ctx->arena); ctx->arena = nullptr; ctx->arena_bytes = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    void *p = nullptr;
+    if (!hip_ok(hipMalloc(&p, want), "hipMalloc(scratch)")) return nullptr;
+    ctx->arena = p;
+    ctx->arena_bytes = want;
+    return p;
+}
+
+void *ctx_pinned(DeviceCtx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pinned_bytes) return ctx->pinned;
+    if (ctx->pinned) { (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_bytes = 0; }
+    void *p = nullptr;
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    if (!hip_ok(hipHostMalloc(&p, want, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
+    ctx->pinned = p;
+    ctx->pinned_bytes = want;
+    return p;
+}
+
+}  // namespace sg
+
+extern "C" {
+
+void sg_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(sg::tl_error, sizeof(sg::tl_error), fmt, ap);
+    va_end(ap);
+}
+
+const char *savgol_hip_last_error(void) { return sg::tl_error; }
+const char *savgol_hip_version(void) { return "savgol-hip 0.1 (gfx950)"; }
+
+int savgol_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int savgol_hip_set_device(int ordinal)
+{
+    if (ordinal < 0 || ordinal >= savgol_hip_device_count()) {
+        sg_set_error("savgol_hip_set_device: no device %d", ordinal);
+        return -1;
+    }
+    if (!sg::hip_ok(hipSetDevice(ordinal), "hipSetDevice")) return -1;
+    sg::tl_device = ordinal;
+    return 0;
+}
+
+int savgol_hip_get_device(void)
+{
+    if (sg::tl_device >= 0) return sg::tl_device;
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return d;
+}
+
+int savgol_hip_synchronize(void *stream)
+{
+    return sg::hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize") ? 0 : -1;
+}
+
+}  // extern "C"
