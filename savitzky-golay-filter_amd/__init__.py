@@ -92,6 +92,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {_HERE} -j8` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
+        try:                # if torch is around, let it load ITS HIP runtime first so both share one copy
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch
@@ -147,9 +151,9 @@ class Filter:
         self.ws = 2 * half_window + 1
 
     def close(self):
-        if getattr(self, "ptr", None):
-            lib().savgol_destroy(self.ptr)
-            self.ptr = None
+        if getattr(self, "ptr", None) and _lib is not None:      # (_lib is gone at interpreter shutdown)
+            _lib.savgol_destroy(self.ptr)
+        self.ptr = None
 
     __del__ = close
 

@@ -138,7 +138,9 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         job.out = d_out + c0 * out_ld;
         job.total_tiles = (unsigned)(nc * job.tiles_per_channel);
         unsigned blocks = (job.total_tiles + 3u) / 4u;
-        const unsigned resident = (unsigned)ctx->cu_count * 4u;          // 4 blocks of 4 waves per CU (LDS bound)
+        static const char *env_bpc = getenv("SAVGOL_HIP_BLOCKS_PER_CU");           // tuning knob (default 4: LDS bound)
+        const unsigned bpc = env_bpc ? (unsigned)atoi(env_bpc) : 4u;
+        const unsigned resident = (unsigned)ctx->cu_count * (bpc ? bpc : 4u);
         if (blocks > resident) blocks = resident;
         blocks = (blocks + 7u) & ~7u;                                    // the XCD remap wants a multiple of 8
         if (sg::launch_center<T>(n, job, taps, blocks, st) != 0) return -1;

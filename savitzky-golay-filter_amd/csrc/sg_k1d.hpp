@@ -27,6 +27,21 @@
 
 namespace sg {
 
+#ifdef SG_STAMPS   // diagnostic build only (tools/stamp_1d.hip): phase timestamps of block 0 / wave 0
+__device__ unsigned long long *g_stamps;
+__device__ __forceinline__ void stamp(bool on, int it, int slot)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (on && it < 64 && (threadIdx.x & 63) == 0) g_stamps[it * 8 + slot] = t;
+}
+#define SG_STAMP(slot) stamp(stamp_on, stamp_it, slot)
+#else
+#define SG_STAMP(slot) do {} while (0)
+#endif
+
 template <typename T> struct V16;
 template <> struct V16<float>  { typedef float4  type; static constexpr int E = 4; };
 template <> struct V16<double> { typedef double2 type; static constexpr int E = 2; };
@@ -108,15 +123,23 @@ __global__ __launch_bounds__(256, 4) void sg1d_center_kernel(const Job1D job, co
     const int mode = (int)(job.flags & JOB_MODE_MASK);
 
     VT p0, p1, p2, p3, p4, p5, p6, p7, p8;       // next tile, in flight while this one is computed
-    unsigned tile = blk * K::WAVES + wave;
 
-    auto tile_is_fast = [&](int ts) -> bool {
+    // Work distribution.  Round k covers tiles [k*nwaves, (k+1)*nwaves); inside a round a wave takes
+    // the tile at `slot`, and slots rotate by ROT from round to round.  Without the rotation a wave
+    // would always land on the same tile-in-channel index whenever nwaves and tiles_per_channel share
+    // factors, so the few waves that own channel ends (slower, see below) would own ONLY channel ends.
+    constexpr unsigned ROT = 67;
+    unsigned slot = blk * K::WAVES + wave;
+    unsigned base = 0;
+
+    // a tile is "full" when every 16-B vector of tile + halo lies inside the row: the common case
+    auto tile_is_full = [&](int ts) -> bool {
         return (job.flags & JOB_VEC_IN) && ts - NA >= 0 && ts + TW + NA <= L;
     };
     auto prefetch = [&](unsigned t) {
         const unsigned c = t / job.tiles_per_channel;
         const int ts = (int)(t - c * job.tiles_per_channel) * TW;
-        if (tile_is_fast(ts)) {
+        if (tile_is_full(ts)) {
             const VT *src = reinterpret_cast<const VT *>(gin + (long long)c * job.in_ld + (ts - NA));
             p0 = src[lane];       p1 = src[lane + 64];  p2 = src[lane + 128]; p3 = src[lane + 192];
             p4 = src[lane + 256]; p5 = src[lane + 320]; p6 = src[lane + 384]; p7 = src[lane + 448];
@@ -124,32 +147,62 @@ __global__ __launch_bounds__(256, 4) void sg1d_center_kernel(const Job1D job, co
         }
     };
 
-    if (tile < job.total_tiles) prefetch(tile);
+    if (base + slot < job.total_tiles) prefetch(base + slot);
 
-    while (tile < job.total_tiles) {
+#ifdef SG_STAMPS
+    const bool stamp_on = (blockIdx.x == 8 && wave == 1);
+    int stamp_it = -1;
+#endif
+    while (base + slot < job.total_tiles) {
+#ifdef SG_STAMPS
+        ++stamp_it;
+#endif
+        SG_STAMP(0);
+        const unsigned tile = base + slot;
         const unsigned c = tile / job.tiles_per_channel;
         const int ts = (int)(tile - c * job.tiles_per_channel) * TW;
         const T *__restrict__ row = gin + (long long)c * job.in_ld;
 
         // ---- stage tile + halo into the slab ----
-        if (tile_is_fast(ts)) {
+        if (tile_is_full(ts)) {
             VT *dst = reinterpret_cast<VT *>(slab + slab_vec_off(lane));     // +64 vectors = +72 slots
             dst[0] = p0;   dst[72] = p1;  dst[144] = p2; dst[216] = p3;
             dst[288] = p4; dst[360] = p5; dst[432] = p6; dst[504] = p7;
             if (lane < 2 * HV) dst[576] = p8;
         } else {
-            // channel ends / short or unaligned rows: element-wise, with the boundary remap
+            // Channel ends, short rows, rows without 16-B alignment.  Vectors that lie wholly inside the
+            // row are still moved as vectors; the rest (the part of the halo that sticks out of the row,
+            // remapped per boundary mode; everything if the row is unaligned) goes element by element.
+            const bool vec = (job.flags & JOB_VEC_IN) != 0;
+            const int lim = L + NA;                                      // nothing beyond is ever used
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const int v = lane + 64 * s;
+                const int g0 = ts - NA + v * E;
+                if (v < K::SV && vec && g0 >= 0 && g0 + E <= L)
+                    *reinterpret_cast<VT *>(slab + slab_vec_off(v)) = *reinterpret_cast<const VT *>(row + g0);
+            }
+#pragma unroll 4
             for (int e = lane; e < K::SL; e += 64) {
                 int g = ts - NA + e;
-                bool zero = false;
-                if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
-                const T x = zero ? T(0) : row[g];
-                *reinterpret_cast<T *>(slab + slab_vec_off(e / E) + (e % E) * (int)sizeof(T)) = x;
+                const int g0 = g - (e % E);
+                const bool direct = vec && g0 >= 0 && g0 + E <= L;
+                if (!direct && g < lim) {
+                    bool zero = false;
+                    if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
+                    const T x = zero ? T(0) : row[g];
+                    *reinterpret_cast<T *>(slab + slab_vec_off(e / E) + (e % E) * (int)sizeof(T)) = x;
+                }
             }
         }
-        const unsigned next = tile + nwaves;
-        if (next < job.total_tiles) prefetch(next);
+        SG_STAMP(1);
+        // next round
+        unsigned nslot = slot + ROT;
+        if (nslot >= nwaves) nslot -= nwaves;
+        const unsigned nbase = base + nwaves;
+        if (nbase + nslot < job.total_tiles) prefetch(nbase + nslot);
         wave_lds_sync();
+        SG_STAMP(2);
 
         // ---- the convolution: lane owns outputs [lane*R, lane*R + R) of the tile ----
         T acc[R];
@@ -175,6 +228,7 @@ __global__ __launch_bounds__(256, 4) void sg1d_center_kernel(const Job1D job, co
             for (int r = 0; r < R; ++r) acc[r] *= s;
         }
         wave_lds_sync();                                   // all window reads done before overwrite
+        SG_STAMP(3);
 
         // ---- results back through the slab, then coalesced rows to HBM ----
 #pragma unroll
@@ -186,7 +240,8 @@ __global__ __launch_bounds__(256, 4) void sg1d_center_kernel(const Job1D job, co
         }
         wave_lds_sync();
         T *__restrict__ orow = gout + (long long)c * job.out_ld - (long long)job.out_shift;
-        const bool whole = (job.flags & JOB_VEC_OUT) && ts >= (int)job.store_lo && ts + TW <= (int)job.store_hi;
+        const int lo = (int)job.store_lo, hi = (int)job.store_hi;
+        const bool whole = (job.flags & JOB_VEC_OUT) && ts >= lo && ts + TW <= hi;
         if (whole) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
@@ -195,14 +250,26 @@ __global__ __launch_bounds__(256, 4) void sg1d_center_kernel(const Job1D job, co
                 *reinterpret_cast<VT *>(orow + ts + p * E) = o;
             }
         } else {
-            for (int e = lane; e < TW; e += 64) {
-                const int g = ts + e;
-                if (g >= (int)job.store_lo && g < (int)job.store_hi)
-                    orow[g] = *reinterpret_cast<const T *>(slab + slab_vec_off(e / E) + (e % E) * (int)sizeof(T));
+            // first / last tile of a channel (the stored range ends inside it) or unaligned output rows
+            const bool vec = (job.flags & JOB_VEC_OUT) != 0;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int p = lane + 64 * s;
+                const int g0 = ts + p * E;
+                const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off(p));
+                if (vec && g0 >= lo && g0 + E <= hi) {
+                    *reinterpret_cast<VT *>(orow + g0) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if (g0 + e >= lo && g0 + e < hi) orow[g0 + e] = vget(o, e);
+                }
             }
         }
         wave_lds_sync();                                   // slab is free for the next tile
-        tile = next;
+        SG_STAMP(4);
+        slot = nslot;
+        base = nbase;
     }
 }
 

@@ -3,6 +3,9 @@
 // the 64 heavily unrolled instantiations build in parallel.
 #include "sg_k1d.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 #if !defined(SG_T) || !defined(SG_NLO) || !defined(SG_NHI) || !defined(SG_FN)
 #error "compile with -DSG_T=float|double -DSG_NLO=.. -DSG_NHI=.. -DSG_FN=symbol"
 #endif
@@ -14,6 +17,15 @@ struct Dispatch1D {
     static int go(int n, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st)
     {
         if (n == N) {
+            static const bool debug = getenv("SAVGOL_HIP_DEBUG") != nullptr;
+            if (debug) {
+                int nb = -1;
+                hipFuncAttributes fa;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg1d_center_kernel<T, N>, 256, 0);
+                (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(sg1d_center_kernel<T, N>));
+                fprintf(stderr, "[savgol-hip] sg1d_center_kernel<%s,%d>: grid %u x 256, occupancy API %d blocks/CU, %d VGPR, %zu B LDS\n",
+                        sizeof(T) == 4 ? "float" : "double", N, grid, nb, fa.numRegs, fa.sharedSizeBytes);
+            }
             hipLaunchKernelGGL((sg1d_center_kernel<T, N>), dim3(grid), dim3(256), 0, st, job, taps);
             return 1;
         }

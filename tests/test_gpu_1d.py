@@ -6,6 +6,8 @@ Tolerances, stated once:
   * fp64 kernels vs the same oracle:                                         TOL_F64  = 1e-12
   * fp32 kernels vs the reference's own fp32 output (golden fixtures): the reference itself sits
     up to ~1e-6 from the oracle (4 chains, separate mul/add), so             TOL_GOLD = 2e-6
+  * derivative filters (d >= 1) amplify rounding (sum|w||x| >> max|out|): the reference's own fp32 paths
+    disagree with each other by 1.3e-6 there, the bound is      TOL_F32_DERIV = 2e-6
   * order-10 / 4th-derivative case (weights cancel catastrophically; the reference's own fp32 result
     is 1e-5 off the oracle there) uses the looser bound stated at the test.
 """
@@ -19,7 +21,7 @@ from tests.golden.make_golden import APPLY_CASES
 
 pytestmark = pytest.mark.gpu
 
-TOL_F32, TOL_F64, TOL_GOLD = 1e-6, 1e-12, 2e-6
+TOL_F32, TOL_F32_DERIV, TOL_F64, TOL_GOLD = 1e-6, 2e-6, 1e-12, 2e-6
 
 
 @pytest.fixture(scope="module")
@@ -51,7 +53,7 @@ def test_savgol_apply_matches_reference_golden(sg, sgo, golden, torch_gpu, ci):
         y = f.apply(x)
         want = g[f"c{ci}_mode{mode}_out"]
         hi = sgo.Filter(n, m, d, dt, mode).apply_f64(x.astype(np.float64))
-        assert normwise(y, hi) < (2e-5 if hard else TOL_F32), (ci, mode, normwise(y, hi))
+        assert normwise(y, hi) < (2e-5 if hard else TOL_F32 if d == 0 else TOL_F32_DERIV), (ci, mode, normwise(y, hi))
         assert normwise(y, want) < (4e-5 if hard else TOL_GOLD), (ci, mode, normwise(y, want))
     f = sg.Filter(n, m, d, dt, 0)
     v = f.apply_valid(x)
@@ -130,7 +132,7 @@ def test_batch_every_half_window(sg, sgo, torch_gpu, n, dtype):
     m = min(4, 2 * n)
     d = int(rng.integers(0, min(m, 2) + 1))
     dt = float(rng.choice([1.0, 0.5]))
-    tdt, ndt, tol = (torch.float32, np.float32, TOL_F32) if dtype == "f32" else (torch.float64, np.float64, TOL_F64)
+    tdt, ndt, tol = (torch.float32, np.float32, TOL_F32 if d == 0 else TOL_F32_DERIV) if dtype == "f32" else (torch.float64, np.float64, TOL_F64)
     tile = 2048 if dtype == "f32" else 1024
     ch = 3
     for length in (2 * n + 1, tile - 1, tile + 2 * n + 5, 3 * tile):
