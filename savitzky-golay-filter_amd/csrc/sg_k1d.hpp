@@ -99,6 +99,104 @@ struct K1D {
 
 __device__ __forceinline__ int slab_vec_off(int v) { return 16 * (v + (v >> 3)); }
 
+
+// ---------------------------------------------------------------------------------------------
+// The inner product, "input stationary": walk the lane's window once, feed every input into all
+// the accumulators it touches.  acc[r] = sum_k w[k] * x[r + k + OFF], k ascending, one FMA chain.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int N>
+struct Conv {                      // generic form (used for fp64): one v_fma per tap per output
+    typedef K1D<T, N> K;
+    typedef typename K::VT VT;
+    static __device__ __forceinline__ void run(const char *win, const Taps &taps, T (&acc)[K::R])
+    {
+        constexpr int E = K::E, R = K::R, OFF = K::OFF;
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = T(0);
+#pragma unroll
+        for (int q = 0; q < K::WQ; ++q) {
+            const VT v = *reinterpret_cast<const VT *>(win + 16 * (q + (q >> 3)));
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const T x = vget(v, e);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int k = q * E + e - r - OFF;             // literal after unrolling
+                    if (k >= 0 && k <= 2 * N) acc[r] = fma_t((T)taps.w[k], x, acc[r]);
+                }
+            }
+        }
+    }
+};
+
+// fp32: plain v_fma_f32 runs at half the packed rate on CDNA4 (a wave64 VALU op takes 4 cycles either
+// way), so the taps loop is written with v_pk_fma_f32: accumulators live as pairs (acc[2j], acc[2j+1]),
+// inputs as pairs (x[i], x[i+1]), and one instruction does  pair_j += w[k] * (x[i], x[i+1])  with
+// i = 2j + k + OFF.  The tap is broadcast out of an aligned SGPR pair with op_sel, so the 65 taps still
+// occupy 66 SGPRs; pairs that start at an odd i are assembled with one v_pk_mov_b32 each and then
+// shared by up to 16 accumulator pairs.  Written as inline asm because the compiler's own packing of
+// this loop builds (w[k], w[k-1]) SGPR pairs instead and spills hundreds of SGPRs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int SEL>
+__device__ __forceinline__ void pk_fma_bcast(f32x2 &acc, const f32x2 wpair, const f32x2 x)
+{
+    if constexpr (SEL == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
+}
+
+// (a.y, b.x): the input pair that straddles two aligned pairs
+__device__ __forceinline__ f32x2 pk_straddle(const f32x2 a, const f32x2 b)
+{
+    f32x2 o;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+
+template <int N>
+struct Conv<float, N> {
+    typedef K1D<float, N> K;
+    // all accumulator pairs fed by the input pair that starts at window index I
+    template <int I, int J = 0>
+    static __device__ __forceinline__ void feed(f32x2 (&A)[K::R / 2], const f32x2 (&W)[33], const f32x2 x)
+    {
+        if constexpr (J < K::R / 2) {
+            constexpr int k = I - 2 * J - K::OFF;
+            if constexpr (k >= 0 && k <= 2 * N) pk_fma_bcast<(k & 1)>(A[J], W[k >> 1], x);
+            feed<I, J + 1>(A, W, x);
+        }
+    }
+    template <int Q>
+    static __device__ __forceinline__ void quads(const char *win, f32x2 (&A)[K::R / 2], const f32x2 (&W)[33], f32x2 prev)
+    {
+        if constexpr (Q < K::WQ) {
+            const float4 v = *reinterpret_cast<const float4 *>(win + 16 * (Q + (Q >> 3)));
+            const f32x2 e0 = {v.x, v.y}, e1 = {v.z, v.w};
+            if constexpr (Q > 0) {
+                feed<4 * Q - 1>(A, W, pk_straddle(prev, e0));
+            }
+            feed<4 * Q>(A, W, e0);
+            feed<4 * Q + 1>(A, W, pk_straddle(e0, e1));
+            feed<4 * Q + 2>(A, W, e1);
+            quads<Q + 1>(win, A, W, e1);
+        }
+    }
+    static __device__ __forceinline__ void run(const char *win, const Taps &taps, float (&acc)[K::R])
+    {
+        f32x2 W[33];
+#pragma unroll
+        for (int p = 0; p < 33; ++p) W[p] = f32x2{taps.w[2 * p], taps.w[2 * p + 1]};
+        f32x2 A[K::R / 2];
+#pragma unroll
+        for (int j = 0; j < K::R / 2; ++j) A[j] = f32x2{0.0f, 0.0f};
+        quads<0>(win, A, W, f32x2{0.0f, 0.0f});
+#pragma unroll
+        for (int j = 0; j < K::R / 2; ++j) { acc[2 * j] = A[j].x; acc[2 * j + 1] = A[j].y; }
+    }
+};
+
 template <typename T, int N>
 __global__ __launch_bounds__(256, 4) void sg1d_center_kernel(const Job1D job, const Taps taps)
 {
@@ -206,22 +304,7 @@ __global__ __launch_bounds__(256, 4) void sg1d_center_kernel(const Job1D job, co
 
         // ---- the convolution: lane owns outputs [lane*R, lane*R + R) of the tile ----
         T acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = T(0);
-        const char *win = slab + 16 * (lane * 9);
-#pragma unroll
-        for (int q = 0; q < K::WQ; ++q) {
-            const VT v = *reinterpret_cast<const VT *>(win + 16 * (q + (q >> 3)));
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const T x = vget(v, e);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int k = q * E + e - r - OFF;             // literal after unrolling
-                    if (k >= 0 && k <= 2 * N) acc[r] = fma_t((T)taps.w[k], x, acc[r]);
-                }
-            }
-        }
+        Conv<T, N>::run(slab + 16 * (lane * 9), taps, acc);
         if (job.flags & JOB_SCALE) {
             const T s = (T)job.dt_inv;
 #pragma unroll

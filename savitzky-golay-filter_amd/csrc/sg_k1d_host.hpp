@@ -8,7 +8,9 @@
 
 namespace sg {
 
-struct Taps { float w[SAVGOL_MAX_WINDOW]; };       // by-value kernarg -> s_load -> SGPRs
+// by-value kernarg -> s_load -> SGPRs.  66 floats = 33 aligned pairs: the fp32 kernel feeds whole
+// SGPR pairs to v_pk_fma_f32 and picks the tap with op_sel.
+struct alignas(8) Taps { float w[SAVGOL_MAX_WINDOW + 1]; };
 
 struct Job1D {
     const void *in;

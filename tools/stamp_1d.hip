@@ -22,7 +22,8 @@ static void run(const float *in, float *out, unsigned channels, unsigned length,
     job.store_lo = 0; job.store_hi = length; job.out_shift = 0; job.dt_inv = 1.0f;
     job.flags = 1u | sg::JOB_VEC_IN | sg::JOB_VEC_OUT;
     sg::Taps taps;
-    for (int k = 0; k < 65; ++k) taps.w[k] = 1.0f / (2 * N + 1);
+    memset(&taps, 0, sizeof(taps));
+    for (int k = 0; k < 2 * N + 1; ++k) taps.w[k] = 1.0f / (2 * N + 1);
     unsigned long long *d_st;
     CK(hipMalloc(&d_st, 64 * 8 * 8));
     CK(hipMemset(d_st, 0, 64 * 8 * 8));
