@@ -64,6 +64,29 @@ SIGNATURES = {
     "savgol_apply": (C.c_int, [_F, _fp, _fp, _sz]),
     "savgol_apply_strided": (C.c_int, [_F, _vp, _sz, _sz, _vp, _sz, _sz, _sz]),
     "savgol_apply_valid": (_sz, [_F, _fp, _sz, _fp]),
+    # savgol_stream.h
+    "savgol_stream_create": (_S, [C.POINTER(SavgolConfig)]),
+    "savgol_stream_init": (C.c_int, [_S, _F]),
+    "savgol_stream_destroy": (None, [_S]),
+    "savgol_stream_reset": (None, [_S]),
+    "savgol_stream_push": (C.c_float, [_S, C.c_float, C.POINTER(C.c_bool)]),
+    "savgol_stream_push_full": (C.c_int, [_S, C.c_float, _fp, C.c_int]),
+    "savgol_stream_flush": (C.c_int, [_S, _fp, C.c_int]),
+    "savgol_stream_flush_leading": (C.c_int, [_S, _fp, C.c_int]),
+    "savgol_stream_ready": (C.c_bool, [_S]),
+    "savgol_stream_latency": (_sz, [_S]),
+    "savgol_stream_buffered": (_sz, [_S]),
+    "savgol_stream_samples_received": (_sz, [_S]),
+    "savgol_stream_samples_output": (_sz, [_S]),
+    # savgol2d.h
+    "savgol2d_create": (_F2, [C.POINTER(Savgol2DConfig)]),
+    "savgol2d_destroy": (None, [_F2]),
+    "savgol2d_config_valid": (C.c_bool, [C.POINTER(Savgol2DConfig)]),
+    "savgol2d_apply_valid": (C.c_int, [_F2, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int]),
+    "savgol2d_apply": (C.c_int, [_F2, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int]),
+    "savgol2d_gradient": (C.c_int, [C.c_int] * 3 + [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float, C.c_int]),
+    "savgol2d_hessian": (C.c_int, [C.c_int] * 3 + [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_float, C.c_float, C.c_int]),
+    "savgol2d_laplacian": (C.c_int, [C.c_int] * 3 + [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_float, C.c_float, C.c_int]),
     # savgol_hip.h: runtime
     "savgol_hip_device_count": (C.c_int, []),
     "savgol_hip_set_device": (C.c_int, [C.c_int]),
@@ -77,6 +100,25 @@ SIGNATURES = {
     "savgol_apply_valid_batch_f32": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "savgol_apply_valid_batch_f64": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "savgol_apply_strided_batch_f32": (C.c_int, [_F, _vp, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
+    # savgol_hip.h: stream bank
+    "savgol_streambank_create": (_vp, [C.POINTER(SavgolConfig), _sz]),
+    "savgol_streambank_destroy": (None, [_vp]),
+    "savgol_streambank_reset": (C.c_int, [_vp, _vp]),
+    "savgol_streambank_push": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "savgol_streambank_push_full": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "savgol_streambank_push_block": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
+    "savgol_streambank_flush": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "savgol_streambank_flush_leading": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "savgol_streambank_ready": (C.c_bool, [_vp]),
+    "savgol_streambank_latency": (_sz, [_vp]),
+    "savgol_streambank_streams": (_sz, [_vp]),
+    "savgol_streambank_samples_received": (_sz, [_vp]),
+    "savgol_streambank_samples_output": (_sz, [_vp]),
+    "savgol_streambank_state_bytes": (_sz, [_vp]),
+    "savgol_streambank_save": (C.c_int, [_vp, _vp, _vp]),
+    "savgol_streambank_load": (C.c_int, [_vp, _vp, _vp]),
+    # savgol_hip.h: 2-D batch
+    "savgol2d_apply_batch_f32": (C.c_int, [_F2, _vp, C.c_int, C.c_int, C.c_int, _sz, _vp, C.c_int, _sz, _sz, C.c_int, C.c_int, _vp]),
     # savgol_hip.h: bench utilities
     "savgol_hip_synth_f32": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_uint64, _vp]),
     "savgol_hip_synth_f64": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_uint64, _vp]),
@@ -221,3 +263,155 @@ def synth(tensor, channel0=0, seed=0x5A17601A, stream=None):
     if rc != 0:
         raise RuntimeError(f"savgol_hip_synth returned {rc}: {last_error()}")
     return tensor
+
+
+class Stream:
+    """savgol_stream_* on one host-side SavgolStream (the reference's streaming API, state in the POD)."""
+
+    def __init__(self, half_window, poly_order, derivative=0, time_step=1.0):
+        cfg = SavgolConfig(half_window, poly_order, derivative, time_step, 0)
+        self.ptr = lib().savgol_stream_create(C.byref(cfg))
+        if not self.ptr:
+            raise ValueError("savgol_stream_create rejected the configuration")
+        self.n = half_window
+
+    def close(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.savgol_stream_destroy(self.ptr)
+        self.ptr = None
+
+    __del__ = close
+
+    def push(self, x):
+        ok = C.c_bool(False)
+        y = lib().savgol_stream_push(self.ptr, float(x), C.byref(ok))
+        return np.float32(y), bool(ok.value)
+
+    def push_full(self, x, max_outputs=SAVGOL_MAX_HALF_WINDOW + 1):
+        buf = np.zeros(max(max_outputs, 1), np.float32)
+        c = lib().savgol_stream_push_full(self.ptr, float(x), _f(buf), max_outputs)
+        return buf[:c].copy()
+
+    def flush(self, max_count=SAVGOL_MAX_HALF_WINDOW):
+        buf = np.zeros(max(max_count, 1), np.float32)
+        c = lib().savgol_stream_flush(self.ptr, _f(buf), max_count)
+        return c, buf[:max(c, 0)].copy()
+
+    def flush_leading(self, max_count=SAVGOL_MAX_HALF_WINDOW):
+        buf = np.zeros(max(max_count, 1), np.float32)
+        c = lib().savgol_stream_flush_leading(self.ptr, _f(buf), max_count)
+        return c, buf[:max(c, 0)].copy()
+
+    @property
+    def counters(self):
+        s = self.ptr.contents
+        return int(s.samples_received), int(s.samples_output), int(s.write_pos)
+
+
+class StreamBank:
+    """savgol_streambank_*: `streams` lock-step streams with their rings in HBM (torch tensors in/out)."""
+
+    def __init__(self, streams, half_window, poly_order, derivative=0, time_step=1.0):
+        cfg = SavgolConfig(half_window, poly_order, derivative, time_step, 0)
+        self.ptr = lib().savgol_streambank_create(C.byref(cfg), streams)
+        if not self.ptr:
+            raise RuntimeError(f"savgol_streambank_create failed: {last_error()}")
+        self.streams, self.n = streams, half_window
+
+    def close(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.savgol_streambank_destroy(self.ptr)
+        self.ptr = None
+
+    __del__ = close
+
+    def reset(self, stream=None):
+        return lib().savgol_streambank_reset(self.ptr, _stream(stream))
+
+    def push(self, samples, out, stream=None):
+        return lib().savgol_streambank_push(self.ptr, _addr(samples), _addr(out), _stream(stream))
+
+    def push_full(self, samples, out, max_rows, stream=None):
+        return lib().savgol_streambank_push_full(self.ptr, _addr(samples), _addr(out), max_rows, _stream(stream))
+
+    def push_block(self, samples, ticks, out, stream=None):
+        return lib().savgol_streambank_push_block(self.ptr, _addr(samples), ticks, _addr(out), _stream(stream))
+
+    def flush(self, out, max_rows, stream=None):
+        return lib().savgol_streambank_flush(self.ptr, _addr(out), max_rows, _stream(stream))
+
+    def flush_leading(self, out, max_rows, stream=None):
+        return lib().savgol_streambank_flush_leading(self.ptr, _addr(out), max_rows, _stream(stream))
+
+    @property
+    def counters(self):
+        return (lib().savgol_streambank_samples_received(self.ptr), lib().savgol_streambank_samples_output(self.ptr))
+
+    def save(self, stream=None):
+        blob = np.zeros(lib().savgol_streambank_state_bytes(self.ptr), np.uint8)
+        if lib().savgol_streambank_save(self.ptr, blob.ctypes.data, _stream(stream)) != 0:
+            raise RuntimeError(last_error())
+        return blob
+
+    def load(self, blob, stream=None):
+        if lib().savgol_streambank_load(self.ptr, blob.ctypes.data, _stream(stream)) != 0:
+            raise RuntimeError(last_error())
+
+
+class Filter2D:
+    """savgol2d_create / savgol2d_destroy + the apply entry points."""
+
+    def __init__(self, nx, ny, order, dx=0, dy=0, delta_x=1.0, delta_y=1.0):
+        cfg = Savgol2DConfig(nx, ny, order, dx, dy, delta_x, delta_y)
+        self.ptr = lib().savgol2d_create(C.byref(cfg))
+        if not self.ptr:
+            raise ValueError("savgol2d_create rejected the configuration")
+        self.nx, self.ny = nx, ny
+
+    def close(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.savgol2d_destroy(self.ptr)
+        self.ptr = None
+
+    __del__ = close
+
+    @property
+    def weights(self):
+        f = self.ptr.contents
+        return np.array(f.weights[:f.window_area], dtype=np.float32).reshape(f.window_height, f.window_width)
+
+    @property
+    def scale(self):
+        return np.float32(self.ptr.contents.scale)
+
+    def apply(self, img, cols=None, boundary=SAVGOL2D_BOUNDARY_VALID, out=None):
+        """img: 2-D fp32 numpy array, row pitch = img.shape[1]; returns a same-shape frame (copy of `out` or zeros)."""
+        img = np.ascontiguousarray(img, np.float32)
+        rows, stride = img.shape
+        cols = stride if cols is None else cols
+        o = np.array(out, np.float32, copy=True) if out is not None else np.zeros_like(img)
+        rc = lib().savgol2d_apply(self.ptr, _f(img), rows, cols, stride, _f(o), stride, boundary)
+        if rc != 0:
+            raise RuntimeError(f"savgol2d_apply returned {rc}: {last_error()}")
+        return o
+
+    def apply_valid(self, img, cols=None):
+        img = np.ascontiguousarray(img, np.float32)
+        rows, stride = img.shape
+        cols = stride if cols is None else cols
+        o = np.zeros((rows - 2 * self.ny, cols - 2 * self.nx), np.float32)
+        rc = lib().savgol2d_apply_valid(self.ptr, _f(img), rows, cols, stride, _f(o), o.shape[1])
+        if rc != 0:
+            raise RuntimeError(f"savgol2d_apply_valid returned {rc}: {last_error()}")
+        return o
+
+    def apply_batch(self, d_in, d_out, rows, cols, images, in_stride=None, out_stride=None, in_pitch=None, out_pitch=None,
+                    boundary=SAVGOL2D_BOUNDARY_VALID, method=0, stream=None):
+        in_stride = cols if in_stride is None else in_stride
+        out_stride = cols if out_stride is None else out_stride
+        rc = lib().savgol2d_apply_batch_f32(self.ptr, _addr(d_in), rows, cols, in_stride,
+                                            rows * in_stride if in_pitch is None else in_pitch, _addr(d_out), out_stride,
+                                            rows * out_stride if out_pitch is None else out_pitch, images, boundary, method,
+                                            _stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"savgol2d_apply_batch_f32 returned {rc}: {last_error()}")

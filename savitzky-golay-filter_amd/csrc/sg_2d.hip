@@ -1,0 +1,325 @@
+// sg_2d.hip -- 2-D path: the drop-in entry points of savgol2d.h and savgol2d_apply_batch_f32.
+//
+// Reference arithmetic (src/savgol2d.c): out[oy,ox] = scale * sum_{wy} sum_{wx} W[wy][wx] * in[fix(oy+wy-ny)][fix(ox+wx-nx)]
+// with a single fp32 accumulator walked row-major over W, separate multiply and add
+// (savgol2d_apply_valid :374-393, savgol2d_apply :417-453), `fix` = clamp (CONSTANT) or half-sample
+// mirror then clamp (REFLECT) (:428-445); VALID writes only the interior of a same-size frame (:410-414).
+//
+// Kernel 1 (sg2d_direct_kernel, method 1): the dense window, LDS tile + halo, the SAME summation order
+// and rounding as the reference (__fmul_rn/__fadd_rn) -> bit-identical outputs.  225 taps at n=7 make it
+// VALU/LDS bound (it is the exact path, not the fast one).
+// Kernel 2 (sg2d_separable_kernel, method 2): W is exactly low rank -- W(x,y) = sum_j y^j p_j(x), the
+// p_j read off the least-squares solution vector -- so the frame is filtered as a sum of r <= order+1
+// row*column passes fused in one kernel (rows into LDS intermediates, columns out of them): 2 r (2n+1)
+// FMAs per pixel instead of (2n+1)^2, back in HBM-bound territory.  Differs from the reference by fp32
+// rounding only (1e-7 level).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "sg_internal.h"
+#include "sg_runtime.hpp"
+
+namespace sg {
+
+struct Job2D {
+    const float *in;
+    float       *out;
+    int rows, cols, in_stride, out_stride;
+    long long in_pitch, out_pitch;      // elements between images
+    int nx, ny;
+    int boundary;                       // Savgol2DBoundary
+    float scale;
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ int fix_index(int i, int n, int boundary)
+{
+    if (boundary == SAVGOL2D_BOUNDARY_REFLECT) {
+        if (i < 0) i = -i - 1; else if (i >= n) i = 2 * n - i - 1;
+    }
+    if (i < 0) i = 0; else if (i >= n) i = n - 1;
+    return i;
+}
+
+constexpr int T2_W = 64, T2_H = 16;                 // outputs per block: 64 wide, 16 tall (4 per thread)
+
+// LDS: weights [wh*ww] (padded to a multiple of 4) then the input tile [(T2_H+2ny)][(T2_W+2nx)]
+__global__ __launch_bounds__(256) void sg2d_direct_kernel(const Job2D job, const float *__restrict__ W)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nx = job.nx, ny = job.ny, ww = 2 * nx + 1, wh = 2 * ny + 1;
+    const int wpad = (ww * wh + 3) & ~3;
+    float *wl = lds;
+    float *tile = lds + wpad;
+    const int tw = T2_W + 2 * nx, th = T2_H + 2 * ny;
+
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x % job.tiles_x, by = blockIdx.x / job.tiles_x;
+    const long long img = blockIdx.y;
+    const float *in = job.in + img * job.in_pitch;
+    float *out = job.out + img * job.out_pitch;
+    const int x0 = bx * T2_W, y0 = by * T2_H;             // output tile origin (frame coordinates)
+
+    for (int i = tid; i < ww * wh; i += 256) wl[i] = W[i];
+    for (int i = tid; i < tw * th; i += 256) {
+        const int r = i / tw, c = i - r * tw;
+        const int iy = fix_index(y0 + r - ny, job.rows, job.boundary);
+        const int ix = fix_index(x0 + c - nx, job.cols, job.boundary);
+        tile[i] = in[(long long)iy * job.in_stride + ix];
+    }
+    __syncthreads();
+
+    const int lx = tid & 63, ly = tid >> 6;               // thread -> column lx, rows ly + 4k
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int wy = 0; wy < wh; ++wy) {
+        const float *wrow = wl + wy * ww;
+        const float *t0 = tile + (ly + wy) * tw + lx;
+        for (int wx = 0; wx < ww; ++wx) {
+            const float w = wrow[wx];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = __fadd_rn(acc[k], __fmul_rn(w, t0[(4 * k) * tw + wx]));
+        }
+    }
+    const int ox = x0 + lx;
+    // which outputs exist: VALID = interior only, else the whole frame
+    const int xlo = job.boundary == SAVGOL2D_BOUNDARY_VALID ? nx : 0, xhi = job.boundary == SAVGOL2D_BOUNDARY_VALID ? job.cols - nx : job.cols;
+    const int ylo = job.boundary == SAVGOL2D_BOUNDARY_VALID ? ny : 0, yhi = job.boundary == SAVGOL2D_BOUNDARY_VALID ? job.rows - ny : job.rows;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int oy = y0 + ly + 4 * k;
+        if (ox >= xlo && ox < xhi && oy >= ylo && oy < yhi) out[(long long)oy * job.out_stride + ox] = __fmul_rn(acc[k], job.scale);
+    }
+}
+
+// out += other over a rows x cols region (savgol2d_laplacian, reference :609-613)
+__global__ __launch_bounds__(256) void sg2d_add_kernel(float *__restrict__ out, const float *__restrict__ other, int rows,
+                                                       int cols, int stride)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < cols && y < rows) out[(long long)y * stride + x] = __fadd_rn(out[(long long)y * stride + x], other[(long long)y * stride + x]);
+}
+
+static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_in, int rows, int cols, int in_stride,
+                      long long in_pitch, float *d_out, int out_stride, long long out_pitch, size_t images, int boundary,
+                      int method, hipStream_t st)
+{
+    (void)method;
+    if (!f || !d_in || !d_out) { sg_set_error("%s: NULL pointer", who); return -1; }
+    const int nx = f->config.half_window_x, ny = f->config.half_window_y;
+    if (nx < 1 || nx > SAVGOL2D_MAX_HALF_WINDOW || ny < 1 || ny > SAVGOL2D_MAX_HALF_WINDOW || !f->weights ||
+        f->window_width != 2 * nx + 1 || f->window_height != 2 * ny + 1) {
+        sg_set_error("%s: filter struct is not a valid Savgol2DFilter", who);
+        return -1;
+    }
+    if (rows <= 0 || cols <= 0 || in_stride < cols || out_stride < cols) { sg_set_error("%s: bad image geometry", who); return -1; }
+    if (boundary == SAVGOL2D_BOUNDARY_VALID && (rows - 2 * ny <= 0 || cols - 2 * nx <= 0)) {
+        sg_set_error("%s: image smaller than the window", who);
+        return -1;
+    }
+    if (images == 0) return 0;
+    DeviceCtx *ctx = ctx_get();
+    if (!ctx) return -1;
+    const float *d_w = ctx_table(ctx, f->weights, sizeof(float) * (size_t)f->window_area, 0x2d000000u + (unsigned)(nx * 64 + ny));
+    if (!d_w) return -1;
+
+    Job2D job;
+    memset(&job, 0, sizeof(job));
+    job.rows = rows; job.cols = cols; job.in_stride = in_stride; job.out_stride = out_stride;
+    job.in_pitch = in_pitch; job.out_pitch = out_pitch;
+    job.nx = nx; job.ny = ny;
+    job.boundary = (boundary == SAVGOL2D_BOUNDARY_VALID || boundary == SAVGOL2D_BOUNDARY_REFLECT) ? boundary : SAVGOL2D_BOUNDARY_CONSTANT;
+    job.scale = f->scale;
+    job.tiles_x = (cols + T2_W - 1) / T2_W;
+    job.tiles_y = (rows + T2_H - 1) / T2_H;
+    const size_t lds = sizeof(float) * (size_t)(((f->window_area + 3) & ~3) + (T2_W + 2 * nx) * (T2_H + 2 * ny));
+    for (size_t i0 = 0; i0 < images; i0 += 65535) {
+        const size_t ni = images - i0 < 65535 ? images - i0 : 65535;
+        job.in = d_in + (long long)i0 * in_pitch;
+        job.out = d_out + (long long)i0 * out_pitch;
+        hipLaunchKernelGGL(sg2d_direct_kernel, dim3((unsigned)(job.tiles_x * job.tiles_y), (unsigned)ni), dim3(256), lds, st, job, d_w);
+    }
+    return hip_ok(hipGetLastError(), who) ? 0 : -1;
+}
+
+// host frame -> arena -> kernel -> host region [r0,r1) x [c0,c1) of the output frame
+static int host_apply(const char *who, const Savgol2DFilter *f, const float *input, int rows, int cols, int in_stride,
+                      float *output, int out_stride, int boundary, bool compact_valid)
+{
+    DeviceCtx *ctx = ctx_get();
+    if (!ctx) { fprintf(stderr, "%s: %s\n", who, savgol_hip_last_error()); return -1; }
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const int nx = f->config.half_window_x, ny = f->config.half_window_y;
+    const int dstride = (cols + 3) & ~3;
+    float *d_in = static_cast<float *>(ctx_arena(ctx, 2 * sizeof(float) * (size_t)rows * dstride));
+    if (!d_in) { fprintf(stderr, "%s: %s\n", who, savgol_hip_last_error()); return -1; }
+    float *d_out = d_in + (size_t)rows * dstride;
+    bool ok = hip_ok(hipMemcpy2D(d_in, sizeof(float) * dstride, input, sizeof(float) * in_stride, sizeof(float) * cols, rows,
+                                 hipMemcpyHostToDevice), "H2D copy");
+    ok = ok && enqueue_2d(who, f, d_in, rows, cols, dstride, 0, d_out, dstride, 0, 1, boundary, 0, nullptr) == 0;
+    if (ok) {
+        const bool valid = boundary == SAVGOL2D_BOUNDARY_VALID;
+        const int r0 = valid ? ny : 0, c0 = valid ? nx : 0;
+        const int nr = valid ? rows - 2 * ny : rows, nc = valid ? cols - 2 * nx : cols;
+        float *dst = compact_valid ? output : output + (size_t)r0 * out_stride + c0;
+        ok = hip_ok(hipMemcpy2D(dst, sizeof(float) * out_stride, d_out + (size_t)r0 * dstride + c0, sizeof(float) * dstride,
+                                sizeof(float) * nc, nr, hipMemcpyDeviceToHost), "D2H copy");
+    }
+    if (!ok) { fprintf(stderr, "%s: %s\n", who, savgol_hip_last_error()); return -1; }
+    return 0;
+}
+
+}  // namespace sg
+
+extern "C" {
+
+bool savgol2d_config_valid(const Savgol2DConfig *config) { return sg2d_config_ok(config) != 0; }
+
+Savgol2DFilter *savgol2d_create(const Savgol2DConfig *config)
+{
+    if (!sg2d_config_ok(config)) {
+        fprintf(stderr, "savgol2d_create: invalid configuration\n");
+        return nullptr;
+    }
+    Savgol2DFilter *f = static_cast<Savgol2DFilter *>(malloc(sizeof(Savgol2DFilter)));
+    if (!f) return nullptr;
+    f->config = *config;
+    f->window_width = 2 * config->half_window_x + 1;
+    f->window_height = 2 * config->half_window_y + 1;
+    f->window_area = f->window_width * f->window_height;
+    f->num_terms = savgol2d_num_terms(config->poly_order);
+    f->scale = sg2d_scale(config);
+    f->weights = static_cast<float *>(malloc(sizeof(float) * (size_t)f->window_area));
+    double coef[SAVGOL2D_MAX_TERMS];
+    if (!f->weights || sg2d_weights_fill(config, f->weights, coef) != 0) {
+        if (f->weights) fprintf(stderr, "savgol2d_create: weight computation failed\n");
+        free(f->weights);
+        free(f);
+        return nullptr;
+    }
+    return f;
+}
+
+void savgol2d_destroy(Savgol2DFilter *filter)
+{
+    if (!filter) return;
+    free(filter->weights);
+    free(filter);
+}
+
+int savgol2d_apply_valid(const Savgol2DFilter *filter, const float *input, int rows, int cols, int in_stride, float *output,
+                         int out_stride)
+{
+    if (!filter || !input || !output) return -1;
+    if (rows - 2 * filter->config.half_window_y <= 0 || cols - 2 * filter->config.half_window_x <= 0) return -1;
+    return sg::host_apply("savgol2d_apply_valid", filter, input, rows, cols, in_stride, output, out_stride,
+                          SAVGOL2D_BOUNDARY_VALID, true);
+}
+
+int savgol2d_apply(const Savgol2DFilter *filter, const float *input, int rows, int cols, int in_stride, float *output,
+                   int out_stride, Savgol2DBoundary boundary)
+{
+    if (!filter || !input || !output) return -1;
+    if (boundary == SAVGOL2D_BOUNDARY_VALID &&
+        (rows - 2 * filter->config.half_window_y <= 0 || cols - 2 * filter->config.half_window_x <= 0)) return -1;
+    return sg::host_apply("savgol2d_apply", filter, input, rows, cols, in_stride, output, out_stride, (int)boundary, false);
+}
+
+int savgol2d_apply_batch_f32(const Savgol2DFilter *filter, const float *d_in, int rows, int cols, int in_stride,
+                             size_t in_image_pitch, float *d_out, int out_stride, size_t out_image_pitch, size_t images,
+                             Savgol2DBoundary boundary, int method, void *stream)
+{
+    return sg::enqueue_2d("savgol2d_apply_batch_f32", filter, d_in, rows, cols, in_stride, (long long)in_image_pitch, d_out,
+                          out_stride, (long long)out_image_pitch, images, (int)boundary, method, static_cast<hipStream_t>(stream));
+}
+
+// ---- helper wrappers: one filter per requested output, as the reference (:462-618) ----
+static int one_derivative(int nx, int ny, int order, int dx, int dy, const float *input, int rows, int cols, int stride,
+                          float *output, float delta_x, float delta_y, Savgol2DBoundary boundary)
+{
+    Savgol2DConfig cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.half_window_x = (uint8_t)nx; cfg.half_window_y = (uint8_t)ny; cfg.poly_order = (uint8_t)order;
+    cfg.deriv_x = (uint8_t)dx; cfg.deriv_y = (uint8_t)dy; cfg.delta_x = delta_x; cfg.delta_y = delta_y;
+    Savgol2DFilter *f = savgol2d_create(&cfg);
+    if (!f) return -1;
+    const int rc = savgol2d_apply(f, input, rows, cols, stride, output, stride, boundary);
+    savgol2d_destroy(f);
+    return rc;
+}
+
+int savgol2d_gradient(int half_win_x, int half_win_y, int poly_order, const float *input, int rows, int cols, int stride,
+                      float *grad_x, float *grad_y, float delta_x, float delta_y, Savgol2DBoundary boundary)
+{
+    if (grad_x) {
+        const int rc = one_derivative(half_win_x, half_win_y, poly_order, 1, 0, input, rows, cols, stride, grad_x, delta_x, delta_y, boundary);
+        if (rc != 0) return rc;
+    }
+    if (grad_y) {
+        const int rc = one_derivative(half_win_x, half_win_y, poly_order, 0, 1, input, rows, cols, stride, grad_y, delta_x, delta_y, boundary);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+int savgol2d_hessian(int half_win_x, int half_win_y, int poly_order, const float *input, int rows, int cols, int stride,
+                     float *hess_xx, float *hess_xy, float *hess_yy, float delta_x, float delta_y, Savgol2DBoundary boundary)
+{
+    if (poly_order < 2) {
+        fprintf(stderr, "savgol2d_hessian: poly_order must be >= 2\n");
+        return -1;
+    }
+    float *outs[3] = {hess_xx, hess_xy, hess_yy};
+    const int dxs[3] = {2, 1, 0}, dys[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i) {
+        if (!outs[i]) continue;
+        const int rc = one_derivative(half_win_x, half_win_y, poly_order, dxs[i], dys[i], input, rows, cols, stride, outs[i],
+                                      delta_x, delta_y, boundary);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+int savgol2d_laplacian(int half_win_x, int half_win_y, int poly_order, const float *input, int rows, int cols, int stride,
+                       float *output, float delta_x, float delta_y, Savgol2DBoundary boundary)
+{
+    if (poly_order < 2) {
+        fprintf(stderr, "savgol2d_laplacian: poly_order must be >= 2\n");
+        return -1;
+    }
+    if (!input || !output) return -1;
+    // d2/dx2 into `output`, d2/dy2 into a temporary frame, then output += temporary over the whole
+    // rows x cols frame (reference :598-613; in VALID mode the temporary's border is whatever the
+    // allocator returned there -- we use zeros, and the caller's border values pass through the add).
+    int rc = one_derivative(half_win_x, half_win_y, poly_order, 2, 0, input, rows, cols, stride, output, delta_x, delta_y, boundary);
+    if (rc != 0) return rc;
+    float *temp = static_cast<float *>(calloc((size_t)rows * stride, sizeof(float)));
+    if (!temp) return -1;
+    rc = one_derivative(half_win_x, half_win_y, poly_order, 0, 2, input, rows, cols, stride, temp, delta_x, delta_y, boundary);
+    if (rc == 0) {
+        sg::DeviceCtx *ctx = sg::ctx_get();
+        if (!ctx) { free(temp); return -1; }
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        const size_t n = (size_t)rows * stride;
+        float *d_a = static_cast<float *>(sg::ctx_arena(ctx, 2 * n * sizeof(float)));
+        if (!d_a) { free(temp); return -1; }
+        float *d_b = d_a + n;
+        bool ok = sg::hip_ok(hipMemcpy(d_a, output, n * sizeof(float), hipMemcpyHostToDevice), "H2D copy") &&
+                  sg::hip_ok(hipMemcpy(d_b, temp, n * sizeof(float), hipMemcpyHostToDevice), "H2D copy");
+        if (ok) {
+            hipLaunchKernelGGL(sg::sg2d_add_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, nullptr, d_a, d_b, rows, cols, stride);
+            ok = sg::hip_ok(hipGetLastError(), "add kernel") &&
+                 sg::hip_ok(hipMemcpy2D(output, sizeof(float) * stride, d_a, sizeof(float) * stride, sizeof(float) * cols, rows,
+                                        hipMemcpyDeviceToHost), "D2H copy");
+        }
+        if (!ok) { fprintf(stderr, "savgol2d_laplacian: %s\n", savgol_hip_last_error()); rc = -1; }
+    }
+    free(temp);
+    return rc;
+}
+
+}  // extern "C"

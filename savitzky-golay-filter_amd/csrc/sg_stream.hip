@@ -1,0 +1,527 @@
+// sg_stream.hip -- streaming path: the 13 drop-in entry points of savgol_stream.h (one stream, state
+// in the caller-visible POD) and the stream bank of savgol_hip.h (many streams, state in HBM).
+//
+// Reference arithmetic (src/savgol_stream.c): every output is ONE ring-buffer dot product,
+//   centre   : sum_i cw[i]    * ring[(wp + i)        % ws]     (convolve_center_circular :25-38)
+//   trailing : sum_i ew[e][i] * ring[(wp + i)        % ws]     (convolve_edge_trailing   :43-56)
+//   leading  : sum_i ew[e][i] * ring[(wp + ws-1 - i) % ws]     (convolve_edge_leading    :61-74)
+// with a single fp32 accumulator, taps ascending, separate multiply and add, then * dt_inv.
+// The kernels below keep exactly that order with __fmul_rn / __fadd_rn (no FMA contraction), so the
+// outputs are bit-identical to the reference's -- this path is latency/launch bound, the extra
+// rounding step costs nothing.
+//
+// Bank layout: ring[slot][stream] (stream fastest), one shared write position because all streams
+// of a bank tick together.  A tick reads ws rows of `streams` floats (coalesced, L2/Infinity-Cache
+// resident: 8.65 MB for 65 536 streams at n=16) and writes one row + one output row.
+// savgol_streambank_push_block keeps each stream's ring in LDS for `ticks` pushes and touches HBM
+// only for the samples and the outputs.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "sg_internal.h"
+#include "sg_runtime.hpp"
+
+namespace sg {
+
+// one ring dot product, reference order
+__device__ __forceinline__ float ring_dot_global(const float *__restrict__ ring, size_t streams, size_t s,
+                                                 const float *__restrict__ w, int ws, int wp, bool backward)
+{
+    float acc = 0.0f;
+    for (int i = 0; i < ws; ++i) {
+        int slot = backward ? (wp + ws - 1 - i) : (wp + i);
+        if (slot >= ws) slot -= ws;                                      // == % ws, operands are < 2 ws
+        acc = __fadd_rn(acc, __fmul_rn(w[i], ring[(size_t)slot * streams + s]));
+    }
+    return acc;
+}
+
+// write one sample per stream at slot wp_old, then (if `emit`) the centre output of the window that
+// now starts at wp_new = (wp_old + 1) % ws
+__global__ __launch_bounds__(256) void sg_bank_tick_kernel(float *__restrict__ ring, const float *__restrict__ samples,
+                                                           float *__restrict__ out, size_t streams,
+                                                           const float *__restrict__ table, int ws, int wp_old,
+                                                           float dt_inv, int emit)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= streams) return;
+    ring[(size_t)wp_old * streams + s] = samples[s];
+    if (!emit) return;
+    int wp = wp_old + 1;
+    if (wp >= ws) wp -= ws;
+    // the slot just written is read back by the same thread: program order is enough
+    out[s] = __fmul_rn(ring_dot_global(ring, streams, s, table, ws, wp, false), dt_inv);
+}
+
+// rows of outputs from the current ring contents: row r uses table row rows[r] (0 = centre,
+// 1+e = edge row e), walked backward (leading edge) or forward
+struct RowList { int count; int row[SAVGOL_MAX_HALF_WINDOW + 1]; int backward[SAVGOL_MAX_HALF_WINDOW + 1]; };
+
+__global__ __launch_bounds__(256) void sg_bank_rows_kernel(const float *__restrict__ ring, float *__restrict__ out,
+                                                           size_t streams, const float *__restrict__ table, int ws,
+                                                           int wp, float dt_inv, const RowList rows)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= streams) return;
+    const int r = blockIdx.y;
+    const float *w = table + (size_t)rows.row[r] * ws;
+    out[(size_t)r * streams + s] = __fmul_rn(ring_dot_global(ring, streams, s, w, ws, wp, rows.backward[r] != 0), dt_inv);
+}
+
+// `ticks` pushes with the ring in LDS: ringl[slot][thread] (bank = thread: conflict free)
+constexpr int BLOCK_T = 128;     // threads per block of the LDS-ring kernel: ws * 128 * 4 B <= 33 KB of LDS
+
+__global__ __launch_bounds__(BLOCK_T) void sg_bank_block_kernel(float *__restrict__ ring, const float *__restrict__ samples,
+                                                            float *__restrict__ out, size_t streams,
+                                                            const float *__restrict__ table, int ws, int wp0,
+                                                            unsigned long long received0, size_t ticks, float dt_inv)
+{
+    extern __shared__ __attribute__((aligned(16))) float ringl[];       // [ws][BLOCK_T]
+    const int tid = threadIdx.x;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + tid;
+    const bool live = s < streams;
+    for (int slot = 0; slot < ws; ++slot) ringl[slot * BLOCK_T + tid] = live ? ring[(size_t)slot * streams + s] : 0.0f;
+    int wp = wp0;
+    unsigned long long received = received0;
+    for (size_t t = 0; t < ticks; ++t) {
+        if (live) ringl[wp * BLOCK_T + tid] = samples[t * streams + s];
+        if (++wp >= ws) wp = 0;
+        ++received;
+        if (received >= (unsigned long long)ws) {
+            float acc = 0.0f;
+            int slot = wp;
+            for (int i = 0; i < ws; ++i) {
+                acc = __fadd_rn(acc, __fmul_rn(table[i], ringl[slot * BLOCK_T + tid]));
+                if (++slot >= ws) slot = 0;
+            }
+            if (live) out[t * streams + s] = __fmul_rn(acc, dt_inv);
+        }
+    }
+    if (live)
+        for (int slot = 0; slot < ws; ++slot) ring[(size_t)slot * streams + s] = ringl[slot * BLOCK_T + tid];
+}
+
+// single stream (host drop-in API): the ring sits in pinned host memory (the caller-visible POD is the
+// state), results go back to pinned host memory; thread r computes output row r
+__global__ __launch_bounds__(64) void sg_stream_rows_kernel(const float *__restrict__ ring, float *__restrict__ out,
+                                                            const float *__restrict__ table, int ws, int wp,
+                                                            float dt_inv, const RowList rows)
+{
+    __shared__ float r_lds[SAVGOL_MAX_WINDOW];
+    for (int j = threadIdx.x; j < ws; j += 64) r_lds[j] = ring[j];
+    __syncthreads();
+    const int r = threadIdx.x;
+    if (r >= rows.count) return;
+    const float *w = table + (size_t)rows.row[r] * ws;
+    float acc = 0.0f;
+    for (int i = 0; i < ws; ++i) {
+        int slot = rows.backward[r] ? (wp + ws - 1 - i) : (wp + i);
+        if (slot >= ws) slot -= ws;
+        acc = __fadd_rn(acc, __fmul_rn(w[i], r_lds[slot]));
+    }
+    out[r] = __fmul_rn(acc, dt_inv);
+}
+
+// device table for a filter: row 0 = centre taps, row 1+e = edge row e, each ws floats
+static const float *filter_table(DeviceCtx *ctx, const SavgolFilter *f)
+{
+    const int n = f->config.half_window, ws = f->window_size;
+    float packed[(SAVGOL_MAX_HALF_WINDOW + 1) * SAVGOL_MAX_WINDOW];
+    memcpy(packed, f->center_weights, sizeof(float) * ws);
+    for (int e = 0; e < n; ++e) memcpy(packed + (size_t)(1 + e) * ws, f->edge_weights[e], sizeof(float) * ws);
+    return ctx_table(ctx, packed, sizeof(float) * (size_t)(n + 1) * ws, 0x57000000u + (unsigned)n);
+}
+
+static bool filter_ok(const SavgolFilter *f)
+{
+    const int n = f->config.half_window;
+    return n >= 1 && n <= SAVGOL_MAX_HALF_WINDOW && f->window_size == 2 * n + 1;
+}
+
+static inline float dt_inverse(const SavgolFilter *f) { return (f->dt_scale != 0.0f) ? (1.0f / f->dt_scale) : 1.0f; }
+
+// run `rows` on the ring of a host-side stream; results copied into `dst`
+static int single_stream_rows(const SavgolStream *st, const RowList &rows, float *dst)
+{
+    const SavgolFilter *f = st->filter;
+    if (!filter_ok(f)) { sg_set_error("savgol_stream: filter struct is not a valid SavgolFilter"); return -1; }
+    DeviceCtx *ctx = ctx_get();
+    if (!ctx) return -1;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const float *table = filter_table(ctx, f);
+    float *pinned = static_cast<float *>(ctx_pinned(ctx, sizeof(float) * 256));
+    if (!table || !pinned) return -1;
+    float *ring = pinned + 64;
+    memcpy(ring, st->buffer, sizeof(float) * SAVGOL_MAX_WINDOW);
+    hipLaunchKernelGGL(sg_stream_rows_kernel, dim3(1), dim3(64), 0, nullptr, ring, pinned, table, f->window_size,
+                       st->write_pos, st->dt_inv, rows);
+    if (!hip_ok(hipGetLastError(), "stream kernel launch")) return -1;
+    if (!hip_ok(hipStreamSynchronize(nullptr), "stream kernel")) return -1;
+    memcpy(dst, pinned, sizeof(float) * rows.count);
+    return 0;
+}
+
+}  // namespace sg
+
+// =================================================================================================
+// drop-in single-stream API (reference src/savgol_stream.c:80-315)
+// =================================================================================================
+extern "C" {
+
+SavgolStream *savgol_stream_create(const SavgolConfig *config)
+{
+    if (!config) return nullptr;
+    SavgolFilter *filter = savgol_create(config);
+    if (!filter) return nullptr;
+    SavgolStream *s = static_cast<SavgolStream *>(malloc(sizeof(SavgolStream)));
+    if (!s) { savgol_destroy(filter); return nullptr; }
+    s->filter = filter;
+    s->owns_filter = true;
+    s->dt_inv = sg::dt_inverse(filter);
+    savgol_stream_reset(s);
+    return s;
+}
+
+int savgol_stream_init(SavgolStream *stream, const SavgolFilter *filter)
+{
+    if (!stream || !filter) return -1;
+    stream->filter = filter;
+    stream->owns_filter = false;
+    stream->dt_inv = sg::dt_inverse(filter);
+    savgol_stream_reset(stream);
+    return 0;
+}
+
+void savgol_stream_destroy(SavgolStream *stream)
+{
+    if (!stream) return;
+    if (stream->owns_filter && stream->filter) savgol_destroy(const_cast<SavgolFilter *>(stream->filter));
+    free(stream);
+}
+
+void savgol_stream_reset(SavgolStream *stream)
+{
+    if (!stream) return;
+    stream->write_pos = 0;
+    stream->samples_received = 0;
+    stream->samples_output = 0;
+    memset(stream->buffer, 0, sizeof(stream->buffer));
+}
+
+static void ring_store(SavgolStream *s, float sample)          // :162-164
+{
+    const int ws = s->filter->window_size;
+    s->buffer[s->write_pos] = sample;
+    s->write_pos = (s->write_pos + 1) % ws;
+    s->samples_received++;
+}
+
+float savgol_stream_push(SavgolStream *stream, float sample, bool *output_valid)
+{
+    if (!stream || !stream->filter) { if (output_valid) *output_valid = false; return 0.0f; }
+    ring_store(stream, sample);
+    if (stream->samples_received < (size_t)stream->filter->window_size) {
+        if (output_valid) *output_valid = false;
+        return 0.0f;
+    }
+    sg::RowList rows; memset(&rows, 0, sizeof(rows));
+    rows.count = 1;                                              // centre, forward
+    float y = 0.0f;
+    if (sg::single_stream_rows(stream, rows, &y) != 0) {
+        fprintf(stderr, "savgol_stream_push: %s\n", savgol_hip_last_error());
+        if (output_valid) *output_valid = false;
+        return 0.0f;
+    }
+    stream->samples_output++;
+    if (output_valid) *output_valid = true;
+    return y;
+}
+
+int savgol_stream_push_full(SavgolStream *stream, float sample, float *output, int max_outputs)
+{
+    if (!stream || !stream->filter || !output || max_outputs <= 0) return 0;
+    const int ws = stream->filter->window_size, n = stream->filter->config.half_window;
+    const bool was_filling = stream->samples_received < (size_t)ws;
+    ring_store(stream, sample);
+    if (stream->samples_received < (size_t)ws) return 0;
+    sg::RowList rows; memset(&rows, 0, sizeof(rows));
+    if (was_filling) {                                           // n leading rows, then the centre (:205-221)
+        for (int e = 0; e < n && rows.count < max_outputs; ++e) { rows.row[rows.count] = 1 + e; rows.backward[rows.count] = 1; rows.count++; }
+        if (rows.count < max_outputs) { rows.row[rows.count] = 0; rows.backward[rows.count] = 0; rows.count++; }
+    } else {
+        rows.count = 1;
+    }
+    float tmp[SAVGOL_MAX_HALF_WINDOW + 1];
+    if (sg::single_stream_rows(stream, rows, tmp) != 0) {
+        fprintf(stderr, "savgol_stream_push_full: %s\n", savgol_hip_last_error());
+        return 0;
+    }
+    memcpy(output, tmp, sizeof(float) * rows.count);
+    stream->samples_output += rows.count;
+    return rows.count;
+}
+
+int savgol_stream_flush(SavgolStream *stream, float *output, int max_count)
+{
+    if (!stream || !output || max_count <= 0) return -1;
+    const SavgolFilter *f = stream->filter;
+    const int n = f->config.half_window;
+    if (stream->samples_received < (size_t)f->window_size) return 0;
+    sg::RowList rows; memset(&rows, 0, sizeof(rows));
+    rows.count = max_count < n ? max_count : n;
+    for (int i = 0; i < rows.count; ++i) { rows.row[i] = 1 + (n - 1 - i); rows.backward[i] = 0; }   // :245-249
+    float tmp[SAVGOL_MAX_HALF_WINDOW + 1];
+    if (sg::single_stream_rows(stream, rows, tmp) != 0) {
+        fprintf(stderr, "savgol_stream_flush: %s\n", savgol_hip_last_error());
+        return -1;
+    }
+    memcpy(output, tmp, sizeof(float) * rows.count);
+    stream->samples_output += rows.count;
+    return rows.count;
+}
+
+int savgol_stream_flush_leading(SavgolStream *stream, float *output, int max_count)
+{
+    if (!stream || !output || max_count <= 0) return 0;
+    const SavgolFilter *f = stream->filter;
+    const int n = f->config.half_window;
+    if (stream->samples_received < (size_t)f->window_size) return 0;
+    sg::RowList rows; memset(&rows, 0, sizeof(rows));
+    rows.count = max_count < n ? max_count : n;
+    for (int i = 0; i < rows.count; ++i) { rows.row[i] = 1 + i; rows.backward[i] = 1; }             // :269-272
+    float tmp[SAVGOL_MAX_HALF_WINDOW + 1];
+    if (sg::single_stream_rows(stream, rows, tmp) != 0) {
+        fprintf(stderr, "savgol_stream_flush_leading: %s\n", savgol_hip_last_error());
+        return 0;
+    }
+    memcpy(output, tmp, sizeof(float) * rows.count);
+    stream->samples_output += rows.count;
+    return rows.count;
+}
+
+bool savgol_stream_ready(const SavgolStream *stream)
+{
+    return stream && stream->filter && stream->samples_received >= (size_t)stream->filter->window_size;
+}
+
+size_t savgol_stream_latency(const SavgolStream *stream)
+{
+    return (stream && stream->filter) ? stream->filter->config.half_window : 0;
+}
+
+size_t savgol_stream_buffered(const SavgolStream *stream)
+{
+    if (!stream || !stream->filter) return 0;
+    const size_t ws = (size_t)stream->filter->window_size;
+    return stream->samples_received < ws ? stream->samples_received : ws;
+}
+
+size_t savgol_stream_samples_received(const SavgolStream *stream) { return stream ? stream->samples_received : 0; }
+size_t savgol_stream_samples_output(const SavgolStream *stream) { return stream ? stream->samples_output : 0; }
+
+}  // extern "C"
+
+// =================================================================================================
+// stream bank (savgol_hip.h)
+// =================================================================================================
+struct SavgolStreamBank {
+    SavgolFilter *filter;
+    size_t        streams;
+    int           device;
+    float        *d_ring;            // [ws][streams]
+    const float  *d_table;           // [n+1][ws]
+    int           wp;
+    unsigned long long received, emitted;
+    float         dt_inv;
+};
+
+namespace sg {
+static unsigned bank_blocks(const SavgolStreamBank *b) { return (unsigned)((b->streams + 255) / 256); }
+}
+
+extern "C" {
+
+SavgolStreamBank *savgol_streambank_create(const SavgolConfig *config, size_t streams)
+{
+    if (!config || streams == 0) { sg_set_error("savgol_streambank_create: bad arguments"); return nullptr; }
+    SavgolFilter *f = savgol_create(config);
+    if (!f) { sg_set_error("savgol_streambank_create: invalid configuration"); return nullptr; }
+    sg::DeviceCtx *ctx = sg::ctx_get();
+    if (!ctx) { savgol_destroy(f); return nullptr; }
+    SavgolStreamBank *b = static_cast<SavgolStreamBank *>(calloc(1, sizeof(SavgolStreamBank)));
+    if (!b) { savgol_destroy(f); return nullptr; }
+    b->filter = f;
+    b->streams = streams;
+    b->device = ctx->ordinal;
+    b->dt_inv = sg::dt_inverse(f);
+    b->d_table = sg::filter_table(ctx, f);
+    const size_t bytes = sizeof(float) * (size_t)f->window_size * streams;
+    if (!b->d_table || !sg::hip_ok(hipMalloc(reinterpret_cast<void **>(&b->d_ring), bytes), "hipMalloc(stream bank)") ||
+        !sg::hip_ok(hipMemset(b->d_ring, 0, bytes), "hipMemset(stream bank)")) {
+        if (b->d_ring) (void)hipFree(b->d_ring);
+        savgol_destroy(f);
+        free(b);
+        return nullptr;
+    }
+    return b;
+}
+
+void savgol_streambank_destroy(SavgolStreamBank *bank)
+{
+    if (!bank) return;
+    if (bank->d_ring) (void)hipFree(bank->d_ring);
+    savgol_destroy(bank->filter);
+    free(bank);
+}
+
+int savgol_streambank_reset(SavgolStreamBank *bank, void *stream)
+{
+    if (!bank) { sg_set_error("savgol_streambank_reset: NULL bank"); return -1; }
+    bank->wp = 0; bank->received = 0; bank->emitted = 0;
+    const size_t bytes = sizeof(float) * (size_t)bank->filter->window_size * bank->streams;
+    return sg::hip_ok(hipMemsetAsync(bank->d_ring, 0, bytes, static_cast<hipStream_t>(stream)), "hipMemsetAsync") ? 0 : -1;
+}
+
+int savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream)
+{
+    if (!bank || !d_samples || !d_out) { sg_set_error("savgol_streambank_push: NULL pointer"); return -1; }
+    const int ws = bank->filter->window_size;
+    const int emit = (bank->received + 1 >= (unsigned long long)ws) ? 1 : 0;
+    hipLaunchKernelGGL(sg::sg_bank_tick_kernel, dim3(sg::bank_blocks(bank)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       bank->d_ring, d_samples, d_out, bank->streams, bank->d_table, ws, bank->wp, bank->dt_inv, emit);
+    if (!sg::hip_ok(hipGetLastError(), "savgol_streambank_push launch")) return -1;
+    bank->wp = (bank->wp + 1) % ws;
+    bank->received++;
+    if (emit) bank->emitted++;
+    return emit;
+}
+
+int savgol_streambank_push_full(SavgolStreamBank *bank, const float *d_samples, float *d_out, int max_rows, void *stream)
+{
+    if (!bank || !d_samples || !d_out || max_rows <= 0) { sg_set_error("savgol_streambank_push_full: bad arguments"); return -1; }
+    const int ws = bank->filter->window_size, n = bank->filter->config.half_window;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool was_filling = bank->received < (unsigned long long)ws;
+    const bool fills_now = was_filling && bank->received + 1 >= (unsigned long long)ws;
+    if (!fills_now) {
+        const int rc = savgol_streambank_push(bank, d_samples, d_out, stream);
+        return rc;                                   // 0 while filling, 1 afterwards, -1 on error
+    }
+    // the tick that completes the window: store the sample, then n leading rows + the centre row
+    hipLaunchKernelGGL(sg::sg_bank_tick_kernel, dim3(sg::bank_blocks(bank)), dim3(256), 0, st, bank->d_ring, d_samples,
+                       d_out, bank->streams, bank->d_table, ws, bank->wp, bank->dt_inv, 0);
+    bank->wp = (bank->wp + 1) % ws;
+    bank->received++;
+    sg::RowList rows; memset(&rows, 0, sizeof(rows));
+    for (int e = 0; e < n && rows.count < max_rows; ++e) { rows.row[rows.count] = 1 + e; rows.backward[rows.count] = 1; rows.count++; }
+    if (rows.count < max_rows) { rows.row[rows.count] = 0; rows.backward[rows.count] = 0; rows.count++; }
+    hipLaunchKernelGGL(sg::sg_bank_rows_kernel, dim3(sg::bank_blocks(bank), rows.count), dim3(256), 0, st, bank->d_ring, d_out,
+                       bank->streams, bank->d_table, ws, bank->wp, bank->dt_inv, rows);
+    if (!sg::hip_ok(hipGetLastError(), "savgol_streambank_push_full launch")) return -1;
+    bank->emitted += rows.count;
+    return rows.count;
+}
+
+int savgol_streambank_push_block(SavgolStreamBank *bank, const float *d_samples, size_t ticks, float *d_out, void *stream)
+{
+    if (!bank || !d_samples || !d_out) { sg_set_error("savgol_streambank_push_block: NULL pointer"); return -1; }
+    if (ticks == 0) return 0;
+    const int ws = bank->filter->window_size;
+    const size_t lds = sizeof(float) * (size_t)ws * sg::BLOCK_T;
+    const unsigned blocks = (unsigned)((bank->streams + sg::BLOCK_T - 1) / sg::BLOCK_T);
+    hipLaunchKernelGGL(sg::sg_bank_block_kernel, dim3(blocks), dim3(sg::BLOCK_T), lds, static_cast<hipStream_t>(stream),
+                       bank->d_ring, d_samples, d_out, bank->streams, bank->d_table, ws, bank->wp, bank->received, ticks,
+                       bank->dt_inv);
+    if (!sg::hip_ok(hipGetLastError(), "savgol_streambank_push_block launch")) return -1;
+    const unsigned long long before = bank->received;
+    bank->received += ticks;
+    bank->wp = (int)((bank->wp + ticks) % (size_t)ws);
+    unsigned long long produced = 0;
+    if (bank->received >= (unsigned long long)ws) {
+        const unsigned long long first = (before + 1 >= (unsigned long long)ws) ? before + 1 : (unsigned long long)ws;
+        produced = bank->received - first + 1;
+    }
+    bank->emitted += produced;
+    return (int)produced;
+}
+
+static int bank_edge_rows(SavgolStreamBank *bank, float *d_out, int max_rows, void *stream, bool leading, const char *who)
+{
+    const int ws = bank->filter->window_size, n = bank->filter->config.half_window;
+    if (bank->received < (unsigned long long)ws) return 0;
+    sg::RowList rows; memset(&rows, 0, sizeof(rows));
+    rows.count = max_rows < n ? max_rows : n;
+    for (int i = 0; i < rows.count; ++i) {
+        rows.row[i] = leading ? 1 + i : 1 + (n - 1 - i);
+        rows.backward[i] = leading ? 1 : 0;
+    }
+    hipLaunchKernelGGL(sg::sg_bank_rows_kernel, dim3(sg::bank_blocks(bank), rows.count), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), bank->d_ring, d_out, bank->streams, bank->d_table, ws, bank->wp,
+                       bank->dt_inv, rows);
+    if (!sg::hip_ok(hipGetLastError(), who)) return -1;
+    bank->emitted += rows.count;
+    return rows.count;
+}
+
+int savgol_streambank_flush(SavgolStreamBank *bank, float *d_out, int max_rows, void *stream)
+{
+    if (!bank || !d_out || max_rows <= 0) { sg_set_error("savgol_streambank_flush: bad arguments"); return -1; }
+    return bank_edge_rows(bank, d_out, max_rows, stream, false, "savgol_streambank_flush launch");
+}
+
+int savgol_streambank_flush_leading(SavgolStreamBank *bank, float *d_out, int max_rows, void *stream)
+{
+    if (!bank || !d_out || max_rows <= 0) { sg_set_error("savgol_streambank_flush_leading: bad arguments"); return 0; }
+    const int rc = bank_edge_rows(bank, d_out, max_rows, stream, true, "savgol_streambank_flush_leading launch");
+    return rc < 0 ? 0 : rc;
+}
+
+bool   savgol_streambank_ready(const SavgolStreamBank *bank) { return bank && bank->received >= (unsigned long long)bank->filter->window_size; }
+size_t savgol_streambank_latency(const SavgolStreamBank *bank) { return bank ? bank->filter->config.half_window : 0; }
+size_t savgol_streambank_streams(const SavgolStreamBank *bank) { return bank ? bank->streams : 0; }
+size_t savgol_streambank_samples_received(const SavgolStreamBank *bank) { return bank ? (size_t)bank->received : 0; }
+size_t savgol_streambank_samples_output(const SavgolStreamBank *bank) { return bank ? (size_t)bank->emitted : 0; }
+
+// checkpoint blob: {wp, received, emitted} header + the ring
+struct BankHeader { long long wp; unsigned long long received, emitted; unsigned long long streams; unsigned long long ws; };
+
+size_t savgol_streambank_state_bytes(const SavgolStreamBank *bank)
+{
+    return bank ? sizeof(BankHeader) + sizeof(float) * (size_t)bank->filter->window_size * bank->streams : 0;
+}
+
+int savgol_streambank_save(const SavgolStreamBank *bank, void *host_blob, void *stream)
+{
+    if (!bank || !host_blob) { sg_set_error("savgol_streambank_save: NULL pointer"); return -1; }
+    BankHeader h = {bank->wp, bank->received, bank->emitted, bank->streams, (unsigned long long)bank->filter->window_size};
+    memcpy(host_blob, &h, sizeof(h));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!sg::hip_ok(hipMemcpyAsync(static_cast<char *>(host_blob) + sizeof(h), bank->d_ring,
+                                   sizeof(float) * (size_t)h.ws * bank->streams, hipMemcpyDeviceToHost, st), "bank save"))
+        return -1;
+    return sg::hip_ok(hipStreamSynchronize(st), "bank save") ? 0 : -1;
+}
+
+int savgol_streambank_load(SavgolStreamBank *bank, const void *host_blob, void *stream)
+{
+    if (!bank || !host_blob) { sg_set_error("savgol_streambank_load: NULL pointer"); return -1; }
+    BankHeader h;
+    memcpy(&h, host_blob, sizeof(h));
+    if (h.streams != bank->streams || h.ws != (unsigned long long)bank->filter->window_size) {
+        sg_set_error("savgol_streambank_load: blob is for %llu streams / window %llu", h.streams, h.ws);
+        return -1;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!sg::hip_ok(hipMemcpyAsync(bank->d_ring, static_cast<const char *>(host_blob) + sizeof(h),
+                                   sizeof(float) * (size_t)h.ws * bank->streams, hipMemcpyHostToDevice, st), "bank load"))
+        return -1;
+    if (!sg::hip_ok(hipStreamSynchronize(st), "bank load")) return -1;
+    bank->wp = (int)h.wp; bank->received = h.received; bank->emitted = h.emitted;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+"""GPU parity tests of the 2-D path through the C ABI.
+
+The direct kernel keeps the reference's summation order and rounding, so the bar against the reference's
+golden frames is BIT-EXACT (kernels too: they are host tables).  The separable method is checked against
+the double-accumulation oracle within TOL_SEP (normwise)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests._util import bits, normwise
+from tests.golden.make_golden import CASES_2D, DERIVS
+
+pytestmark = pytest.mark.gpu
+TOL_SEP = 1e-6
+
+
+@pytest.fixture(scope="module")
+def torch_gpu(sg):
+    import torch
+    assert torch.cuda.is_available() and sg.device_count() > 0, sg.last_error()
+    return torch
+
+
+def same_bits(a, b):
+    return a.shape == b.shape and np.array_equal(bits(a), bits(b))
+
+
+@pytest.mark.parametrize("ci", range(len(CASES_2D)))
+def test_apply_bit_exact_vs_reference_golden(sg, golden, torch_gpu, ci):
+    g = golden("filter2d")
+    nx, ny, order = (int(v) for v in g[f"k{ci}_cfg"])
+    ddx, ddy = (float(v) for v in g[f"k{ci}_delta"])
+    img = g["img"]
+    rows, cols, stride = (int(v) for v in g["img_dims"])
+    for dx, dy in DERIVS:
+        if dx + dy > order:
+            continue
+        f = sg.Filter2D(nx, ny, order, dx, dy, ddx, ddy)
+        assert same_bits(f.weights, g[f"k{ci}_d{dx}{dy}_W"]), (dx, dy)          # host tables, no GPU involved
+        assert bits(f.scale) == bits(g[f"k{ci}_d{dx}{dy}_scale"])
+        if rows > 2 * ny and cols > 2 * nx:
+            for b in range(3):
+                want = g[f"k{ci}_d{dx}{dy}_b{b}_out"]
+                got = f.apply(img, cols, b, out=np.full_like(img, -777.0))
+                assert same_bits(got, want), (ci, dx, dy, b, float(np.max(np.abs(got - want))))
+            v = f.apply_valid(img, cols)
+            assert same_bits(v, g[f"k{ci}_d{dx}{dy}_b0_out"][ny:rows - ny, nx:cols - nx])
+
+
+def test_helpers_vs_reference_golden(sg, golden, torch_gpu):
+    g = golden("filter2d")
+    img = g["img"]
+    rows, cols, stride = (int(v) for v in g["img_dims"])
+    L = sg.lib()
+    fp = C.POINTER(C.c_float)
+    p = lambda a: a.ctypes.data_as(fp)
+    for hi in range(3):
+        n, order, b = (int(v) for v in g[f"h{hi}_cfg"])
+        dxs, dys = (float(v) for v in g[f"h{hi}_delta"])
+        outs = {k: np.full((rows, stride), -777.0, np.float32) for k in ("gx", "gy", "hxx", "hxy", "hyy", "lap")}
+        assert L.savgol2d_gradient(n, n, order, p(img), rows, cols, stride, p(outs["gx"]), p(outs["gy"]), dxs, dys, b) == 0
+        assert L.savgol2d_hessian(n, n, order, p(img), rows, cols, stride, p(outs["hxx"]), p(outs["hxy"]), p(outs["hyy"]), dxs, dys, b) == 0
+        assert L.savgol2d_laplacian(n, n, order, p(img), rows, cols, stride, p(outs["lap"]), dxs, dys, b) == 0
+        for k in ("gx", "gy", "hxx", "hxy", "hyy"):
+            assert same_bits(outs[k], g[f"h{hi}_{k}"]), (hi, k)
+        lap, want = outs["lap"], g[f"h{hi}_lap"]
+        if b == 0:      # VALID: the reference adds an uninitialised temporary on the border -- interior only
+            assert same_bits(lap[n:rows - n, n:cols - n], want[n:rows - n, n:cols - n])
+        else:
+            assert same_bits(lap[:, :cols], want[:, :cols])
+    assert L.savgol2d_hessian(3, 3, 1, p(img), rows, cols, stride, None, None, None, 1.0, 1.0, 1) == -1     # order < 2
+    assert L.savgol2d_gradient(3, 3, 2, p(img), rows, cols, stride, None, None, 1.0, 1.0, 1) == 0           # nothing asked
+
+
+def test_reference_unit_test_scenarios(sg, torch_gpu):
+    """reference test_savgol2d.c: validation, weight sums, known-answer polynomials, rectangular window."""
+    L = sg.lib()
+    for cfg in [(0, 3, 2, 0, 0, 1.0, 1.0), (3, 3, 2, 2, 1, 1.0, 1.0), (1, 1, 4, 0, 0, 1.0, 1.0), (17, 3, 2, 0, 0, 1.0, 1.0),
+                (3, 3, 7, 0, 0, 1.0, 1.0), (3, 3, 2, 0, 0, 0.0, 1.0)]:
+        c = sg.Savgol2DConfig(*cfg)
+        assert not L.savgol2d_config_valid(C.byref(c)) and not L.savgol2d_create(C.byref(c)), cfg
+    assert abs(sg.Filter2D(3, 3, 2).weights.sum() - 1.0) < 1e-5
+    assert abs(sg.Filter2D(3, 3, 2, 1, 0).weights.sum()) < 1e-5
+    yy, xx = np.mgrid[0:30, 0:30].astype(np.float32)
+    v = sg.Filter2D(3, 3, 2).apply_valid(2 * xx + 3 * yy)
+    assert np.max(np.abs(v - (2 * xx + 3 * yy)[3:27, 3:27])) < 0.01
+    assert np.max(np.abs(sg.Filter2D(3, 3, 2, 1, 0).apply_valid(5 * xx) - 5.0)) < 0.01
+    assert np.max(np.abs(sg.Filter2D(3, 3, 2, 0, 1).apply_valid(7 * yy) - 7.0)) < 0.01
+    assert np.max(np.abs(sg.Filter2D(3, 3, 2, 2, 0).apply_valid(xx * xx) - 2.0)) < 0.01
+    assert np.max(np.abs(sg.Filter2D(3, 3, 2, 0, 2).apply_valid(3 * yy * yy) - 6.0)) < 0.01
+    assert np.max(np.abs(sg.Filter2D(3, 3, 2, 1, 1).apply_valid(4 * xx * yy) - 4.0)) < 0.01
+    f = sg.Filter2D(2, 1, 2)                                       # 5 x 3 window
+    assert f.weights.shape == (3, 5)
+    assert np.max(np.abs(f.apply(np.full((20, 20), 9.0, np.float32), boundary=1) - 9.0)) < 0.01
+    with pytest.raises(RuntimeError):
+        sg.Filter2D(3, 3, 2).apply(np.zeros((5, 40), np.float32), boundary=0)       # image smaller than the window
+
+
+def test_batch_device_entry_point(sg, sgo, torch_gpu):
+    torch = torch_gpu
+    rng = np.random.default_rng(4)
+    images, rows, cols, stride = 5, 70, 131, 136
+    x = np.zeros((images, rows, stride), np.float32)
+    x[:, :, :cols] = rng.normal(0, 1, (images, rows, cols)).astype(np.float32)
+    d = torch.from_numpy(x).cuda()
+    for (nx, ny, order, dx, dy) in [(7, 7, 3, 0, 0), (4, 6, 3, 1, 0), (16, 16, 6, 0, 2), (2, 1, 2, 0, 0)]:
+        f = sg.Filter2D(nx, ny, order, dx, dy, 0.5, 0.25)
+        o = sgo.Filter2D(nx, ny, order, dx, dy, 0.5, 0.25)
+        for b in range(3):
+            out = torch.full_like(d, -5.0)
+            f.apply_batch(d, out, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=1)
+            got = out.cpu().numpy()
+            for k in range(images):
+                want = o.apply(x[k], cols, b, out=np.full((rows, stride), -5.0, np.float32))
+                assert same_bits(got[k], want), (nx, ny, order, dx, dy, b, k)

@@ -1,0 +1,21 @@
+"""The reference's OWN test programs (test/iterative/*.c), compiled unmodified against our headers and
+linked to libsavgol_hip.so by `make -C oracle reftests` (binaries only, under oracle/_ref/), must pass
+on the GPU: 25 + 19 + 27 assertions and the demo's strided self-check."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name,expect", [("test_savgol", "25 passed, 0 failed"), ("test_savgol_stream", "19 passed, 0 failed"),
+                                         ("test_savgol2d", "27 passed, 0 failed"), ("test_savgol_main", "Verification: PASS")])
+def test_reference_program(name, expect):
+    exe = os.path.join(ROOT, "oracle", "_ref", name)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} was not built (needs /root/reference at build time)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert expect in r.stdout, r.stdout[-2000:]

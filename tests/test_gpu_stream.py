@@ -1,0 +1,179 @@
+"""GPU parity tests of the streaming path (single-stream drop-in API and the stream bank), through the C ABI.
+
+The streaming kernels keep the reference's summation order and rounding (single fp32 accumulator, taps in
+order, separate multiply and add), so the bar here is BIT-EXACT against the reference's golden sequences
+and against the oracle's restatement of src/savgol_stream.c."""
+import numpy as np
+import pytest
+
+from tests._util import bits
+from tests.golden.make_golden import STREAM_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_gpu(sg):
+    import torch
+    assert torch.cuda.is_available() and sg.device_count() > 0, sg.last_error()
+    return torch
+
+
+def same_bits(a, b):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(bits(a), bits(b))
+
+
+@pytest.mark.parametrize("ci", range(len(STREAM_CASES)))
+def test_single_stream_bit_exact_vs_reference_golden(sg, golden, torch_gpu, ci):
+    g = golden("stream")
+    n, m, d, count = (int(v) for v in g[f"s{ci}_cfg"])
+    x = g[f"s{ci}_in"]
+    dt = float(g[f"s{ci}_dt"])
+    s = sg.Stream(n, m, d, dt)
+    vals, valid = zip(*[s.push(v) for v in x])
+    assert same_bits(np.array(vals, np.float32), g[f"s{ci}_push_val"])
+    assert np.array_equal(np.array(valid), g[f"s{ci}_push_valid"])
+    assert list(s.counters) == list(g[f"s{ci}_push_counters"])
+
+    s = sg.Stream(n, m, d, dt)
+    seq, counts = [], []
+    for v in x:
+        o = s.push_full(v)
+        counts.append(o.size); seq.extend(o.tolist())
+    assert np.array_equal(np.array(counts), g[f"s{ci}_full_counts"])
+    assert same_bits(np.array(seq, np.float32), g[f"s{ci}_full_seq"])
+    c, lead = s.flush_leading()
+    assert c == int(g[f"s{ci}_flush_leading_rc"]) and same_bits(lead, g[f"s{ci}_flush_leading"])
+    c, tail = s.flush()
+    assert c == int(g[f"s{ci}_flush_rc"]) and same_bits(tail, g[f"s{ci}_flush"])
+    assert list(s.counters) == list(g[f"s{ci}_full_counters"])
+
+    s = sg.Stream(n, m, d, dt)                 # max_outputs < n+1 silently truncates the burst (reference :209-218)
+    tr = []
+    for v in x:
+        tr.extend(s.push_full(v, 2).tolist())
+    assert same_bits(np.array(tr, np.float32), g[f"s{ci}_full_trunc2"])
+
+
+def test_single_stream_reference_test_scenarios(sg, torch_gpu):
+    """reference test_savgol_stream.c: lifecycle / latency / readiness / flush limits / stream == batch."""
+    L = sg.lib()
+    s = sg.Stream(5, 3)
+    assert L.savgol_stream_latency(s.ptr) == 5 and not L.savgol_stream_ready(s.ptr)
+    for i in range(10):
+        _, ok = s.push(float(i))
+        assert not ok
+    assert L.savgol_stream_buffered(s.ptr) == 10
+    _, ok = s.push(10.0)
+    assert ok and L.savgol_stream_ready(s.ptr) and L.savgol_stream_buffered(s.ptr) == 11
+    c, _ = s.flush(3)
+    assert c == 3                                                   # respects max_count
+    L.savgol_stream_reset(s.ptr)
+    assert s.counters == (0, 0, 0) and not L.savgol_stream_ready(s.ptr)
+    c, _ = s.flush()
+    assert c == 0                                                   # never filled
+    assert L.savgol_stream_flush(None, None, 3) == -1 and L.savgol_stream_flush_leading(None, None, 3) == 0
+    # stream == batch (push_full + flush vs savgol_apply), reference tolerance 1e-5   (:140-189)
+    rng = np.random.default_rng(1)
+    x = (np.sin(np.arange(100) * 0.1) + rng.normal(0, 0.05, 100)).astype(np.float32)
+    s = sg.Stream(5, 3)
+    seq = []
+    for v in x:
+        seq.extend(s.push_full(v).tolist())
+    seq.extend(s.flush()[1].tolist())
+    assert len(seq) == 100 and s.counters[1] == 100
+    batch = sg.Filter(5, 3).apply(x)
+    assert np.max(np.abs(np.array(seq, np.float32) - batch)) < 1e-5
+    # derivative stream: d/dx(2x) = 2 at the centre                                  (:191-224)
+    s = sg.Stream(5, 2, 1, 1.0)
+    outs = [s.push(2.0 * i) for i in range(30)]
+    assert all(abs(v - 2.0) < 0.01 for v, ok in outs if ok)
+    # user-allocated stream borrowing a filter (savgol_stream_init)
+    import ctypes as C
+    f = sg.Filter(3, 2)
+    st = sg.SavgolStream()
+    assert L.savgol_stream_init(C.byref(st), f.ptr) == 0 and not st.owns_filter
+    for i in range(7):
+        y = L.savgol_stream_push(C.byref(st), 4.0, None)           # output_valid may be NULL
+    assert abs(y - 4.0) < 1e-5 and st.samples_output == 1
+
+
+@pytest.mark.parametrize("cfg", [(16, 2, 1, 1e-3), (5, 3, 0, 1.0), (32, 4, 2, 0.5)])
+def test_stream_bank_bit_exact_vs_oracle(sg, sgo, torch_gpu, cfg):
+    torch = torch_gpu
+    n, m, d, dt = cfg
+    S, T = 1000, 3 * (2 * n + 1) + 5
+    rng = np.random.default_rng(n)
+    x = rng.normal(0, 1, (T, S)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    f = sgo.Filter(n, m, d, dt)
+    pick = [0, 1, 63, 64, 511, 999]
+    oracles = {s: sgo.Stream(f) for s in pick}
+
+    bank = sg.StreamBank(S, n, m, d, dt)
+    out = torch.zeros((n + 1, S), dtype=torch.float32, device="cuda")
+    for t in range(T):
+        rows = bank.push_full(xd[t], out, n + 1)
+        want = {s: oracles[s].push_full(x[t, s]) for s in pick}
+        assert rows == want[0].size, (t, rows)
+        if rows:
+            got = out[:rows].cpu().numpy()
+            for s in pick:
+                assert same_bits(got[:, s], want[s]), (t, s)
+    rows = bank.flush_leading(out, n)
+    got = out[:rows].cpu().numpy()
+    for s in pick:
+        c, w = oracles[s].flush_leading()
+        assert c == rows and same_bits(got[:, s], w)
+    rows = bank.flush(out, n)
+    got = out[:rows].cpu().numpy()
+    for s in pick:
+        c, w = oracles[s].flush()
+        assert c == rows and same_bits(got[:, s], w)
+    assert bank.counters == (T, oracles[0].counters[1])
+
+    # plain push + the multi-tick block push + checkpoint/resume give the same centre outputs
+    bank2 = sg.StreamBank(S, n, m, d, dt)
+    o1 = torch.zeros(S, dtype=torch.float32, device="cuda")
+    centre = []
+    for t in range(T):
+        if bank2.push(xd[t], o1) == 1:
+            centre.append(o1.cpu().numpy().copy())
+    centre = np.stack(centre)
+    bank3 = sg.StreamBank(S, n, m, d, dt)
+    ob = torch.full((T, S), np.nan, dtype=torch.float32, device="cuda")
+    half = T // 2
+    p1 = bank3.push_block(xd, half, ob)
+    blob = bank3.save()
+    bank4 = sg.StreamBank(S, n, m, d, dt)
+    bank4.load(blob)
+    p2 = bank4.push_block(xd[half:], T - half, ob[half:])
+    torch.cuda.synchronize()
+    assert p1 + p2 == centre.shape[0] == T - 2 * n
+    assert same_bits(ob[2 * n:].cpu().numpy(), centre)
+    assert torch.isnan(ob[:2 * n]).all()                                # ticks without output are not written
+    # and the centre outputs equal the oracle's push() sequence
+    for s in pick:
+        o = sgo.Stream(f)
+        seq = [o.push(v) for v in x[:, s]]
+        assert same_bits(np.array([v for v, ok in seq if ok], np.float32), centre[:, s])
+
+
+def test_stream_bank_config3_shape(sg, sgo, torch_gpu):
+    """BASELINE config 3: 65 536 streams, n=16, m=2, d=1, dt=1e-3 -- sampled streams, bit-exact."""
+    torch = torch_gpu
+    S, n, T = 65536, 16, 80
+    x = torch.empty((T, S), dtype=torch.float32, device="cuda")
+    sg.synth(x.view(T, S))                                  # rows = ticks here; any deterministic data will do
+    bank = sg.StreamBank(S, n, 2, 1, 1e-3)
+    out = torch.zeros((T, S), dtype=torch.float32, device="cuda")
+    produced = bank.push_block(x, T, out)
+    torch.cuda.synchronize()
+    assert produced == T - 2 * n
+    xh = x.cpu().numpy()
+    f = sgo.Filter(n, 2, 1, 1e-3)
+    for s in (0, 1, 4095, 32768, 65535):
+        o = sgo.Stream(f)
+        seq = np.array([v for v, ok in (o.push(v) for v in xh[:, s]) if ok], np.float32)
+        assert same_bits(out[2 * n:, s].cpu().numpy(), seq)
