@@ -197,8 +197,54 @@ struct Conv<float, N> {
     }
 };
 
+// fp64: the taps stay fp32 in SGPRs (65 doubles would not fit the scalar file) and are promoted -- exactly
+// -- with one v_cvt_f64_f32 each at the step where they are first needed.  In input-stationary order step I
+// uses taps I-OFF-r, r = 0..15: a sliding window of 16 taps, kept in 16 register pairs and recycled, so the
+// loop carries 16 accumulators + 16 promoted taps instead of 65 promoted taps (which spilled).  The cvt is
+// an asm that also names the current input, which pins it to its step.
+template <int N>
+struct Conv<double, N> {
+    typedef K1D<double, N> K;
+    template <int I, int Rr = 0>
+    static __device__ __forceinline__ void feed(double (&acc)[K::R], const double (&wd)[16], const double x)
+    {
+        if constexpr (Rr < K::R) {
+            constexpr int k = I - Rr - K::OFF;
+            if constexpr (k >= 0 && k <= 2 * N) acc[Rr] = __builtin_fma(wd[k & 15], x, acc[Rr]);
+            feed<I, Rr + 1>(acc, wd, x);
+        }
+    }
+    template <int I>
+    static __device__ __forceinline__ void step(double (&acc)[K::R], double (&wd)[16], const Taps &taps, const double x)
+    {
+        constexpr int knew = I - K::OFF;
+        if constexpr (knew >= 0 && knew <= 2 * N)
+            asm("v_cvt_f64_f32 %0, %1" : "=v"(wd[knew & 15]) : "s"(taps.w[knew]), "v"(x));
+        feed<I>(acc, wd, x);
+    }
+    template <int Q>
+    static __device__ __forceinline__ void vecs(const char *win, double (&acc)[K::R], double (&wd)[16], const Taps &taps)
+    {
+        if constexpr (Q < K::WQ) {
+            const double2 v = *reinterpret_cast<const double2 *>(win + 16 * (Q + (Q >> 3)));
+            step<2 * Q>(acc, wd, taps, v.x);
+            step<2 * Q + 1>(acc, wd, taps, v.y);
+            vecs<Q + 1>(win, acc, wd, taps);
+        }
+    }
+    static __device__ __forceinline__ void run(const char *win, const Taps &taps, double (&acc)[K::R])
+    {
+        double wd[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wd[j] = 0.0;
+#pragma unroll
+        for (int r = 0; r < K::R; ++r) acc[r] = 0.0;
+        vecs<0>(win, acc, wd, taps);
+    }
+};
+
 template <typename T, int N>
-__global__ __launch_bounds__(256, 4) void sg1d_center_kernel(const Job1D job, const Taps taps)
+__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_kernel(const Job1D job, const Taps taps)
 {
     typedef K1D<T, N> K;
     typedef typename K::VT VT;

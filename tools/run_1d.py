@@ -20,6 +20,7 @@ ap.add_argument("--dtype", default="f32")
 ap.add_argument("--channels", type=int, default=4096)
 ap.add_argument("--length", type=int, default=1 << 20)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--fill", default="synth", help="synth | zero | f32 (fp32-representable values)")
 ap.add_argument("--copy", action="store_true", help="also time a device-to-device copy of the same bytes")
 a = ap.parse_args()
 
@@ -28,6 +29,10 @@ tdt = torch.float32 if a.dtype == "f32" else torch.float64
 x = torch.empty((a.channels, a.length), dtype=tdt, device="cuda")
 y = torch.empty_like(x)
 sg.synth(x)
+if a.fill == 'zero':
+    x.zero_()
+elif a.fill == 'f32':
+    x.copy_(x.float().to(tdt))
 f = sg.Filter(a.n, a.m, a.d, 1.0, a.mode)
 f.apply_batch(x, y, a.channels, a.length, dtype=a.dtype)
 torch.cuda.synchronize()

@@ -11,13 +11,14 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int N>
-static void run(const float *in, float *out, unsigned channels, unsigned length, unsigned grid)
+template <typename T, int N>
+static void run(const T *in, T *out, unsigned channels, unsigned length, unsigned grid)
 {
     sg::Job1D job;
     memset(&job, 0, sizeof(job));
     job.in = in; job.out = out; job.in_ld = length; job.out_ld = length; job.length = length;
-    job.tiles_per_channel = (length + 2047) / 2048;
+    const unsigned TW = 64 * 128 / sizeof(T);
+    job.tiles_per_channel = (length + TW - 1) / TW;
     job.total_tiles = channels * job.tiles_per_channel;
     job.store_lo = 0; job.store_hi = length; job.out_shift = 0; job.dt_inv = 1.0f;
     job.flags = 1u | sg::JOB_VEC_IN | sg::JOB_VEC_OUT;
@@ -31,13 +32,13 @@ static void run(const float *in, float *out, unsigned channels, unsigned length,
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((sg::sg1d_center_kernel<float, N>), dim3(grid), dim3(256), 0, 0, job, taps);
+        hipLaunchKernelGGL((sg::sg1d_center_kernel<T, N>), dim3(grid), dim3(256), 0, 0, job, taps);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     }
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     std::vector<unsigned long long> st(64 * 8);
     CK(hipMemcpy(st.data(), d_st, 64 * 8 * 8, hipMemcpyDeviceToHost));
-    printf("N=%d grid=%u: %.3f ms (stamped build)\n", N, grid, ms);
+    printf("%s N=%d grid=%u: %.3f ms (stamped build)\n", sizeof(T) == 4 ? "f32" : "f64", N, grid, ms);
     printf("  iter:  wait+stage   prefetch-issue   compute   store   | total (cycles)\n");
     for (int it = 0; it < 12; ++it) {
         const unsigned long long *s = &st[it * 8];
@@ -52,8 +53,10 @@ int main()
     float *in, *out;
     CK(hipMalloc(&in, (size_t)channels * length * 4)); CK(hipMalloc(&out, (size_t)channels * length * 4));
     CK(hipMemset(in, 0, (size_t)channels * length * 4));
-    run<5>(in, out, channels, length, 1024);
-    run<32>(in, out, channels, length, 1024);
-    run<5>(in, out, channels, length, 256);
+    run<float, 5>(in, out, channels, length, 1024);
+    run<float, 32>(in, out, channels, length, 1024);
+    run<double, 32>((const double *)in, (double *)out, channels / 2, length, 1024);
+    run<double, 16>((const double *)in, (double *)out, channels / 2, length, 1024);
+    run<double, 5>((const double *)in, (double *)out, channels / 2, length, 1024);
     return 0;
 }
