@@ -59,6 +59,22 @@ def cpu_baseline(length, budget_s=12.0):
                       f"savgol_apply back to back for {el:.1f} s, 1 thread"}
 
 
+def pmc_traffic(ch, length):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of the same command
+    (FETCH_SIZE x2 for gfx950 + WRITE_SIZE, separate passes; see profiles/*_pmc_summary.json).  bench.py cannot
+    collect counters itself; the newest committed summary for the same workload is reported, else null."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_1d_f32_n32_pmc_summary.json"))):
+        try:
+            d = json.load(open(path))
+            if d.get("algorithmic_bytes_per_launch") == 8.0 * ch * length:
+                best = d["hbm_traffic_bytes_per_launch"]
+        except Exception:
+            pass
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,7 +172,7 @@ def main():
                        "channels_per_gpu": ch, "length": length, "sharding": "channels, no collective"},
             "roofline": {"bound": "hbm", "kernel": f"sg1d_center_kernel<float,{N}>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(ch, length),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
                          "launches_timed": len(launches_ms)},
             "parity_normwise_vs_fp64_oracle": checked,

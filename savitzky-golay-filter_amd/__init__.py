@@ -181,6 +181,18 @@ def _f(a):
     return a.ctypes.data_as(_fp)
 
 
+def shard_range(total, world_size, rank):
+    """Contiguous slice [lo, hi) of `total` independent units (channels, streams, images) owned by `rank`.
+
+    The hot path has no exchange step, so multi-GPU = every rank filters its own slice; the first
+    `total % world_size` ranks take one unit more."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad world_size / rank")
+    q, r = divmod(total, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
 class Filter:
     """RAII wrapper around savgol_create / savgol_destroy with the apply entry points as methods."""
 
