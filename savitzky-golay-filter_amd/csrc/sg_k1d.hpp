@@ -54,6 +54,31 @@ __device__ __forceinline__ void   vset(double2 &v, int e, double x) { if (e == 0
 __device__ __forceinline__ float  fma_t(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// streamed-once data: nontemporal loads/stores (SG_NT=0 falls back to the default cache policy)
+#ifndef SG_NT
+#define SG_NT 1
+#endif
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));      // the builtins want a native vector type
+template <typename VT> __device__ __forceinline__ VT ld_stream(const VT *p)
+{
+    static_assert(sizeof(VT) == 16, "16-byte vectors only");
+#if SG_NT
+    const u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return __builtin_bit_cast(VT, raw);
+#else
+    return *p;
+#endif
+}
+template <typename VT> __device__ __forceinline__ void st_stream(VT *p, const VT &v)
+{
+    static_assert(sizeof(VT) == 16, "16-byte vectors only");
+#if SG_NT
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4 *>(p));
+#else
+    *p = v;
+#endif
+}
+
 // lanes of one wave exchanging data through LDS: order the compiler's memory ops, nothing else
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -285,9 +310,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_ker
         const int ts = (int)(t - c * job.tiles_per_channel) * TW;
         if (tile_is_full(ts)) {
             const VT *src = reinterpret_cast<const VT *>(gin + (long long)c * job.in_ld + (ts - NA));
-            p0 = src[lane];       p1 = src[lane + 64];  p2 = src[lane + 128]; p3 = src[lane + 192];
-            p4 = src[lane + 256]; p5 = src[lane + 320]; p6 = src[lane + 384]; p7 = src[lane + 448];
-            if (lane < 2 * HV) p8 = src[512 + lane];
+            p0 = ld_stream(src + lane);       p1 = ld_stream(src + lane + 64);  p2 = ld_stream(src + lane + 128);
+            p3 = ld_stream(src + lane + 192); p4 = ld_stream(src + lane + 256); p5 = ld_stream(src + lane + 320);
+            p6 = ld_stream(src + lane + 384); p7 = ld_stream(src + lane + 448);
+            if (lane < 2 * HV) p8 = src[512 + lane];          // halo: re-read by the neighbour tile, keep it cached
         }
     };
 
@@ -376,7 +402,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_ker
             for (int s = 0; s < 8; ++s) {
                 const int p = lane + 64 * s;
                 const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off(p));
-                *reinterpret_cast<VT *>(orow + ts + p * E) = o;
+                st_stream(reinterpret_cast<VT *>(orow + ts + p * E), o);
             }
         } else {
             // first / last tile of a channel (the stored range ends inside it) or unaligned output rows

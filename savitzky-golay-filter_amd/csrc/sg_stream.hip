@@ -27,17 +27,38 @@
 
 namespace sg {
 
-// one ring dot product, reference order
-__device__ __forceinline__ float ring_dot_global(const float *__restrict__ ring, size_t streams, size_t s,
-                                                 const float *__restrict__ w, int ws, int wp, bool backward)
+// one ring dot product, reference order: taps ascending, ring walked forward from the oldest sample
+// (slot wp) or backward from the newest (slot wp-1), wrapping once.  `w` points into LDS (broadcast
+// reads).  The loads are issued 8 at a time so their latency overlaps; the multiply-add chain itself stays
+// strictly sequential (that is what makes the result bit-identical to the reference).
+template <typename Load>
+__device__ __forceinline__ float ring_dot(Load load, const float *w, int ws, int wp, bool backward)
 {
     float acc = 0.0f;
-    for (int i = 0; i < ws; ++i) {
+    int i = 0;
+    for (; i + 8 <= ws; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int slot = backward ? (wp + ws - 1 - (i + j)) : (wp + i + j);
+            if (slot >= ws) slot -= ws;
+            v[j] = load(slot);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __fadd_rn(acc, __fmul_rn(w[i + j], v[j]));
+    }
+    for (; i < ws; ++i) {
         int slot = backward ? (wp + ws - 1 - i) : (wp + i);
-        if (slot >= ws) slot -= ws;                                      // == % ws, operands are < 2 ws
-        acc = __fadd_rn(acc, __fmul_rn(w[i], ring[(size_t)slot * streams + s]));
+        if (slot >= ws) slot -= ws;
+        acc = __fadd_rn(acc, __fmul_rn(w[i], load(slot)));
     }
     return acc;
+}
+
+__device__ __forceinline__ float ring_dot_global(const float *__restrict__ ring, size_t streams, size_t s,
+                                                 const float *w, int ws, int wp, bool backward)
+{
+    return ring_dot([&](int slot) { return ring[(size_t)slot * streams + s]; }, w, ws, wp, backward);
 }
 
 // write one sample per stream at slot wp_old, then (if `emit`) the centre output of the window that
@@ -47,6 +68,11 @@ __global__ __launch_bounds__(256) void sg_bank_tick_kernel(float *__restrict__ r
                                                            const float *__restrict__ table, int ws, int wp_old,
                                                            float dt_inv, int emit)
 {
+    __shared__ float wl[SAVGOL_MAX_WINDOW];
+    if (emit) {
+        for (int i = threadIdx.x; i < ws; i += blockDim.x) wl[i] = table[i];
+        __syncthreads();
+    }
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= streams) return;
     ring[(size_t)wp_old * streams + s] = samples[s];
@@ -54,7 +80,7 @@ __global__ __launch_bounds__(256) void sg_bank_tick_kernel(float *__restrict__ r
     int wp = wp_old + 1;
     if (wp >= ws) wp -= ws;
     // the slot just written is read back by the same thread: program order is enough
-    out[s] = __fmul_rn(ring_dot_global(ring, streams, s, table, ws, wp, false), dt_inv);
+    out[s] = __fmul_rn(ring_dot_global(ring, streams, s, wl, ws, wp, false), dt_inv);
 }
 
 // rows of outputs from the current ring contents: row r uses table row rows[r] (0 = centre,
@@ -65,11 +91,13 @@ __global__ __launch_bounds__(256) void sg_bank_rows_kernel(const float *__restri
                                                            size_t streams, const float *__restrict__ table, int ws,
                                                            int wp, float dt_inv, const RowList rows)
 {
+    __shared__ float wl[SAVGOL_MAX_WINDOW];
+    const int r = blockIdx.y;
+    for (int i = threadIdx.x; i < ws; i += blockDim.x) wl[i] = table[(size_t)rows.row[r] * ws + i];
+    __syncthreads();
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= streams) return;
-    const int r = blockIdx.y;
-    const float *w = table + (size_t)rows.row[r] * ws;
-    out[(size_t)r * streams + s] = __fmul_rn(ring_dot_global(ring, streams, s, w, ws, wp, rows.backward[r] != 0), dt_inv);
+    out[(size_t)r * streams + s] = __fmul_rn(ring_dot_global(ring, streams, s, wl, ws, wp, rows.backward[r] != 0), dt_inv);
 }
 
 // `ticks` pushes with the ring in LDS: ringl[slot][thread] (bank = thread: conflict free)
@@ -80,25 +108,34 @@ __global__ __launch_bounds__(BLOCK_T) void sg_bank_block_kernel(float *__restric
                                                             const float *__restrict__ table, int ws, int wp0,
                                                             unsigned long long received0, size_t ticks, float dt_inv)
 {
-    extern __shared__ __attribute__((aligned(16))) float ringl[];       // [ws][BLOCK_T]
+    extern __shared__ __attribute__((aligned(16))) float ringl[];       // [ws][BLOCK_T], then the ws centre taps
+    float *wl = ringl + ws * BLOCK_T;
     const int tid = threadIdx.x;
+    for (int i = tid; i < ws; i += BLOCK_T) wl[i] = table[i];
     const size_t s = (size_t)blockIdx.x * blockDim.x + tid;
     const bool live = s < streams;
     for (int slot = 0; slot < ws; ++slot) ringl[slot * BLOCK_T + tid] = live ? ring[(size_t)slot * streams + s] : 0.0f;
+    __syncthreads();
     int wp = wp0;
     unsigned long long received = received0;
-    for (size_t t = 0; t < ticks; ++t) {
-        if (live) ringl[wp * BLOCK_T + tid] = samples[t * streams + s];
-        if (++wp >= ws) wp = 0;
-        ++received;
-        if (received >= (unsigned long long)ws) {
-            float acc = 0.0f;
-            int slot = wp;
-            for (int i = 0; i < ws; ++i) {
-                acc = __fadd_rn(acc, __fmul_rn(table[i], ringl[slot * BLOCK_T + tid]));
-                if (++slot >= ws) slot = 0;
+    // samples are fetched 16 ticks at a time so the HBM latency is paid once per 16 ticks, not per tick
+    constexpr int CH = 16;
+    for (size_t t0 = 0; t0 < ticks; t0 += CH) {
+        float nx[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) nx[j] = (live && t0 + j < ticks) ? samples[(t0 + j) * streams + s] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const size_t t = t0 + j;
+            if (t < ticks) {                                             // uniform
+                ringl[wp * BLOCK_T + tid] = nx[j];
+                if (++wp >= ws) wp = 0;
+                ++received;
+                if (received >= (unsigned long long)ws) {
+                    const float acc = ring_dot([&](int slot) { return ringl[slot * BLOCK_T + tid]; }, wl, ws, wp, false);
+                    if (live) out[t * streams + s] = __fmul_rn(acc, dt_inv);
+                }
             }
-            if (live) out[t * streams + s] = __fmul_rn(acc, dt_inv);
         }
     }
     if (live)
@@ -431,7 +468,7 @@ int savgol_streambank_push_block(SavgolStreamBank *bank, const float *d_samples,
     if (!bank || !d_samples || !d_out) { sg_set_error("savgol_streambank_push_block: NULL pointer"); return -1; }
     if (ticks == 0) return 0;
     const int ws = bank->filter->window_size;
-    const size_t lds = sizeof(float) * (size_t)ws * sg::BLOCK_T;
+    const size_t lds = sizeof(float) * ((size_t)ws * sg::BLOCK_T + (size_t)ws);
     const unsigned blocks = (unsigned)((bank->streams + sg::BLOCK_T - 1) / sg::BLOCK_T);
     hipLaunchKernelGGL(sg::sg_bank_block_kernel, dim3(blocks), dim3(sg::BLOCK_T), lds, static_cast<hipStream_t>(stream),
                        bank->d_ring, d_samples, d_out, bank->streams, bank->d_table, ws, bank->wp, bank->received, ticks,
