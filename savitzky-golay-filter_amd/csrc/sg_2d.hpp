@@ -1,0 +1,38 @@
+// sg_2d.hpp -- shared by the two 2-D kernel files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "sg_internal.h"
+
+namespace sg {
+
+struct Job2D {
+    const float *in;
+    float       *out;
+    int rows, cols, in_stride, out_stride;
+    long long in_pitch, out_pitch;      // elements between images
+    int nx, ny;
+    int boundary;                       // Savgol2DBoundary (anything else was mapped to CONSTANT by the host)
+    float scale;
+    int tiles_x, tiles_y;
+};
+
+// frame coordinate fix-up of the padded modes (reference src/savgol2d.c:428-445); VALID only clamps
+// (its out-of-frame reads feed outputs that are never stored)
+__device__ __forceinline__ int fix_index(int i, int n, int boundary)
+{
+    if (boundary == SAVGOL2D_BOUNDARY_REFLECT) {
+        if (i < 0) i = -i - 1; else if (i >= n) i = 2 * n - i - 1;
+    }
+    if (i < 0) i = 0; else if (i >= n) i = n - 1;
+    return i;
+}
+
+constexpr int SEP_MAX_TERMS = 4;
+
+// sg_2d_sep.hip
+int sg2d_separable_factors(const Savgol2DConfig *cfg, float *factors, int max_terms);   // returns #terms, 0 = not separable here
+int sg2d_launch_separable(int n, const Job2D &job, const float *d_factors, int terms, unsigned images, hipStream_t st);
+
+}  // namespace sg

@@ -12,7 +12,9 @@ from tests._util import bits, normwise
 from tests.golden.make_golden import CASES_2D, DERIVS
 
 pytestmark = pytest.mark.gpu
-TOL_SEP = 1e-6
+# separable method vs the double-accumulation oracle (normwise): smoothing 1e-6, derivative kernels 4e-6 (outputs ~1e-3 of the inputs: conditioning, not the method).
+# For scale: the reference's own dense fp32 sum sits 3e-7 .. 7.7e-6 from that oracle on the same frames.
+TOL_SEP, TOL_SEP_DERIV = 1e-6, 4e-6
 
 
 @pytest.fixture(scope="module")
@@ -114,3 +116,49 @@ def test_batch_device_entry_point(sg, sgo, torch_gpu):
             for k in range(images):
                 want = o.apply(x[k], cols, b, out=np.full((rows, stride), -5.0, np.float32))
                 assert same_bits(got[k], want), (nx, ny, order, dx, dy, b, k)
+
+
+@pytest.mark.parametrize("cfg", [(7, 3, 1.0, 1.0), (3, 2, 1.0, 1.0), (7, 4, 0.5, 2.0), (16, 3, 1.0, 1.0), (1, 2, 1.0, 1.0), (12, 2, 0.1, 0.1)])
+def test_separable_method_vs_double_oracle(sg, sgo, torch_gpu, cfg):
+    """method 2 (exact low-rank separable passes): fp32 rounding only -> <= TOL_SEP normwise vs the double-accumulation
+    oracle, for every derivative pair and all three boundary modes, on ragged frame sizes."""
+    torch = torch_gpu
+    n, order, ddx, ddy = cfg
+    rng = np.random.default_rng(n * 10 + order)
+    images, rows, cols, stride = 3, 2 * n + 71, 2 * n + 150, 2 * n + 152
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    x = np.zeros((images, rows, stride), np.float32)
+    for k in range(images):
+        x[k, :, :cols] = (np.sin(0.11 * xx + k) * np.cos(0.07 * yy) + 0.002 * xx + rng.normal(0, 0.1, (rows, cols))).astype(np.float32)
+    d = torch.from_numpy(x).cuda()
+    for dx, dy in DERIVS:
+        if dx + dy > order:
+            continue
+        f = sg.Filter2D(n, n, order, dx, dy, ddx, ddy)
+        o = sgo.Filter2D(n, n, order, dx, dy, ddx, ddy)
+        for b in range(3):
+            out = torch.full_like(d, -5.0)
+            f.apply_batch(d, out, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=2)
+            got = out.cpu().numpy()
+            for k in range(images):
+                hi = o.apply_f64acc(x[k], cols, b)
+                sel = np.zeros((rows, stride), bool)
+                if b == 0:
+                    sel[n:rows - n, n:cols - n] = True
+                else:
+                    sel[:, :cols] = True
+                assert np.all(got[k][~sel] == -5.0), "wrote outside the output region"
+                assert normwise(got[k][sel], hi[sel]) < (TOL_SEP if dx + dy == 0 else TOL_SEP_DERIV), (cfg, dx, dy, b, normwise(got[k][sel], hi[sel]))
+
+
+def test_separable_falls_back_or_refuses(sg, torch_gpu):
+    torch = torch_gpu
+    d = torch.zeros((64, 64), device="cuda")
+    out = torch.zeros_like(d)
+    with pytest.raises(RuntimeError):                        # rectangular window: no separable kernel
+        sg.Filter2D(4, 6, 3).apply_batch(d, out, 64, 64, 1, boundary=1, method=2)
+    with pytest.raises(RuntimeError):                        # order 6 smoothing has rank > 4
+        sg.Filter2D(16, 16, 6).apply_batch(d, out, 64, 64, 1, boundary=1, method=2)
+    sg.Filter2D(4, 6, 3).apply_batch(d, out, 64, 64, 1, boundary=1, method=0)        # auto: direct kernel
+    sg.Filter2D(16, 16, 6).apply_batch(d, out, 64, 64, 1, boundary=1, method=0)
+    torch.cuda.synchronize()
