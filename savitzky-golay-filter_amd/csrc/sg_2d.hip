@@ -142,11 +142,14 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
         if (terms > 0) {
             const float *d_f = ctx_table(ctx, factors, sizeof(float) * (size_t)terms * 2 * (2 * nx + 2), 0x5e000000u + (unsigned)nx);
             if (!d_f) return -1;
-            for (size_t i0 = 0; i0 < images; i0 += 65535) {
-                const size_t ni = images - i0 < 65535 ? images - i0 : 65535;
+            // chunks of images so that a launch indexes < 2^31 tiles
+            const size_t tiles_per_image = (size_t)((cols + 63) / 64) * (size_t)(rows / 1 + 1);
+            const size_t max_img = tiles_per_image ? ((size_t)1 << 30) / tiles_per_image + 1 : images;
+            for (size_t i0 = 0; i0 < images; i0 += max_img) {
+                const size_t ni = images - i0 < max_img ? images - i0 : max_img;
                 job.in = d_in + (long long)i0 * in_pitch;
                 job.out = d_out + (long long)i0 * out_pitch;
-                if (sg2d_launch_separable(nx, job, d_f, terms, (unsigned)ni, st) != 0) { sg_set_error("%s: no separable kernel for n=%d", who, nx); return -1; }
+                if (sg2d_launch_separable(nx, job, d_f, terms, (unsigned)ni, ctx->cu_count, st) != 0) { sg_set_error("%s: no separable kernel for n=%d", who, nx); return -1; }
             }
             return hip_ok(hipGetLastError(), who) ? 0 : -1;
         }

@@ -33,6 +33,6 @@ constexpr int SEP_MAX_TERMS = 4;
 
 // sg_2d_sep.hip
 int sg2d_separable_factors(const Savgol2DConfig *cfg, float *factors, int max_terms);   // returns #terms, 0 = not separable here
-int sg2d_launch_separable(int n, const Job2D &job, const float *d_factors, int terms, unsigned images, hipStream_t st);
+int sg2d_launch_separable(int n, const Job2D &job, const float *d_factors, int terms, unsigned images, int cu_count, hipStream_t st);
 
 }  // namespace sg

@@ -85,122 +85,166 @@ struct Sep {
     static constexpr int RYP = (RY + 1) & ~1;               // padded to an even count (pairs)
     static constexpr int PIN = ((64 + 2 * N + 15) & ~15) + 4;   // input tile pitch (floats): = 4 mod 16 -> the row pass's b128 reads are conflict free
     static constexpr int PH = 64 + 4;                       // intermediate pitch: 68 -> conflict-free column reads
-    static constexpr int LDS_FLOATS = ROWS * PIN + ROWS * PH + 2 * (2 * N + 2);
 };
 
 template <int N>
-__global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, const float *__restrict__ factors, int terms)
+__global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, const float *__restrict__ factors, int terms,
+                                                             unsigned total_tiles)
 {
     typedef Sep<N> S;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *tin = lds;                                   // [ROWS][PIN]
     float *hbuf = tin + S::ROWS * S::PIN;               // [ROWS][PH]
-    float *wl = hbuf + S::ROWS * S::PH;                 // Q_t (2N+2 floats) then G_t (2N+2 floats)
+    float *wl = hbuf + S::ROWS * S::PH;                 // per term: Q_t (2N+2 floats) then G_t (2N+2 floats)
 
     const int tid = threadIdx.x;
-    const int bx = blockIdx.x % job.tiles_x, by = blockIdx.x / job.tiles_x;
-    const long long img = blockIdx.y;
-    const float *in = job.in + img * job.in_pitch;
-    float *out = job.out + img * job.out_pitch;
-    const int x0 = bx * S::TW, y0 = by * S::TH;
-
-    // 1. input tile (frame rows y0-N .. y0+TH+N-1, columns x0-N .. x0+63+N), remapped at the frame border
     constexpr int TCOLS = 64 + 2 * N;
-    for (int i = tid; i < S::ROWS * TCOLS; i += 256) {
-        const int r = i / TCOLS, c = i - r * TCOLS;
-        const int iy = fix_index(y0 + r - N, job.rows, job.boundary);
-        const int ix = fix_index(x0 + c - N, job.cols, job.boundary);
-        tin[r * S::PIN + c] = in[(long long)iy * job.in_stride + ix];
-    }
 
-    f32x2 acc[S::RYP / 2];
+    // persistent blocks; blocks that share an XCD (blockIdx % 8) walk neighbouring tiles (halo reuse in L2)
+    const unsigned nblk = gridDim.x;
+    const unsigned blk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const unsigned tiles_per_image = (unsigned)(job.tiles_x * job.tiles_y);
+
+    for (int i = tid; i < terms * 2 * (2 * N + 2); i += 256) wl[i] = factors[i];
+
+    // input tile of tile id t: frame rows y0-N .. y0+TH+N-1, columns x0-N .. x0+63+N, remapped at the frame
+    // border (reference savgol2d.c:428-445).  Loaded into registers one tile ahead of the arithmetic.
+    // Input tile of tile id t: frame rows y0-N .. y0+TH+N-1, columns x0-N .. x0+63+N, remapped at the frame
+    // border (reference savgol2d.c:428-445), loaded into registers one tile ahead of the arithmetic.
+    // Wave w takes tile rows w, w+4, ...: the row index (and its remap) is scalar, a lane keeps its two
+    // remapped column indices for the whole tile -- no per-element division or remap.
+    constexpr int RPW = (S::ROWS + 3) / 4;              // rows per wave
+    float pre0[RPW], pre1[RPW];
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto prefetch = [&](unsigned t) {
+        const unsigned img = t / tiles_per_image, rem = t - img * tiles_per_image;
+        const int by = (int)(rem / (unsigned)job.tiles_x), bx = (int)(rem - (unsigned)by * (unsigned)job.tiles_x);
+        const float *in = job.in + (long long)img * job.in_pitch;
+        const int x0 = bx * S::TW, y0 = by * S::TH;
+        const int ix0 = fix_index(x0 + lane - N, job.cols, job.boundary);
+        const int ix1 = fix_index(x0 + lane + 64 - N, job.cols, job.boundary);
 #pragma unroll
-    for (int j = 0; j < S::RYP / 2; ++j) acc[j] = f32x2{0.0f, 0.0f};
+        for (int j = 0; j < RPW; ++j) {
+            const int r = wv + 4 * j;
+            if (r < S::ROWS) {                           // uniform
+                const float *row = in + (long long)fix_index(y0 + r - N, job.rows, job.boundary) * job.in_stride;
+                pre0[j] = row[ix0];
+                if (lane + 64 < TCOLS) pre1[j] = row[ix1];
+            }
+        }
+    };
+
+    unsigned tile = blk;
+    if (tile < total_tiles) prefetch(tile);
 
     const int crow = (tid >> 6) * S::RY;                // column pass: this lane's first output row (tile coords)
     const int ccol = tid & 63;
 
-    for (int t = 0; t < terms; ++t) {
-        __syncthreads();                                // tin ready / previous term's hbuf consumed
-        if (tid < 2 * (2 * N + 2)) wl[tid] = factors[t * 2 * (2 * N + 2) + tid];
-        __syncthreads();
-        // 2a. row pass: item = (tile row, 16-column segment); lane slides over 16 + 2N inputs
-        {
-            f32x2 Wq[N + 1];
+    while (tile < total_tiles) {
+        const unsigned img = tile / tiles_per_image, rem = tile - img * tiles_per_image;
+        const int by = (int)(rem / (unsigned)job.tiles_x), bx = (int)(rem - (unsigned)by * (unsigned)job.tiles_x);
+        float *out = job.out + (long long)img * job.out_pitch;
+        const int x0 = bx * S::TW, y0 = by * S::TH;
+
+        __syncthreads();                                // previous tile's passes are done with tin / hbuf
 #pragma unroll
-            for (int p = 0; p < N + 1; ++p) Wq[p] = f32x2{wl[2 * p], wl[2 * p + 1]};
-            const int item = tid;                       // ROWS * 4 <= 256 items
-            if (item < S::ROWS * 4) {
-                const int r = item >> 2, seg = item & 3;
-                const float *src = tin + r * S::PIN + seg * 16;
-                f32x2 A[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) A[j] = f32x2{0.0f, 0.0f};
-                WinConv<N, 16>::template quads<0>([&](int q) { return *reinterpret_cast<const float4 *>(src + 4 * q); }, A, Wq,
-                                                  f32x2{0.0f, 0.0f});
-                float *dst = hbuf + r * S::PH + seg * 16;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<float4 *>(dst + 4 * j) = make_float4(A[2 * j].x, A[2 * j].y, A[2 * j + 1].x, A[2 * j + 1].y);
+        for (int j = 0; j < RPW; ++j) {
+            const int r = wv + 4 * j;
+            if (r < S::ROWS) {
+                tin[r * S::PIN + lane] = pre0[j];
+                if (lane + 64 < TCOLS) tin[r * S::PIN + lane + 64] = pre1[j];
             }
         }
-        __syncthreads();
-        // 2b. column pass: lane = column ccol, rows crow .. crow+RY-1; window gathered down the column
-        {
-            f32x2 Wg[N + 1];
-#pragma unroll
-            for (int p = 0; p < N + 1; ++p) Wg[p] = f32x2{wl[(2 * N + 2) + 2 * p], wl[(2 * N + 2) + 2 * p + 1]};
-            const float *col = hbuf + crow * S::PH + ccol;
-            WinConv<N, S::RYP>::template quads<0>(
-                [&](int q) {
-                    // rows beyond the tile (only touched by the padded accumulator of an odd RY) read row ROWS-1
-                    const int r0 = 4 * q;
-                    auto rd = [&](int r) { return col[(crow + r < S::ROWS ? r : S::ROWS - 1 - crow) * S::PH]; };
-                    return make_float4(rd(r0), rd(r0 + 1), rd(r0 + 2), rd(r0 + 3));
-                },
-                acc, Wg, f32x2{0.0f, 0.0f});
-        }
-    }
+        const unsigned next = tile + nblk;
+        if (next < total_tiles) prefetch(next);
 
-    // 3. store
-    const int xlo = job.boundary == SAVGOL2D_BOUNDARY_VALID ? N : 0, xhi = job.boundary == SAVGOL2D_BOUNDARY_VALID ? job.cols - N : job.cols;
-    const int ylo = job.boundary == SAVGOL2D_BOUNDARY_VALID ? N : 0, yhi = job.boundary == SAVGOL2D_BOUNDARY_VALID ? job.rows - N : job.rows;
-    const int ox = x0 + ccol;
+        f32x2 acc[S::RYP / 2];
 #pragma unroll
-    for (int j = 0; j < S::RY; ++j) {
-        const int oy = y0 + crow + j;
-        const float v = (j & 1) ? acc[j >> 1].y : acc[j >> 1].x;
-        if (ox >= xlo && ox < xhi && oy >= ylo && oy < yhi && oy < y0 + S::TH) out[(long long)oy * job.out_stride + ox] = v * job.scale;
+        for (int j = 0; j < S::RYP / 2; ++j) acc[j] = f32x2{0.0f, 0.0f};
+
+        for (int t = 0; t < terms; ++t) {
+            __syncthreads();                            // tin ready / previous term's hbuf consumed
+            const float *wt = wl + t * 2 * (2 * N + 2);
+            // 2a. row pass: item = (tile row, 16-column segment); lane slides over 16 + 2N inputs
+            {
+                f32x2 Wq[N + 1];
+#pragma unroll
+                for (int p = 0; p < N + 1; ++p) Wq[p] = f32x2{wt[2 * p], wt[2 * p + 1]};
+                if (tid < S::ROWS * 4) {
+                    const int r = tid >> 2, seg = tid & 3;
+                    const float *src = tin + r * S::PIN + seg * 16;
+                    f32x2 A[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) A[j] = f32x2{0.0f, 0.0f};
+                    WinConv<N, 16>::template quads<0>([&](int q) { return *reinterpret_cast<const float4 *>(src + 4 * q); }, A, Wq,
+                                                      f32x2{0.0f, 0.0f});
+                    float *dst = hbuf + r * S::PH + seg * 16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<float4 *>(dst + 4 * j) = make_float4(A[2 * j].x, A[2 * j].y, A[2 * j + 1].x, A[2 * j + 1].y);
+                }
+            }
+            __syncthreads();
+            // 2b. column pass: lane = column ccol, rows crow .. crow+RY-1; window gathered down the column
+            {
+                f32x2 Wg[N + 1];
+#pragma unroll
+                for (int p = 0; p < N + 1; ++p) Wg[p] = f32x2{wt[(2 * N + 2) + 2 * p], wt[(2 * N + 2) + 2 * p + 1]};
+                const float *col = hbuf + crow * S::PH + ccol;
+                WinConv<N, S::RYP>::template quads<0>(
+                    [&](int q) {
+                        // rows beyond the tile (only touched by the padded accumulator of an odd RY) read row ROWS-1
+                        const int r0 = 4 * q;
+                        auto rd = [&](int r) { return col[(crow + r < S::ROWS ? r : S::ROWS - 1 - crow) * S::PH]; };
+                        return make_float4(rd(r0), rd(r0 + 1), rd(r0 + 2), rd(r0 + 3));
+                    },
+                    acc, Wg, f32x2{0.0f, 0.0f});
+            }
+        }
+
+        // 3. store
+        const bool valid = job.boundary == SAVGOL2D_BOUNDARY_VALID;
+        const int xlo = valid ? N : 0, xhi = valid ? job.cols - N : job.cols;
+        const int ylo = valid ? N : 0, yhi = valid ? job.rows - N : job.rows;
+        const int ox = x0 + ccol;
+#pragma unroll
+        for (int j = 0; j < S::RY; ++j) {
+            const int oy = y0 + crow + j;
+            const float v = (j & 1) ? acc[j >> 1].y : acc[j >> 1].x;
+            if (ox >= xlo && ox < xhi && oy >= ylo && oy < yhi) out[(long long)oy * job.out_stride + ox] = v * job.scale;
+        }
+        tile = next;
     }
 }
 
 template <int N>
-static void launch_sep(const Job2D &job, const float *d_factors, int terms, unsigned images, hipStream_t st)
+static void launch_sep(const Job2D &job, const float *d_factors, int terms, unsigned images, int cu_count, hipStream_t st)
 {
     typedef Sep<N> S;
     Job2D j = job;
     j.tiles_x = (job.cols + S::TW - 1) / S::TW;
     j.tiles_y = (job.rows + S::TH - 1) / S::TH;
-    const size_t lds = sizeof(float) * S::LDS_FLOATS;
-    static bool attr_done = false;
-    if (!attr_done && lds > 65536) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sg2d_separable_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((sg2d_separable_kernel<N>), dim3((unsigned)(j.tiles_x * j.tiles_y), images), dim3(256), lds, st, j, d_factors, terms);
+    const size_t lds = sizeof(float) * (S::ROWS * S::PIN + S::ROWS * S::PH + SEP_MAX_TERMS * 2 * (2 * N + 2));
+    const unsigned long long total = (unsigned long long)images * j.tiles_x * j.tiles_y;      // caller keeps this < 2^32
+    const unsigned per_cu = (unsigned)(160 * 1024 / lds) < 4u ? (unsigned)(160 * 1024 / lds) : 4u;
+    unsigned grid = (unsigned)cu_count * (per_cu ? per_cu : 1u);
+    if (grid > total) grid = (unsigned)total;
+    grid = (grid + 7u) & ~7u;
+    hipLaunchKernelGGL((sg2d_separable_kernel<N>), dim3(grid), dim3(256), lds, st, j, d_factors, terms, (unsigned)total);
 }
 
 template <int N>
-static int dispatch_sep(int n, const Job2D &job, const float *d_factors, int terms, unsigned images, hipStream_t st)
+static int dispatch_sep(int n, const Job2D &job, const float *d_factors, int terms, unsigned images, int cu_count, hipStream_t st)
 {
-    if (n == N) { launch_sep<N>(job, d_factors, terms, images, st); return 1; }
-    if constexpr (N < SAVGOL2D_MAX_HALF_WINDOW) return dispatch_sep<N + 1>(n, job, d_factors, terms, images, st);
+    if (n == N) { launch_sep<N>(job, d_factors, terms, images, cu_count, st); return 1; }
+    if constexpr (N < SAVGOL2D_MAX_HALF_WINDOW) return dispatch_sep<N + 1>(n, job, d_factors, terms, images, cu_count, st);
     else return 0;
 }
 
-int sg2d_launch_separable(int n, const Job2D &job, const float *d_factors, int terms, unsigned images, hipStream_t st)
+int sg2d_launch_separable(int n, const Job2D &job, const float *d_factors, int terms, unsigned images, int cu_count, hipStream_t st)
 {
-    return dispatch_sep<1>(n, job, d_factors, terms, images, st) ? 0 : -1;
+    return dispatch_sep<1>(n, job, d_factors, terms, images, cu_count, st) ? 0 : -1;
 }
 
 // ---- host: exact low-rank factors of the least-squares kernel, in double ----

@@ -151,14 +151,19 @@ def test_separable_method_vs_double_oracle(sg, sgo, torch_gpu, cfg):
                 assert normwise(got[k][sel], hi[sel]) < (TOL_SEP if dx + dy == 0 else TOL_SEP_DERIV), (cfg, dx, dy, b, normwise(got[k][sel], hi[sel]))
 
 
-def test_separable_falls_back_or_refuses(sg, torch_gpu):
+def test_separable_rank4_and_rectangular_fallback(sg, sgo, torch_gpu):
     torch = torch_gpu
-    d = torch.zeros((64, 64), device="cuda")
+    rng = np.random.default_rng(8)
+    x = rng.normal(0, 1, (90, 100)).astype(np.float32)
+    d = torch.from_numpy(x).cuda()
     out = torch.zeros_like(d)
+    # order 6: by parity only every other power of y occurs, so the rank is at most 4 -- still separable
+    f = sg.Filter2D(16, 16, 6)
+    f.apply_batch(d, out, 90, 100, 1, boundary=2, method=2)
+    hi = sgo.Filter2D(16, 16, 6).apply_f64acc(x, 100, 2)
+    assert normwise(out.cpu().numpy(), hi) < 2e-6
     with pytest.raises(RuntimeError):                        # rectangular window: no separable kernel
-        sg.Filter2D(4, 6, 3).apply_batch(d, out, 64, 64, 1, boundary=1, method=2)
-    with pytest.raises(RuntimeError):                        # order 6 smoothing has rank > 4
-        sg.Filter2D(16, 16, 6).apply_batch(d, out, 64, 64, 1, boundary=1, method=2)
-    sg.Filter2D(4, 6, 3).apply_batch(d, out, 64, 64, 1, boundary=1, method=0)        # auto: direct kernel
-    sg.Filter2D(16, 16, 6).apply_batch(d, out, 64, 64, 1, boundary=1, method=0)
-    torch.cuda.synchronize()
+        sg.Filter2D(4, 6, 3).apply_batch(d, out, 90, 100, 1, boundary=1, method=2)
+    sg.Filter2D(4, 6, 3).apply_batch(d, out, 90, 100, 1, boundary=1, method=0)        # auto: falls back to the dense kernel
+    want = sgo.Filter2D(4, 6, 3).apply(x, 100, 1)
+    assert np.array_equal(out.cpu().numpy(), want)           # ... which is bit-identical to the reference order
