@@ -95,7 +95,8 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     if (!ctx) return -1;
 
     constexpr int E = 16 / (int)sizeof(T);
-    constexpr unsigned TW = 64u * 8u * E;
+    const int vpl = sg::vectors_per_lane(sizeof(T), f->config.half_window);
+    const unsigned TW = 64u * (unsigned)vpl * E;
     const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
     const bool poly = (mode == SAVGOL_BOUNDARY_POLYNOMIAL);
 
@@ -139,8 +140,9 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         job.total_tiles = (unsigned)(nc * job.tiles_per_channel);
         unsigned blocks = (job.total_tiles + 3u) / 4u;
         static const char *env_bpc = getenv("SAVGOL_HIP_BLOCKS_PER_CU");           // tuning knob (default 4: LDS bound)
-        const unsigned bpc = env_bpc ? (unsigned)atoi(env_bpc) : 4u;
-        const unsigned resident = (unsigned)ctx->cu_count * (bpc ? bpc : 4u);
+        const unsigned bpc_default = vpl <= 4 ? 7u : vpl <= 6 ? 5u : 4u;                 // LDS-bound residency
+        const unsigned bpc = env_bpc ? (unsigned)atoi(env_bpc) : bpc_default;
+        const unsigned resident = (unsigned)ctx->cu_count * (bpc ? bpc : bpc_default);
         if (blocks > resident) blocks = resident;
         blocks = (blocks + 7u) & ~7u;                                    // the XCD remap wants a multiple of 8
         if (sg::launch_center<T>(n, job, taps, blocks, st) != 0) return -1;

@@ -108,21 +108,28 @@ template <typename T, int N>
 struct K1D {
     typedef typename V16<T>::type VT;
     static constexpr int E    = V16<T>::E;
-    static constexpr int R    = 8 * E;                       // outputs per lane
+    static constexpr int VPL  = vectors_per_lane(sizeof(T), N); // 16-B vectors of output per lane (sg_k1d_host.hpp)
+    static constexpr int R    = VPL * E;                     // outputs per lane
+    static constexpr int TV   = 64 * VPL;                    // vectors of output per tile
     static constexpr int TW   = 64 * R;                      // outputs per tile
     static constexpr int NA   = (N + E - 1) / E * E;         // halo rounded to whole vectors
     static constexpr int OFF  = NA - N;
     static constexpr int HV   = NA / E;                      // halo vectors per side
-    static constexpr int SV   = 512 + 2 * HV;                // vectors in a slab
+    static constexpr int SV   = TV + 2 * HV;                 // vectors in a slab
     static constexpr int SL   = SV * E;                      // elements in a slab
     static constexpr int WQ   = (NA + R + N + E - 1) / E;    // vectors a lane reads
-    static constexpr int SLAB = 16 * (SV + (SV + 7) / 8);    // bytes, padded
-    static constexpr int WAVES = 4;
+    static constexpr int SLAB = 16 * (SV + (SV + VPL - 1) / VPL);   // bytes: one pad vector after every VPL
+    static constexpr int WAVES = 4;                          // waves per block, each with its own slab
+    // waves per SIMD the register allocation must allow (the LDS slabs allow as many blocks per CU)
+    static constexpr int MIN_WAVES = sizeof(T) == 8 ? 3 : (VPL <= 4 ? 7 : VPL <= 6 ? 5 : 4);
     static_assert(2 * HV <= 64, "halo must fit one extra vector per lane");
-    static_assert(WQ <= SV - 8 * 63, "lane 63's window must stay inside the slab");
+    static_assert(WQ <= SV - VPL * 63, "lane 63's window must stay inside the slab");
+    static_assert(VPL == 4 || VPL == 6 || VPL == 8, "lane stride (VPL+1)*16 B must be conflict free for ds_read_b128");
 };
 
-__device__ __forceinline__ int slab_vec_off(int v) { return 16 * (v + (v >> 3)); }
+// byte offset of slab vector v: one 16-B pad after every VPL vectors, so a lane's VPL vectors are contiguous and
+// the lane stride is (VPL+1)*16 B = 20 / 28 / 36 banks -- conflict free for the ds_read_b128 lane groups
+template <int VPL> __device__ __forceinline__ constexpr int slab_vec_off(int v) { return 16 * (v + v / VPL); }
 
 
 // ---------------------------------------------------------------------------------------------
@@ -140,7 +147,7 @@ struct Conv {                      // generic form (used for fp64): one v_fma pe
         for (int r = 0; r < R; ++r) acc[r] = T(0);
 #pragma unroll
         for (int q = 0; q < K::WQ; ++q) {
-            const VT v = *reinterpret_cast<const VT *>(win + 16 * (q + (q >> 3)));
+            const VT v = *reinterpret_cast<const VT *>(win + slab_vec_off<K::VPL>(q));
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const T x = vget(v, e);
@@ -180,6 +187,20 @@ __device__ __forceinline__ f32x2 pk_straddle(const f32x2 a, const f32x2 b)
     return o;
 }
 
+#ifndef SG_ODD_FROM_LDS
+#define SG_ODD_FROM_LDS 0   /* measured: 7.72 ms vs 7.40 ms at N=32 -- the extra LDS latency costs more than the v_pk_mov_b32 it saves */
+#endif
+// window elements I and I+1 of this lane, as an aligned register pair (the slab is padded by one 16-B
+// vector after every 8, hence the index arithmetic; both offsets are literals)
+template <int I, int VPL = 8>
+__device__ __forceinline__ f32x2 lds_pair(const char *win)
+{
+    constexpr int a = slab_vec_off<VPL>(I >> 2) / 4 + (I & 3);
+    constexpr int b = slab_vec_off<VPL>((I + 1) >> 2) / 4 + ((I + 1) & 3);
+    const float *w = reinterpret_cast<const float *>(win);
+    return f32x2{w[a], w[b]};
+}
+
 template <int N>
 struct Conv<float, N> {
     typedef K1D<float, N> K;
@@ -194,18 +215,27 @@ struct Conv<float, N> {
         }
     }
     template <int Q>
-    static __device__ __forceinline__ void quads(const char *win, f32x2 (&A)[K::R / 2], const f32x2 (&W)[33], f32x2 prev)
+    static __device__ __forceinline__ void quads(const char *win, const char *win_odd, f32x2 (&A)[K::R / 2], const f32x2 (&W)[33], f32x2 prev)
     {
         if constexpr (Q < K::WQ) {
-            const float4 v = *reinterpret_cast<const float4 *>(win + 16 * (Q + (Q >> 3)));
+            const float4 v = *reinterpret_cast<const float4 *>(win + slab_vec_off<K::VPL>(Q));
             const f32x2 e0 = {v.x, v.y}, e1 = {v.z, v.w};
+#if SG_ODD_FROM_LDS
+            // pairs that start at an odd index are read straight from the slab (ds_read2_b32: the LDS pipe has
+            // slack, the VALU does not) instead of being assembled with v_pk_mov_b32
+            if constexpr (Q > 0) feed<4 * Q - 1>(A, W, lds_pair<4 * Q - 1, K::VPL>(win_odd));
+            feed<4 * Q>(A, W, e0);
+            feed<4 * Q + 1>(A, W, lds_pair<4 * Q + 1, K::VPL>(win_odd));
+            feed<4 * Q + 2>(A, W, e1);
+#else
             if constexpr (Q > 0) {
                 feed<4 * Q - 1>(A, W, pk_straddle(prev, e0));
             }
             feed<4 * Q>(A, W, e0);
             feed<4 * Q + 1>(A, W, pk_straddle(e0, e1));
             feed<4 * Q + 2>(A, W, e1);
-            quads<Q + 1>(win, A, W, e1);
+#endif
+            quads<Q + 1>(win, win_odd, A, W, e1);
         }
     }
     static __device__ __forceinline__ void run(const char *win, const Taps &taps, float (&acc)[K::R])
@@ -216,7 +246,12 @@ struct Conv<float, N> {
         f32x2 A[K::R / 2];
 #pragma unroll
         for (int j = 0; j < K::R / 2; ++j) A[j] = f32x2{0.0f, 0.0f};
-        quads<0>(win, A, W, f32x2{0.0f, 0.0f});
+        // same address, but opaque to the compiler: otherwise it forwards the odd pairs out of the quad registers
+        // (two v_mov each) instead of reading them from LDS
+        int delta = 0;
+        asm("" : "+v"(delta));                        // 0 at run time; keeps win_odd an LDS pointer
+        const char *win_odd = win + delta;
+        quads<0>(win, win_odd, A, W, f32x2{0.0f, 0.0f});
 #pragma unroll
         for (int j = 0; j < K::R / 2; ++j) { acc[2 * j] = A[j].x; acc[2 * j + 1] = A[j].y; }
     }
@@ -251,7 +286,7 @@ struct Conv<double, N> {
     static __device__ __forceinline__ void vecs(const char *win, double (&acc)[K::R], double (&wd)[16], const Taps &taps)
     {
         if constexpr (Q < K::WQ) {
-            const double2 v = *reinterpret_cast<const double2 *>(win + 16 * (Q + (Q >> 3)));
+            const double2 v = *reinterpret_cast<const double2 *>(win + slab_vec_off<K::VPL>(Q));
             step<2 * Q>(acc, wd, taps, v.x);
             step<2 * Q + 1>(acc, wd, taps, v.y);
             vecs<Q + 1>(win, acc, wd, taps);
@@ -269,11 +304,11 @@ struct Conv<double, N> {
 };
 
 template <typename T, int N>
-__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_kernel(const Job1D job, const Taps taps)
+__global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kernel(const Job1D job, const Taps taps)
 {
     typedef K1D<T, N> K;
     typedef typename K::VT VT;
-    constexpr int E = K::E, R = K::R, TW = K::TW, NA = K::NA, OFF = K::OFF, HV = K::HV;
+    constexpr int E = K::E, R = K::R, TW = K::TW, NA = K::NA, HV = K::HV, VPL = K::VPL, TV = K::TV;
 
     __shared__ __attribute__((aligned(16))) char smem[K::WAVES * K::SLAB];
     const int lane = threadIdx.x & 63;
@@ -311,9 +346,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_ker
         if (tile_is_full(ts)) {
             const VT *src = reinterpret_cast<const VT *>(gin + (long long)c * job.in_ld + (ts - NA));
             p0 = ld_stream(src + lane);       p1 = ld_stream(src + lane + 64);  p2 = ld_stream(src + lane + 128);
-            p3 = ld_stream(src + lane + 192); p4 = ld_stream(src + lane + 256); p5 = ld_stream(src + lane + 320);
-            p6 = ld_stream(src + lane + 384); p7 = ld_stream(src + lane + 448);
-            if (lane < 2 * HV) p8 = src[512 + lane];          // halo: re-read by the neighbour tile, keep it cached
+            p3 = ld_stream(src + lane + 192);
+            if constexpr (VPL > 4) { p4 = ld_stream(src + lane + 256); p5 = ld_stream(src + lane + 320); }
+            if constexpr (VPL > 6) { p6 = ld_stream(src + lane + 384); p7 = ld_stream(src + lane + 448); }
+            if (lane < 2 * HV) p8 = src[TV + lane];           // halo: re-read by the neighbour tile, keep it cached
         }
     };
 
@@ -335,10 +371,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_ker
 
         // ---- stage tile + halo into the slab ----
         if (tile_is_full(ts)) {
-            VT *dst = reinterpret_cast<VT *>(slab + slab_vec_off(lane));     // +64 vectors = +72 slots
-            dst[0] = p0;   dst[72] = p1;  dst[144] = p2; dst[216] = p3;
-            dst[288] = p4; dst[360] = p5; dst[432] = p6; dst[504] = p7;
-            if (lane < 2 * HV) dst[576] = p8;
+            auto put = [&](int s, const VT &v) { *reinterpret_cast<VT *>(slab + slab_vec_off<VPL>(lane + 64 * s)) = v; };
+            put(0, p0); put(1, p1); put(2, p2); put(3, p3);
+            if constexpr (VPL > 4) { put(4, p4); put(5, p5); }
+            if constexpr (VPL > 6) { put(6, p6); put(7, p7); }
+            if (lane < 2 * HV) put(VPL, p8);
         } else {
             // Channel ends, short rows, rows without 16-B alignment.  Vectors that lie wholly inside the
             // row are still moved as vectors; the rest (the part of the halo that sticks out of the row,
@@ -346,11 +383,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_ker
             const bool vec = (job.flags & JOB_VEC_IN) != 0;
             const int lim = L + NA;                                      // nothing beyond is ever used
 #pragma unroll
-            for (int s = 0; s < 9; ++s) {
+            for (int s = 0; s < VPL + 1; ++s) {
                 const int v = lane + 64 * s;
                 const int g0 = ts - NA + v * E;
                 if (v < K::SV && vec && g0 >= 0 && g0 + E <= L)
-                    *reinterpret_cast<VT *>(slab + slab_vec_off(v)) = *reinterpret_cast<const VT *>(row + g0);
+                    *reinterpret_cast<VT *>(slab + slab_vec_off<VPL>(v)) = *reinterpret_cast<const VT *>(row + g0);
             }
 #pragma unroll 4
             for (int e = lane; e < K::SL; e += 64) {
@@ -361,7 +398,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_ker
                     bool zero = false;
                     if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
                     const T x = zero ? T(0) : row[g];
-                    *reinterpret_cast<T *>(slab + slab_vec_off(e / E) + (e % E) * (int)sizeof(T)) = x;
+                    *reinterpret_cast<T *>(slab + slab_vec_off<VPL>(e / E) + (e % E) * (int)sizeof(T)) = x;
                 }
             }
         }
@@ -376,7 +413,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_ker
 
         // ---- the convolution: lane owns outputs [lane*R, lane*R + R) of the tile ----
         T acc[R];
-        Conv<T, N>::run(slab + 16 * (lane * 9), taps, acc);
+        Conv<T, N>::run(slab + 16 * (lane * (VPL + 1)), taps, acc);
         if (job.flags & JOB_SCALE) {
             const T s = (T)job.dt_inv;
 #pragma unroll
@@ -387,11 +424,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_ker
 
         // ---- results back through the slab, then coalesced rows to HBM ----
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < VPL; ++s) {
             VT o;
 #pragma unroll
             for (int e = 0; e < E; ++e) vset(o, e, acc[s * E + e]);
-            *reinterpret_cast<VT *>(slab + 16 * (lane * 9 + s)) = o;
+            *reinterpret_cast<VT *>(slab + 16 * (lane * (VPL + 1) + s)) = o;
         }
         wave_lds_sync();
         T *__restrict__ orow = gout + (long long)c * job.out_ld - (long long)job.out_shift;
@@ -399,19 +436,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void sg1d_center_ker
         const bool whole = (job.flags & JOB_VEC_OUT) && ts >= lo && ts + TW <= hi;
         if (whole) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < VPL; ++s) {
                 const int p = lane + 64 * s;
-                const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off(p));
+                const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(p));
                 st_stream(reinterpret_cast<VT *>(orow + ts + p * E), o);
             }
         } else {
             // first / last tile of a channel (the stored range ends inside it) or unaligned output rows
             const bool vec = (job.flags & JOB_VEC_OUT) != 0;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < VPL; ++s) {
                 const int p = lane + 64 * s;
                 const int g0 = ts + p * E;
-                const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off(p));
+                const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(p));
                 if (vec && g0 >= lo && g0 + E <= hi) {
                     *reinterpret_cast<VT *>(orow + g0) = o;
                 } else {

@@ -12,6 +12,16 @@ namespace sg {
 // SGPR pairs to v_pk_fma_f32 and picks the tap with op_sel.
 struct alignas(8) Taps { float w[SAVGOL_MAX_WINDOW + 1]; };
 
+// 16-byte vectors of output each lane owns (tile = 64 lanes x VPL vectors of one channel).  Host and kernels must
+// agree.  The kernel supports 4, 6 and 8 (lane strides of 20 / 28 / 36 banks are all conflict free); 8 -> 8 KiB
+// tiles, 9.5 KB of LDS per wave, 4 waves per SIMD.  Smaller tiles buy occupancy (6 -> 5 waves/SIMD, 4 -> 7) but
+// A/B runs in one process (tools/ab_1d.py, n = 24/28/32) have 8 ahead by 1 % over 6 and 3-7 % over 4: the wide
+// windows are limited by VALU issue at the clock the chip sustains, not by latency hiding.
+#ifndef SG_VPL_F32_WIDE
+#define SG_VPL_F32_WIDE 8          /* fp32, half_window >= 24; A/B builds override this */
+#endif
+constexpr int vectors_per_lane(size_t elem_size, int half_window) { return (elem_size == 4 && half_window >= 24) ? SG_VPL_F32_WIDE : 8; }
+
 struct Job1D {
     const void *in;
     void       *out;
