@@ -1,0 +1,66 @@
+"""Row-band split of the 2-D path across GPUs, with a nearest-neighbour halo exchange.
+
+Images are independent, so the default multi-GPU layout is "each rank filters its own images" and needs no
+communication.  When a frame stack must instead be split *inside* each frame (frames too large for one GPU,
+or fewer frames than GPUs), every rank owns a horizontal band of rows and needs `ny` rows from the bands
+above and below before it can filter: that is the only exchange step anywhere on the hot path
+(SURVEY.md section 8e).  It is point-to-point -- one `isend`/`irecv` pair per neighbour, batched for the whole
+stack -- so on MI355X it rides one xGMI link per neighbour pair (RCCL, `backend="nccl"`); there is no
+all-reduce.
+
+    band = RowBand(rows, ny, rank, world)            # which rows this rank owns
+    ext  = band.exchange(local)                      # local [images, own_rows, cols] -> + halo rows from neighbours
+    out  = band.apply(ext, apply_fn)                 # apply_fn(frames[images, R, cols]) -> same shape; returns own rows
+
+`apply_fn` is the 2-D batch filter with the caller's boundary mode (`Filter2D.apply_batch` on the GPU).  The band
+buffer is filtered as if it were a frame: where its edge is the real frame edge the boundary mode applies there,
+as the reference does (src/savgol2d.c:428-445); where the edge is artificial the rows it taints are exactly the
+halo rows, which are dropped.  VALID leaves the frame's own top/bottom `ny` rows untouched, like the reference.
+"""
+import torch
+import torch.distributed as dist
+
+from . import shard_range
+
+
+class RowBand:
+    def __init__(self, rows, ny, rank=None, world_size=None):
+        self.world = dist.get_world_size() if world_size is None else world_size
+        self.rank = dist.get_rank() if rank is None else rank
+        self.rows, self.ny = rows, ny
+        self.lo, self.hi = shard_range(rows, self.world, self.rank)
+        spans = [shard_range(rows, self.world, r) for r in range(self.world)]
+        if self.world > 1 and min(hi - lo for lo, hi in spans) < ny:
+            raise ValueError(f"row bands thinner than the half window ({ny}): use fewer ranks")
+        self.top = ny if self.rank > 0 else 0                 # halo rows received from above / below
+        self.bottom = ny if self.rank < self.world - 1 else 0
+
+    def exchange(self, local):
+        """local: [images, hi-lo, cols] tensor of this rank's rows.  Returns [images, top + own + bottom, cols]."""
+        images, own, cols = local.shape
+        assert own == self.hi - self.lo
+        ext = torch.empty((images, self.top + own + self.bottom, cols), dtype=local.dtype, device=local.device)
+        ext[:, self.top:self.top + own] = local
+        if self.world == 1:
+            return ext
+        ops, keep = [], []
+        if self.top:                                          # my first ny rows go up, the neighbour's last ny come down
+            send_up = local[:, :self.ny].contiguous()
+            recv_up = torch.empty_like(send_up)
+            ops += [dist.P2POp(dist.isend, send_up, self.rank - 1), dist.P2POp(dist.irecv, recv_up, self.rank - 1)]
+            keep.append((recv_up, slice(0, self.top)))
+        if self.bottom:
+            send_dn = local[:, own - self.ny:].contiguous()
+            recv_dn = torch.empty_like(send_dn)
+            ops += [dist.P2POp(dist.isend, send_dn, self.rank + 1), dist.P2POp(dist.irecv, recv_dn, self.rank + 1)]
+            keep.append((recv_dn, slice(self.top + own, self.top + own + self.bottom)))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for buf, rows in keep:
+            ext[:, rows] = buf
+        return ext
+
+    def apply(self, ext, apply_fn):
+        """Filter the extended band and return this rank's own rows [images, hi-lo, cols]."""
+        out = apply_fn(ext)
+        return out[:, self.top:self.top + (self.hi - self.lo)]

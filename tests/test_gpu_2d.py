@@ -167,3 +167,29 @@ def test_separable_rank4_and_rectangular_fallback(sg, sgo, torch_gpu):
     sg.Filter2D(4, 6, 3).apply_batch(d, out, 90, 100, 1, boundary=1, method=0)        # auto: falls back to the dense kernel
     want = sgo.Filter2D(4, 6, 3).apply(x, 100, 1)
     assert np.array_equal(out.cpu().numpy(), want)           # ... which is bit-identical to the reference order
+
+
+def test_row_bands_on_gpu_equal_whole_frame(sg, torch_gpu):
+    """The row-band split (rowband.py) with the real GPU filter as `apply_fn`: two bands built by hand (the halo
+    exchange itself is covered by the gloo test), stitched, must equal the whole-frame result of the same kernel."""
+    import importlib
+    torch = torch_gpu
+    rowband = importlib.import_module("savgol_amd.rowband")
+    rng = np.random.default_rng(5)
+    images, rows, cols, n = 2, 150, 200, 7
+    x = torch.from_numpy(rng.normal(0, 1, (images, rows, cols)).astype(np.float32)).cuda()
+    f = sg.Filter2D(n, n, 3)
+    for b in range(3):
+        for method in (1, 2):
+            def apply_fn(frames):
+                out = torch.full_like(frames, -9.0)
+                f.apply_batch(frames.contiguous(), out, frames.shape[1], cols, images, boundary=b, method=method)
+                return out
+            whole = apply_fn(x)
+            parts = []
+            for rank in range(2):
+                band = rowband.RowBand(rows, n, rank=rank, world_size=2)
+                ext = x[:, band.lo - band.top:band.hi + band.bottom].contiguous()     # what exchange() would assemble
+                parts.append(band.apply(ext, apply_fn))
+            got = torch.cat(parts, dim=1)
+            assert torch.equal(got, whole), (b, method, (got - whole).abs().max().item())
