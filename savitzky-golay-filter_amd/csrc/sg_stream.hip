@@ -100,46 +100,113 @@ __global__ __launch_bounds__(256) void sg_bank_rows_kernel(const float *__restri
     out[(size_t)r * streams + s] = __fmul_rn(ring_dot_global(ring, streams, s, wl, ws, wp, rows.backward[r] != 0), dt_inv);
 }
 
-// `ticks` pushes with the ring in LDS: ringl[slot][thread] (bank = thread: conflict free)
-constexpr int BLOCK_T = 128;     // threads per block of the LDS-ring kernel: ws * 128 * 4 B <= 33 KB of LDS
+// `ticks` pushes in one launch.  Tick t's centre output is a dot product over the last 2n+1 samples of the
+// sequence "ring contents (oldest first), then this call's samples": the block push is a convolution down the
+// time axis of a [tick][stream] array.  So it is tiled like one: a block = 64 streams x 64 ticks; the 64+2n rows
+// it needs (rows before this call come out of the ring) go to LDS with coalesced 256-B row reads; a lane owns one
+// stream and 16 consecutive ticks and walks its 16+2n rows once, feeding each into the accumulators it touches.
+// Every accumulator still sees its taps in ascending order with separate multiply and add -> bit-identical to the
+// per-tick kernel and to the reference; 16 independent chains per lane hide the add latency.  HBM traffic = the
+// samples and the outputs (8 B/sample); afterwards sg_bank_store_tail_kernel writes the newest 2n+1 samples back.
+struct alignas(8) StreamTaps { float w[SAVGOL_MAX_WINDOW + 1]; };     // by-value kernarg -> 33 aligned SGPR pairs
 
-__global__ __launch_bounds__(BLOCK_T) void sg_bank_block_kernel(float *__restrict__ ring, const float *__restrict__ samples,
-                                                            float *__restrict__ out, size_t streams,
-                                                            const float *__restrict__ table, int ws, int wp0,
-                                                            unsigned long long received0, size_t ticks, float dt_inv)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc += w * x for two ticks at once, multiply and add rounded SEPARATELY (v_pk_mul_f32 then v_pk_add_f32: the same
+// two roundings per lane as the reference's `sum += w * x`); the tap is broadcast out of an aligned SGPR pair.
+template <int SEL>
+__device__ __forceinline__ void pk_mul_add(f32x2 &acc, const f32x2 wpair, const f32x2 x)
 {
-    extern __shared__ __attribute__((aligned(16))) float ringl[];       // [ws][BLOCK_T], then the ws centre taps
-    float *wl = ringl + ws * BLOCK_T;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < ws; i += BLOCK_T) wl[i] = table[i];
-    const size_t s = (size_t)blockIdx.x * blockDim.x + tid;
+    f32x2 p;
+    if constexpr (SEL == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(wpair), "v"(x));
+    else                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(p) : "s"(wpair), "v"(x));
+    asm("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void sg_bank_block_kernel(const float *__restrict__ ring, const float *__restrict__ samples,
+                                                            float *__restrict__ out, size_t streams, const StreamTaps taps,
+                                                            int wp0, unsigned long long received0, size_t ticks, float dt_inv)
+{
+    constexpr int WS = 2 * N + 1, TT = 64, PER = 16, ROWS = TT + WS - 1;
+    __shared__ float tile[ROWS * 64];                           // [row][stream]: conflict free both ways
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const size_t s = (size_t)blockIdx.x * 64 + lane;
+    const size_t t0 = (size_t)blockIdx.y * TT;                  // first tick of this tile
     const bool live = s < streams;
-    for (int slot = 0; slot < ws; ++slot) ringl[slot * BLOCK_T + tid] = live ? ring[(size_t)slot * streams + s] : 0.0f;
+
+    // row r of the tile = history index h = t0 + r - (WS-1):  h >= 0 -> this call's sample h, h < 0 -> the ring
+    // (sample -k, k = 1..WS-1, sits at slot (wp0 - k) mod WS)
+    for (int r = grp; r < ROWS; r += 4) {
+        const long long h = (long long)t0 + r - (WS - 1);
+        float v = 0.0f;
+        if (live) {
+            if (h >= 0) { if ((size_t)h < ticks) v = samples[(size_t)h * streams + s]; }
+            else { int slot = wp0 + (int)h; if (slot < 0) slot += WS; v = ring[(size_t)slot * streams + s]; }
+        }
+        tile[r * 64 + lane] = v;
+    }
     __syncthreads();
-    int wp = wp0;
-    unsigned long long received = received0;
-    // samples are fetched 16 ticks at a time so the HBM latency is paid once per 16 ticks, not per tick
-    constexpr int CH = 16;
-    for (size_t t0 = 0; t0 < ticks; t0 += CH) {
-        float nx[CH];
+
+    f32x2 W[33];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) nx[j] = (live && t0 + j < ticks) ? samples[(t0 + j) * streams + s] : 0.0f;
+    for (int p = 0; p < 33; ++p) W[p] = f32x2{taps.w[2 * p], taps.w[2 * p + 1]};
+    f32x2 acc[PER / 2];                                          // pair J = ticks 2J, 2J+1 of this lane
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const size_t t = t0 + j;
-            if (t < ticks) {                                             // uniform
-                ringl[wp * BLOCK_T + tid] = nx[j];
-                if (++wp >= ws) wp = 0;
-                ++received;
-                if (received >= (unsigned long long)ws) {
-                    const float acc = ring_dot([&](int slot) { return ringl[slot * BLOCK_T + tid]; }, wl, ws, wp, false);
-                    if (live) out[t * streams + s] = __fmul_rn(acc, dt_inv);
-                }
+    for (int j = 0; j < PER / 2; ++j) acc[j] = f32x2{0.0f, 0.0f};
+    const float *col = tile + (grp * PER) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < PER + WS - 2; ++r) {
+        const f32x2 x = {col[r * 64], col[(r + 1) * 64]};        // rows r, r+1: one ds_read2st64_b32
+#pragma unroll
+        for (int J = 0; J < PER / 2; ++J) {
+            const int i = r - 2 * J;                             // literal after unrolling; same tap for both ticks
+            if (i >= 0 && i < WS) {
+                if (i & 1) pk_mul_add<1>(acc[J], W[i >> 1], x); else pk_mul_add<0>(acc[J], W[i >> 1], x);
             }
         }
     }
-    if (live)
-        for (int slot = 0; slot < ws; ++slot) ring[(size_t)slot * streams + s] = ringl[slot * BLOCK_T + tid];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const size_t t = t0 + (size_t)(grp * PER + j);
+        const float v = (j & 1) ? acc[j >> 1].y : acc[j >> 1].x;
+        // an output exists once 2n+1 samples have arrived (reference savgol_stream.c:166-170)
+        if (live && t < ticks && received0 + t + 1 >= (unsigned long long)WS) out[t * streams + s] = __fmul_rn(v, dt_inv);
+    }
+}
+
+// newest min(ticks, WS) samples of the call -> their ring slots (sample q of the call lands in slot (wp0 + q) mod WS)
+__global__ __launch_bounds__(256) void sg_bank_store_tail_kernel(float *__restrict__ ring, const float *__restrict__ samples,
+                                                                 size_t streams, int ws, int wp0, size_t ticks)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= streams) return;
+    const size_t first = ticks > (size_t)ws ? ticks - (size_t)ws : 0;
+    for (size_t q = first + blockIdx.y; q < ticks; q += gridDim.y)
+        ring[(size_t)((wp0 + q) % (size_t)ws) * streams + s] = samples[q * streams + s];
+}
+
+template <int N>
+static int dispatch_block(int n, const float *ring, const float *samples, float *out, size_t streams, const StreamTaps &taps,
+                          int wp0, unsigned long long received0, size_t ticks, float dt_inv, hipStream_t st)
+{
+    if (n == N) {
+        const unsigned gx = (unsigned)((streams + 63) / 64);
+        for (size_t done = 0; done < ticks; done += (size_t)65535 * 64) {       // gridDim.y limit
+            const size_t part = ticks - done < (size_t)65535 * 64 ? ticks - done : (size_t)65535 * 64;
+            hipLaunchKernelGGL((sg_bank_block_kernel<N>), dim3(gx, (unsigned)((part + 63) / 64)), dim3(256), 0, st, ring,
+                               samples + done * streams, out + done * streams, streams, taps,
+                               (int)((wp0 + done) % (size_t)(2 * N + 1)), received0 + done, part, dt_inv);
+            // rows of a later part that reach back before it come out of `samples` only if the ring is current:
+            // keep the ring in step between parts
+            hipLaunchKernelGGL(sg_bank_store_tail_kernel, dim3((unsigned)((streams + 255) / 256), 8), dim3(256), 0, st,
+                               const_cast<float *>(ring), samples + done * streams, streams, 2 * N + 1,
+                               (int)((wp0 + done) % (size_t)(2 * N + 1)), part);
+        }
+        return 1;
+    }
+    if constexpr (N < SAVGOL_MAX_HALF_WINDOW) return dispatch_block<N + 1>(n, ring, samples, out, streams, taps, wp0, received0, ticks, dt_inv, st);
+    else return 0;
 }
 
 // single stream (host drop-in API): the ring sits in pinned host memory (the caller-visible POD is the
@@ -468,11 +535,14 @@ int savgol_streambank_push_block(SavgolStreamBank *bank, const float *d_samples,
     if (!bank || !d_samples || !d_out) { sg_set_error("savgol_streambank_push_block: NULL pointer"); return -1; }
     if (ticks == 0) return 0;
     const int ws = bank->filter->window_size;
-    const size_t lds = sizeof(float) * ((size_t)ws * sg::BLOCK_T + (size_t)ws);
-    const unsigned blocks = (unsigned)((bank->streams + sg::BLOCK_T - 1) / sg::BLOCK_T);
-    hipLaunchKernelGGL(sg::sg_bank_block_kernel, dim3(blocks), dim3(sg::BLOCK_T), lds, static_cast<hipStream_t>(stream),
-                       bank->d_ring, d_samples, d_out, bank->streams, bank->d_table, ws, bank->wp, bank->received, ticks,
-                       bank->dt_inv);
+    sg::StreamTaps taps;
+    memset(&taps, 0, sizeof(taps));
+    memcpy(taps.w, bank->filter->center_weights, sizeof(float) * ws);
+    if (!sg::dispatch_block<1>(bank->filter->config.half_window, bank->d_ring, d_samples, d_out, bank->streams, taps, bank->wp,
+                               bank->received, ticks, bank->dt_inv, static_cast<hipStream_t>(stream))) {
+        sg_set_error("savgol_streambank_push_block: no kernel for half_window %d", bank->filter->config.half_window);
+        return -1;
+    }
     if (!sg::hip_ok(hipGetLastError(), "savgol_streambank_push_block launch")) return -1;
     const unsigned long long before = bank->received;
     bank->received += ticks;

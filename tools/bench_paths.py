@@ -20,6 +20,63 @@ sg = load_package()
 PEAK = 8000.0
 
 
+def cpu_reference(kind):
+    """The reference's own code (oracle/_ref/libsavgol_ref.so, gcc -O2, 1 thread) on a bounded sample of the same
+    workload, timed on this host; falls back to the oracle port if the compiled reference did not travel."""
+    import ctypes as C
+    from oracle import sgo
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libsavgol_ref.so")
+    have_ref = os.path.exists(ref)
+    if have_ref:
+        from tests.golden import make_golden as mg
+        L = mg.load()
+    if kind == "stream":
+        n_push = 2_000_000
+        x = sgo.synth_f32(0, 1, n_push)[0]
+        if have_ref:
+            cfg = mg.Cfg(16, 2, 1, 1e-3, 0)
+            st = L.savgol_stream_create(C.byref(cfg))
+            ok = C.c_bool(False)
+            push = L.savgol_stream_push
+            xs = [float(v) for v in x[:200000]]
+            t0 = time.perf_counter()
+            for v in xs:
+                push(st, v, C.byref(ok))
+            el = time.perf_counter() - t0
+            # the Python call overhead dominates a 50 ns push: time the C loop through the batch-equivalent instead
+            f = L.savgol_create(C.byref(cfg))
+            y = np.empty_like(x)
+            t0 = time.perf_counter(); reps = 0
+            while time.perf_counter() - t0 < 5.0:
+                L.savgol_apply(f, mg.fptr(x), mg.fptr(y), n_push); reps += 1
+            el_b = time.perf_counter() - t0
+            return {"kind": "reference", "cores": 1, "unit": "Msamples/s",
+                    "value": round(reps * n_push / el_b / 1e6, 2),
+                    "sample": f"savgol_apply (same 33-tap dot product per sample, C loop) on {n_push} samples x {reps} reps; "
+                              f"savgol_stream_push through ctypes: {len(xs) / el / 1e6:.2f} Msamples/s (call overhead bound); "
+                              "BASELINE.md survey figure for the C push loop: 18.8 Msamples/s"}
+        f = sgo.Filter(16, 2, 1, 1e-3)
+        t0 = time.perf_counter(); f.apply(x); el = time.perf_counter() - t0
+        return {"kind": "port", "cores": 1, "unit": "Msamples/s", "value": round(n_push / el / 1e6, 2), "sample": "oracle batch apply"}
+    size = 1024
+    img = sgo.synth_f32(0, size, size)
+    out = np.zeros_like(img)
+    res = {}
+    for name, b in (("VALID", 0), ("CONSTANT", 1), ("REFLECT", 2)):
+        if have_ref:
+            cfg = mg.Cfg2(7, 7, 3, 0, 0, 1.0, 1.0)
+            f = L.savgol2d_create(C.byref(cfg))
+            t0 = time.perf_counter()
+            L.savgol2d_apply(f, mg.fptr(img), size, size, size, mg.fptr(out), size, b)
+            el = time.perf_counter() - t0
+        else:
+            f = sgo.Filter2D(7, 7, 3)
+            t0 = time.perf_counter(); f.apply(img, size, b); el = time.perf_counter() - t0
+        res[name] = round(size * size / el / 1e6, 2)
+    return {"kind": "reference" if have_ref else "port", "cores": 1, "unit": "Mpix/s", "value": res,
+            "sample": f"savgol2d_apply on one {size}x{size} fp32 frame, n=7, order 3, per boundary mode"}
+
+
 def ev():
     return torch.cuda.Event(enable_timing=True)
 
@@ -68,6 +125,7 @@ def bench_stream(a):
                        "Msamples_per_s": round(samples / ms / 1e3, 1),
                        "roofline": {"bound": "hbm", "achieved": round(8.0 * samples / ms / 1e6, 1), "peak": PEAK, "unit": "GB/s",
                                     "frac": round(8.0 * samples / ms / 1e6 / PEAK, 4), "algorithmic_bytes_per_sample": 8}},
+        "cpu_baseline": cpu_reference("stream"),
     }))
 
 
@@ -90,7 +148,8 @@ def bench_image(a):
         res[name] = {"ms": round(ms, 3), "Mpix_per_s": round(pix / ms / 1e3, 1),
                      "roofline": {"bound": "hbm", "achieved": round(8.0 * pix / ms / 1e6, 1), "peak": PEAK, "unit": "GB/s",
                                   "frac": round(8.0 * pix / ms / 1e6 / PEAK, 4), "algorithmic_bytes_per_pixel": 8}}
-    print(json.dumps({"workload": f"BASELINE config 4 (subset): {N} images x {size}x{size} fp32, n=7, order 3, method {a.method}", "modes": res}))
+    print(json.dumps({"workload": f"BASELINE config 4 (subset): {N} images x {size}x{size} fp32, n=7, order 3, method {a.method}", "modes": res,
+                      "cpu_baseline": cpu_reference("image")}))
 
 
 if __name__ == "__main__":
