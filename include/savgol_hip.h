@@ -109,6 +109,23 @@ int savgol2d_apply_batch_f32(const Savgol2DFilter *filter,
                              float *d_out, int out_stride, size_t out_image_pitch,
                              size_t images, Savgol2DBoundary boundary, int method, void *stream);
 
+/* Fused derivative frames (arithmetic of savgol2d_gradient / _hessian / _laplacian, src/savgol2d.c:462-618): every
+ * requested output is produced from ONE read of each input tile; the Laplacian uses the single summed kernel
+ * (scale_xx*Wxx + scale_yy*Wyy), no temporary frame.  Outputs may be NULL (skipped), like the reference.  Square
+ * windows use the separable kernel (fp32 rounding only vs the reference); others one dense pass per output.      */
+int savgol2d_gradient_batch_f32(int half_win_x, int half_win_y, int poly_order,
+                                const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,
+                                float *d_grad_x, float *d_grad_y, int out_stride, size_t out_image_pitch,
+                                size_t images, float delta_x, float delta_y, Savgol2DBoundary boundary, void *stream);
+int savgol2d_hessian_batch_f32(int half_win_x, int half_win_y, int poly_order,
+                               const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,
+                               float *d_xx, float *d_xy, float *d_yy, int out_stride, size_t out_image_pitch,
+                               size_t images, float delta_x, float delta_y, Savgol2DBoundary boundary, void *stream);
+int savgol2d_laplacian_batch_f32(int half_win_x, int half_win_y, int poly_order,
+                                 const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,
+                                 float *d_out, int out_stride, size_t out_image_pitch,
+                                 size_t images, float delta_x, float delta_y, Savgol2DBoundary boundary, void *stream);
+
 /* ---------------------------------------------------------------- bench utilities ----- *
  * Synthetic workload of SURVEY.md section 8(d), generated in HBM (never crosses PCIe):
  * x[c][i] = sin(2 pi f_c i) + 0.5 sin(2 pi 7.3 f_c i + phi_c) + 0.1 u(c,i).                  */

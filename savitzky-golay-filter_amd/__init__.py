@@ -119,6 +119,9 @@ SIGNATURES = {
     "savgol_streambank_load": (C.c_int, [_vp, _vp, _vp]),
     # savgol_hip.h: 2-D batch
     "savgol2d_apply_batch_f32": (C.c_int, [_F2, _vp, C.c_int, C.c_int, C.c_int, _sz, _vp, C.c_int, _sz, _sz, C.c_int, C.c_int, _vp]),
+    "savgol2d_gradient_batch_f32": (C.c_int, [C.c_int] * 3 + [_vp, C.c_int, C.c_int, C.c_int, _sz, _vp, _vp, C.c_int, _sz, _sz, C.c_float, C.c_float, C.c_int, _vp]),
+    "savgol2d_hessian_batch_f32": (C.c_int, [C.c_int] * 3 + [_vp, C.c_int, C.c_int, C.c_int, _sz, _vp, _vp, _vp, C.c_int, _sz, _sz, C.c_float, C.c_float, C.c_int, _vp]),
+    "savgol2d_laplacian_batch_f32": (C.c_int, [C.c_int] * 3 + [_vp, C.c_int, C.c_int, C.c_int, _sz, _vp, C.c_int, _sz, _sz, C.c_float, C.c_float, C.c_int, _vp]),
     # savgol_hip.h: bench utilities
     "savgol_hip_synth_f32": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_uint64, _vp]),
     "savgol_hip_synth_f64": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_uint64, _vp]),

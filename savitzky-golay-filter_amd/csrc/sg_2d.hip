@@ -149,7 +149,10 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
                 const size_t ni = images - i0 < max_img ? images - i0 : max_img;
                 job.in = d_in + (long long)i0 * in_pitch;
                 job.out = d_out + (long long)i0 * out_pitch;
-                if (sg2d_launch_separable(nx, job, d_f, terms, (unsigned)ni, ctx->cu_count, st) != 0) { sg_set_error("%s: no separable kernel for n=%d", who, nx); return -1; }
+                SepPlan plan;
+                memset(&plan, 0, sizeof(plan));
+                plan.outputs = 1; plan.terms[0] = terms; plan.scale[0] = f->scale; plan.out[0] = job.out;
+                if (sg2d_launch_separable(nx, job, plan, d_f, (unsigned)ni, ctx->cu_count, st) != 0) { sg_set_error("%s: no separable kernel for n=%d", who, nx); return -1; }
             }
             return hip_ok(hipGetLastError(), who) ? 0 : -1;
         }
@@ -255,6 +258,145 @@ int savgol2d_apply_batch_f32(const Savgol2DFilter *filter, const float *d_in, in
 {
     return sg::enqueue_2d("savgol2d_apply_batch_f32", filter, d_in, rows, cols, in_stride, (long long)in_image_pitch, d_out,
                           out_stride, (long long)out_image_pitch, images, (int)boundary, method, static_cast<hipStream_t>(stream));
+}
+
+// ---- fused multi-output device entry points: ONE read of each input tile feeds every requested
+//      derivative frame; the Laplacian is a single filter with the summed kernel (no temporary frame, no add pass).
+//      Square windows run the separable kernel; other shapes fall back to one dense pass per output. ----
+namespace sg {
+
+struct DerivSpec { int dx, dy; float *out; };
+
+static int enqueue_derivatives(const char *who, int nx, int ny, int order, const float *d_in, int rows, int cols, int in_stride,
+                               size_t in_pitch, const DerivSpec *specs, int nspec, bool sum_into_one, int out_stride,
+                               size_t out_pitch, size_t images, float delta_x, float delta_y, int boundary, hipStream_t st)
+{
+    if (!d_in || nspec <= 0) { sg_set_error("%s: NULL pointer", who); return -1; }
+    Savgol2DConfig cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.half_window_x = (uint8_t)nx; cfg.half_window_y = (uint8_t)ny; cfg.poly_order = (uint8_t)order;
+    cfg.delta_x = delta_x; cfg.delta_y = delta_y;
+    if (nx < 0 || nx > 255 || ny < 0 || ny > 255 || order < 0 || order > 255) { sg_set_error("%s: invalid configuration", who); return -1; }
+    for (int i = 0; i < nspec; ++i) {
+        cfg.deriv_x = (uint8_t)specs[i].dx; cfg.deriv_y = (uint8_t)specs[i].dy;
+        if (!sg2d_config_ok(&cfg)) { sg_set_error("%s: invalid configuration", who); return -1; }
+    }
+    if (rows <= 0 || cols <= 0 || in_stride < cols || out_stride < cols) { sg_set_error("%s: bad image geometry", who); return -1; }
+    if (boundary == SAVGOL2D_BOUNDARY_VALID && (rows - 2 * ny <= 0 || cols - 2 * nx <= 0)) { sg_set_error("%s: image smaller than the window", who); return -1; }
+    if (images == 0) return 0;
+    DeviceCtx *ctx = ctx_get();
+    if (!ctx) return -1;
+
+    if (nx != ny) {                                       // dense fallback: one filter per output (reference structure)
+        float *sum_out = specs[0].out;
+        for (int i = 0; i < nspec; ++i) {
+            cfg.deriv_x = (uint8_t)specs[i].dx; cfg.deriv_y = (uint8_t)specs[i].dy;
+            Savgol2DFilter *f = savgol2d_create(&cfg);
+            if (!f) return -1;
+            float *dst = specs[i].out;
+            std::unique_lock<std::recursive_mutex> lock(ctx->mu, std::defer_lock);
+            if (sum_into_one && i > 0) {                 // d2/dy2 into scratch, then out += scratch (reference :598-613)
+                lock.lock();
+                dst = static_cast<float *>(ctx_arena(ctx, sizeof(float) * images * out_pitch));
+                if (!dst) { savgol2d_destroy(f); return -1; }
+                if (!hip_ok(hipMemsetAsync(dst, 0, sizeof(float) * images * out_pitch, st), who)) { savgol2d_destroy(f); return -1; }
+            }
+            int rc = enqueue_2d(who, f, d_in, rows, cols, in_stride, (long long)in_pitch, dst, out_stride, (long long)out_pitch, images, boundary, 1, st);
+            savgol2d_destroy(f);
+            if (rc != 0) return rc;
+            if (sum_into_one && i > 0) {
+                for (size_t k = 0; k < images; ++k)
+                    hipLaunchKernelGGL(sg2d_add_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, st, sum_out + k * out_pitch,
+                                       dst + k * out_pitch, rows, cols, out_stride);
+                if (!hip_ok(hipStreamSynchronize(st), who)) return -1;        // scratch is released with the lock
+            }
+        }
+        return hip_ok(hipGetLastError(), who) ? 0 : -1;
+    }
+
+    const int n = nx, ws = 2 * n + 1;
+    static thread_local double Wd[33 * 33], Wsum[33 * 33];
+    float factors[SEP_MAX_OUTPUTS * SEP_MAX_TERMS * 2 * (2 * SAVGOL2D_MAX_HALF_WINDOW + 2)];
+    SepPlan plan;
+    memset(&plan, 0, sizeof(plan));
+    int total_terms = 0;
+    if (sum_into_one) {
+        for (int i = 0; i < ws * ws; ++i) Wsum[i] = 0.0;
+        for (int i = 0; i < nspec; ++i) {
+            cfg.deriv_x = (uint8_t)specs[i].dx; cfg.deriv_y = (uint8_t)specs[i].dy;
+            if (sg2d_kernel_double(&cfg, Wd) != 0) { sg_set_error("%s: weight computation failed", who); return -1; }
+            const double sc = (double)sg2d_scale(&cfg);
+            for (int k = 0; k < ws * ws; ++k) Wsum[k] += sc * Wd[k];
+        }
+        const int t = sg2d_factors_from_kernel(Wsum, n, order, factors, SEP_MAX_TERMS);
+        if (t <= 0) { sg_set_error("%s: kernel is not separable with <= %d terms", who, SEP_MAX_TERMS); return -1; }
+        plan.outputs = 1; plan.terms[0] = t; plan.scale[0] = 1.0f; plan.out[0] = specs[0].out;
+        total_terms = t;
+    } else {
+        for (int i = 0; i < nspec; ++i) {
+            cfg.deriv_x = (uint8_t)specs[i].dx; cfg.deriv_y = (uint8_t)specs[i].dy;
+            const int t = sg2d_separable_factors(&cfg, factors + (size_t)total_terms * 2 * (ws + 1), SEP_MAX_TERMS);
+            if (t <= 0) { sg_set_error("%s: kernel is not separable with <= %d terms", who, SEP_MAX_TERMS); return -1; }
+            plan.terms[plan.outputs] = t; plan.scale[plan.outputs] = sg2d_scale(&cfg); plan.out[plan.outputs] = specs[i].out;
+            plan.outputs++;
+            total_terms += t;
+        }
+    }
+    const float *d_f = ctx_table(ctx, factors, sizeof(float) * (size_t)total_terms * 2 * (ws + 1), 0x6d000000u + (unsigned)n);
+    if (!d_f) return -1;
+    Job2D job;
+    memset(&job, 0, sizeof(job));
+    job.in = d_in;
+    job.rows = rows; job.cols = cols; job.in_stride = in_stride; job.out_stride = out_stride;
+    job.in_pitch = (long long)in_pitch; job.out_pitch = (long long)out_pitch;
+    job.nx = n; job.ny = n;
+    job.boundary = (boundary == SAVGOL2D_BOUNDARY_VALID || boundary == SAVGOL2D_BOUNDARY_REFLECT) ? boundary : SAVGOL2D_BOUNDARY_CONSTANT;
+    if (sg2d_launch_separable(n, job, plan, d_f, (unsigned)images, ctx->cu_count, st) != 0) { sg_set_error("%s: no separable kernel for n=%d", who, n); return -1; }
+    return hip_ok(hipGetLastError(), who) ? 0 : -1;
+}
+
+}  // namespace sg
+
+int savgol2d_gradient_batch_f32(int half_win_x, int half_win_y, int poly_order, const float *d_in, int rows, int cols, int in_stride,
+                                size_t in_image_pitch, float *d_grad_x, float *d_grad_y, int out_stride, size_t out_image_pitch,
+                                size_t images, float delta_x, float delta_y, Savgol2DBoundary boundary, void *stream)
+{
+    sg::DerivSpec specs[2];
+    int n = 0;
+    if (d_grad_x) specs[n++] = sg::DerivSpec{1, 0, d_grad_x};
+    if (d_grad_y) specs[n++] = sg::DerivSpec{0, 1, d_grad_y};
+    if (n == 0) return 0;
+    return sg::enqueue_derivatives("savgol2d_gradient_batch_f32", half_win_x, half_win_y, poly_order, d_in, rows, cols, in_stride,
+                                   in_image_pitch, specs, n, false, out_stride, out_image_pitch, images, delta_x, delta_y, (int)boundary,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int savgol2d_hessian_batch_f32(int half_win_x, int half_win_y, int poly_order, const float *d_in, int rows, int cols, int in_stride,
+                               size_t in_image_pitch, float *d_xx, float *d_xy, float *d_yy, int out_stride, size_t out_image_pitch,
+                               size_t images, float delta_x, float delta_y, Savgol2DBoundary boundary, void *stream)
+{
+    if (poly_order < 2) { sg_set_error("savgol2d_hessian_batch_f32: poly_order must be >= 2"); return -1; }
+    sg::DerivSpec specs[3];
+    int n = 0;
+    if (d_xx) specs[n++] = sg::DerivSpec{2, 0, d_xx};
+    if (d_xy) specs[n++] = sg::DerivSpec{1, 1, d_xy};
+    if (d_yy) specs[n++] = sg::DerivSpec{0, 2, d_yy};
+    if (n == 0) return 0;
+    return sg::enqueue_derivatives("savgol2d_hessian_batch_f32", half_win_x, half_win_y, poly_order, d_in, rows, cols, in_stride,
+                                   in_image_pitch, specs, n, false, out_stride, out_image_pitch, images, delta_x, delta_y, (int)boundary,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int savgol2d_laplacian_batch_f32(int half_win_x, int half_win_y, int poly_order, const float *d_in, int rows, int cols, int in_stride,
+                                 size_t in_image_pitch, float *d_out, int out_stride, size_t out_image_pitch, size_t images,
+                                 float delta_x, float delta_y, Savgol2DBoundary boundary, void *stream)
+{
+    if (poly_order < 2) { sg_set_error("savgol2d_laplacian_batch_f32: poly_order must be >= 2"); return -1; }
+    if (!d_out) { sg_set_error("savgol2d_laplacian_batch_f32: NULL pointer"); return -1; }
+    const sg::DerivSpec specs[2] = {sg::DerivSpec{2, 0, d_out}, sg::DerivSpec{0, 2, d_out}};
+    return sg::enqueue_derivatives("savgol2d_laplacian_batch_f32", half_win_x, half_win_y, poly_order, d_in, rows, cols, in_stride,
+                                   in_image_pitch, specs, 2, true, out_stride, out_image_pitch, images, delta_x, delta_y, (int)boundary,
+                                   static_cast<hipStream_t>(stream));
 }
 
 // ---- helper wrappers: one filter per requested output, as the reference (:462-618) ----

@@ -29,10 +29,22 @@ __device__ __forceinline__ int fix_index(int i, int n, int boundary)
     return i;
 }
 
-constexpr int SEP_MAX_TERMS = 4;
+constexpr int SEP_MAX_TERMS = 4;        // per output: rank of a bivariate polynomial of total degree <= 6 is at most 4 (parity in y)
+constexpr int SEP_MAX_OUTPUTS = 3;      // gradient = 2, Hessian = 3 outputs computed from ONE read of the input tile
+
+// what the separable kernel produces from each input tile: `outputs` frames, output o = scale[o] * sum of its terms
+struct SepPlan {
+    int    outputs;
+    int    terms[SEP_MAX_OUTPUTS];      // factors are stored output after output, term after term
+    float  scale[SEP_MAX_OUTPUTS];
+    float *out[SEP_MAX_OUTPUTS];        // same row stride / image pitch for all
+};
 
 // sg_2d_sep.hip
+int sg2d_kernel_double(const Savgol2DConfig *cfg, double *Wd);                           // W in double, [2n+1][2n+1]; 0 on success
+int sg2d_factors_from_kernel(const double *Wd, int n, int order, float *factors, int max_terms);   // #terms, 0 = failed
 int sg2d_separable_factors(const Savgol2DConfig *cfg, float *factors, int max_terms);   // returns #terms, 0 = not separable here
-int sg2d_launch_separable(int n, const Job2D &job, const float *d_factors, int terms, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_separable(int n, const Job2D &job, const SepPlan &plan, const float *d_factors, unsigned images, int cu_count,
+                          hipStream_t st);
 
 }  // namespace sg

@@ -88,7 +88,7 @@ struct Sep {
 };
 
 template <int N>
-__global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, const float *__restrict__ factors, int terms,
+__global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, const SepPlan plan, const float *__restrict__ factors,
                                                              unsigned total_tiles)
 {
     typedef Sep<N> S;
@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
     const unsigned blk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
     const unsigned tiles_per_image = (unsigned)(job.tiles_x * job.tiles_y);
 
-    for (int i = tid; i < terms * 2 * (2 * N + 2); i += 256) wl[i] = factors[i];
+    int all_terms = 0;
+    for (int o = 0; o < plan.outputs; ++o) all_terms += plan.terms[o];
+    for (int i = tid; i < all_terms * 2 * (2 * N + 2); i += 256) wl[i] = factors[i];
 
     // input tile of tile id t: frame rows y0-N .. y0+TH+N-1, columns x0-N .. x0+63+N, remapped at the frame
     // border (reference savgol2d.c:428-445).  Loaded into registers one tile ahead of the arithmetic.
@@ -144,7 +146,6 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
     while (tile < total_tiles) {
         const unsigned img = tile / tiles_per_image, rem = tile - img * tiles_per_image;
         const int by = (int)(rem / (unsigned)job.tiles_x), bx = (int)(rem - (unsigned)by * (unsigned)job.tiles_x);
-        float *out = job.out + (long long)img * job.out_pitch;
         const int x0 = bx * S::TW, y0 = by * S::TH;
 
         __syncthreads();                                // previous tile's passes are done with tin / hbuf
@@ -159,11 +160,13 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
         const unsigned next = tile + nblk;
         if (next < total_tiles) prefetch(next);
 
+        int tbase = 0;
+        for (int o = 0; o < plan.outputs; ++o) {          // every output re-uses the tile that is already in LDS
         f32x2 acc[S::RYP / 2];
 #pragma unroll
         for (int j = 0; j < S::RYP / 2; ++j) acc[j] = f32x2{0.0f, 0.0f};
 
-        for (int t = 0; t < terms; ++t) {
+        for (int t = tbase; t < tbase + plan.terms[o]; ++t) {
             __syncthreads();                            // tin ready / previous term's hbuf consumed
             const float *wt = wl + t * 2 * (2 * N + 2);
             // 2a. row pass: item = (tile row, 16-column segment); lane slides over 16 + 2N inputs
@@ -204,6 +207,7 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
         }
 
         // 3. store
+        float *out = plan.out[o] + (long long)img * job.out_pitch;
         const bool valid = job.boundary == SAVGOL2D_BOUNDARY_VALID;
         const int xlo = valid ? N : 0, xhi = valid ? job.cols - N : job.cols;
         const int ylo = valid ? N : 0, yhi = valid ? job.rows - N : job.rows;
@@ -212,63 +216,68 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
         for (int j = 0; j < S::RY; ++j) {
             const int oy = y0 + crow + j;
             const float v = (j & 1) ? acc[j >> 1].y : acc[j >> 1].x;
-            if (ox >= xlo && ox < xhi && oy >= ylo && oy < yhi) out[(long long)oy * job.out_stride + ox] = v * job.scale;
+            if (ox >= xlo && ox < xhi && oy >= ylo && oy < yhi) out[(long long)oy * job.out_stride + ox] = v * plan.scale[o];
+        }
+        tbase += plan.terms[o];
         }
         tile = next;
     }
 }
 
 template <int N>
-static void launch_sep(const Job2D &job, const float *d_factors, int terms, unsigned images, int cu_count, hipStream_t st)
+static void launch_sep(const Job2D &job, const SepPlan &plan, const float *d_factors, unsigned images, int cu_count, hipStream_t st)
 {
     typedef Sep<N> S;
     Job2D j = job;
     j.tiles_x = (job.cols + S::TW - 1) / S::TW;
     j.tiles_y = (job.rows + S::TH - 1) / S::TH;
-    const size_t lds = sizeof(float) * (S::ROWS * S::PIN + S::ROWS * S::PH + SEP_MAX_TERMS * 2 * (2 * N + 2));
+    const size_t lds = sizeof(float) * (S::ROWS * S::PIN + S::ROWS * S::PH + SEP_MAX_OUTPUTS * SEP_MAX_TERMS * 2 * (2 * N + 2));
     const unsigned long long total = (unsigned long long)images * j.tiles_x * j.tiles_y;      // caller keeps this < 2^32
     const unsigned per_cu = (unsigned)(160 * 1024 / lds) < 4u ? (unsigned)(160 * 1024 / lds) : 4u;
     unsigned grid = (unsigned)cu_count * (per_cu ? per_cu : 1u);
     if (grid > total) grid = (unsigned)total;
     grid = (grid + 7u) & ~7u;
-    hipLaunchKernelGGL((sg2d_separable_kernel<N>), dim3(grid), dim3(256), lds, st, j, d_factors, terms, (unsigned)total);
+    hipLaunchKernelGGL((sg2d_separable_kernel<N>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total);
 }
 
 template <int N>
-static int dispatch_sep(int n, const Job2D &job, const float *d_factors, int terms, unsigned images, int cu_count, hipStream_t st)
+static int dispatch_sep(int n, const Job2D &job, const SepPlan &plan, const float *d_factors, unsigned images, int cu_count, hipStream_t st)
 {
-    if (n == N) { launch_sep<N>(job, d_factors, terms, images, cu_count, st); return 1; }
-    if constexpr (N < SAVGOL2D_MAX_HALF_WINDOW) return dispatch_sep<N + 1>(n, job, d_factors, terms, images, cu_count, st);
+    if (n == N) { launch_sep<N>(job, plan, d_factors, images, cu_count, st); return 1; }
+    if constexpr (N < SAVGOL2D_MAX_HALF_WINDOW) return dispatch_sep<N + 1>(n, job, plan, d_factors, images, cu_count, st);
     else return 0;
 }
 
-int sg2d_launch_separable(int n, const Job2D &job, const float *d_factors, int terms, unsigned images, int cu_count, hipStream_t st)
+int sg2d_launch_separable(int n, const Job2D &job, const SepPlan &plan, const float *d_factors, unsigned images, int cu_count,
+                          hipStream_t st)
 {
-    return dispatch_sep<1>(n, job, d_factors, terms, images, cu_count, st) ? 0 : -1;
+    return dispatch_sep<1>(n, job, plan, d_factors, images, cu_count, st) ? 0 : -1;
 }
 
 // ---- host: exact low-rank factors of the least-squares kernel, in double ----
 // factors layout per term: Q_t[0..2N] then a pad, G_t[0..2N] then a pad  (2 * (2N+2) floats)
-int sg2d_separable_factors(const Savgol2DConfig *cfg, float *factors, int max_terms)
+int sg2d_kernel_double(const Savgol2DConfig *cfg, double *Wd)
 {
-    const int nx = cfg->half_window_x, ny = cfg->half_window_y, order = cfg->poly_order;
-    if (nx != ny) return 0;
-    const int n = nx, ws = 2 * n + 1, nt = savgol2d_num_terms(order);
+    const int n = cfg->half_window_x, order = cfg->poly_order, ws = 2 * n + 1;
     float wf[SAVGOL2D_MAX_WINDOW_AREA];
     double coef[SAVGOL2D_MAX_TERMS];
-    if (sg2d_weights_fill(cfg, wf, coef) != 0) return 0;
-    (void)nt;
+    if (cfg->half_window_x != cfg->half_window_y || sg2d_weights_fill(cfg, wf, coef) != 0) return -1;
     // W in double from the polynomial coefficients (already scaled by dx! dy!)
-    static thread_local double Wd[33 * 33];
-    double wmax = 0.0;
     for (int y = -n; y <= n; ++y)
         for (int x = -n; x <= n; ++x) {
             double s = 0.0;
             for (int px = 0; px <= order; ++px)
                 for (int py = 0; px + py <= order; ++py) s += coef[sg2d_term(px, py)] * std::pow((double)x, px) * std::pow((double)y, py);
             Wd[(y + n) * ws + (x + n)] = s;
-            if (std::fabs(s) > wmax) wmax = std::fabs(s);
         }
+    return 0;
+}
+
+int sg2d_factors_from_kernel(const double *Wd, int n, int order, float *factors, int max_terms)
+{
+    const int ws = 2 * n + 1;
+    double wmax = 0.0;
+    for (int i = 0; i < ws * ws; ++i) if (std::fabs(Wd[i]) > wmax) wmax = std::fabs(Wd[i]);
     // orthonormal polynomials in y on the window (modified Gram-Schmidt on 1, y, y^2, ...)
     const int nb = (order + 1 < ws) ? order + 1 : ws;
     double G[7][33];
@@ -304,6 +313,13 @@ int sg2d_separable_factors(const Savgol2DConfig *cfg, float *factors, int max_te
         ++terms;
     }
     return terms;
+}
+
+int sg2d_separable_factors(const Savgol2DConfig *cfg, float *factors, int max_terms)
+{
+    static thread_local double Wd[33 * 33];
+    if (sg2d_kernel_double(cfg, Wd) != 0) return 0;
+    return sg2d_factors_from_kernel(Wd, cfg->half_window_x, cfg->poly_order, factors, max_terms);
 }
 
 }  // namespace sg

@@ -193,3 +193,57 @@ def test_row_bands_on_gpu_equal_whole_frame(sg, torch_gpu):
                 parts.append(band.apply(ext, apply_fn))
             got = torch.cat(parts, dim=1)
             assert torch.equal(got, whole), (b, method, (got - whole).abs().max().item())
+
+
+def test_fused_gradient_hessian_laplacian_batch(sg, sgo, torch_gpu):
+    """Device entry points that produce all requested derivative frames from one read of the input
+    (SURVEY 8f-1).  Gradient / Hessian frames must equal the single-filter separable outputs bit for bit (same
+    factors, same order of operations); the Laplacian (one summed kernel) is checked against the double oracle."""
+    torch = torch_gpu
+    rng = np.random.default_rng(12)
+    images, rows, cols, stride = 2, 90, 140, 144
+    x = np.zeros((images, rows, stride), np.float32)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    for k in range(images):
+        x[k, :, :cols] = (np.sin(0.09 * xx + k) * np.cos(0.05 * yy) + rng.normal(0, 0.05, (rows, cols))).astype(np.float32)
+    d = torch.from_numpy(x).cuda()
+    L = sg.lib()
+    n, order, ddx, ddy = 7, 3, 0.5, 0.25
+    pitch = rows * stride
+    for b in (1, 2, 0):
+        outs = {k: torch.full_like(d, -3.0) for k in ("gx", "gy", "xx", "xy", "yy", "lap")}
+        assert L.savgol2d_gradient_batch_f32(n, n, order, d.data_ptr(), rows, cols, stride, pitch, outs["gx"].data_ptr(),
+                                             outs["gy"].data_ptr(), stride, pitch, images, ddx, ddy, b, None) == 0, sg.last_error()
+        assert L.savgol2d_hessian_batch_f32(n, n, order, d.data_ptr(), rows, cols, stride, pitch, outs["xx"].data_ptr(),
+                                            outs["xy"].data_ptr(), outs["yy"].data_ptr(), stride, pitch, images, ddx, ddy, b, None) == 0
+        assert L.savgol2d_laplacian_batch_f32(n, n, order, d.data_ptr(), rows, cols, stride, pitch, outs["lap"].data_ptr(),
+                                              stride, pitch, images, ddx, ddy, b, None) == 0
+        torch.cuda.synchronize()
+        single = {}
+        for name, (dx, dy) in (("gx", (1, 0)), ("gy", (0, 1)), ("xx", (2, 0)), ("xy", (1, 1)), ("yy", (0, 2))):
+            f = sg.Filter2D(n, n, order, dx, dy, ddx, ddy)
+            o = torch.full_like(d, -3.0)
+            f.apply_batch(d, o, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=2)
+            single[name] = o
+            assert torch.equal(outs[name], o), (b, name)
+        sel = np.zeros((rows, stride), bool)
+        if b == 0:
+            sel[n:rows - n, n:cols - n] = True
+        else:
+            sel[:, :cols] = True
+        oxx = sgo.Filter2D(n, n, order, 2, 0, ddx, ddy); oyy = sgo.Filter2D(n, n, order, 0, 2, ddx, ddy)
+        lap = outs["lap"].cpu().numpy()
+        for k in range(images):
+            want = oxx.apply_f64acc(x[k], cols, b) + oyy.apply_f64acc(x[k], cols, b)
+            assert np.all(lap[k][~sel] == -3.0)
+            assert normwise(lap[k][sel], want[sel]) < TOL_SEP_DERIV, (b, normwise(lap[k][sel], want[sel]))
+    # NULL outputs are skipped; poly_order < 2 is refused for second derivatives (reference :507-510, :566-569)
+    g = torch.full_like(d, -3.0)
+    assert L.savgol2d_gradient_batch_f32(n, n, order, d.data_ptr(), rows, cols, stride, pitch, None, g.data_ptr(), stride, pitch, images, ddx, ddy, 1, None) == 0
+    assert L.savgol2d_hessian_batch_f32(3, 3, 1, d.data_ptr(), rows, cols, stride, pitch, g.data_ptr(), None, None, stride, pitch, images, 1.0, 1.0, 1, None) == -1
+    # rectangular window: dense fallback, Laplacian = xx + yy as the reference computes it (bit-identical)
+    lap = torch.full_like(d, -3.0)
+    assert L.savgol2d_laplacian_batch_f32(4, 6, 3, d.data_ptr(), rows, cols, stride, pitch, lap.data_ptr(), stride, pitch, images, 1.0, 1.0, 1, None) == 0, sg.last_error()
+    torch.cuda.synchronize()
+    a = sgo.Filter2D(4, 6, 3, 2, 0).apply(x[0], cols, 1); c = sgo.Filter2D(4, 6, 3, 0, 2).apply(x[0], cols, 1)
+    assert np.array_equal(lap[0].cpu().numpy()[:, :cols], (a + c)[:, :cols])

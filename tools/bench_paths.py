@@ -31,33 +31,23 @@ def cpu_reference(kind):
         from tests.golden import make_golden as mg
         L = mg.load()
     if kind == "stream":
+        exe = os.path.join(os.path.dirname(ref), "cpu_stream_bench")
+        if os.path.exists(exe):
+            import subprocess
+            n_push = 20_000_000
+            v = float(subprocess.run([exe, "16", "2", "1", "0.001", str(n_push)], capture_output=True, text=True, check=True).stdout)
+            return {"kind": "reference", "cores": 1, "unit": "Msamples/s", "value": v,
+                    "sample": f"the reference's savgol_stream_push in a C loop, 1 stream, {n_push} samples, best of 5 (oracle/cpu_stream_bench.c)"}
         n_push = 2_000_000
         x = sgo.synth_f32(0, 1, n_push)[0]
-        if have_ref:
-            cfg = mg.Cfg(16, 2, 1, 1e-3, 0)
-            st = L.savgol_stream_create(C.byref(cfg))
-            ok = C.c_bool(False)
-            push = L.savgol_stream_push
-            xs = [float(v) for v in x[:200000]]
-            t0 = time.perf_counter()
-            for v in xs:
-                push(st, v, C.byref(ok))
-            el = time.perf_counter() - t0
-            # the Python call overhead dominates a 50 ns push: time the C loop through the batch-equivalent instead
-            f = L.savgol_create(C.byref(cfg))
-            y = np.empty_like(x)
-            t0 = time.perf_counter(); reps = 0
-            while time.perf_counter() - t0 < 5.0:
-                L.savgol_apply(f, mg.fptr(x), mg.fptr(y), n_push); reps += 1
-            el_b = time.perf_counter() - t0
-            return {"kind": "reference", "cores": 1, "unit": "Msamples/s",
-                    "value": round(reps * n_push / el_b / 1e6, 2),
-                    "sample": f"savgol_apply (same 33-tap dot product per sample, C loop) on {n_push} samples x {reps} reps; "
-                              f"savgol_stream_push through ctypes: {len(xs) / el / 1e6:.2f} Msamples/s (call overhead bound); "
-                              "BASELINE.md survey figure for the C push loop: 18.8 Msamples/s"}
         f = sgo.Filter(16, 2, 1, 1e-3)
-        t0 = time.perf_counter(); f.apply(x); el = time.perf_counter() - t0
-        return {"kind": "port", "cores": 1, "unit": "Msamples/s", "value": round(n_push / el / 1e6, 2), "sample": "oracle batch apply"}
+        o = sgo.Stream(f)
+        t0 = time.perf_counter()
+        for v in x[:200000]:
+            o.push(v)
+        el = time.perf_counter() - t0
+        return {"kind": "port", "cores": 1, "unit": "Msamples/s", "value": round(200000 / el / 1e6, 3),
+                "sample": "oracle push loop through ctypes (call-overhead bound)"}
     size = 1024
     img = sgo.synth_f32(0, size, size)
     out = np.zeros_like(img)
