@@ -4,6 +4,7 @@
 with the HBM-roofline fraction of the dominant kernel and the reference's CPU path timed beside it.
 
     python bench.py [--gpus N --steps K --warmup W]
+    python bench.py --workload stream | image        (secondary: BASELINE configs 3 / 4 on one GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of savgol_apply_batch_f32 over the whole resident batch in EACH of the four boundary
@@ -59,6 +60,132 @@ def cpu_baseline(length, budget_s=12.0):
                       f"savgol_apply back to back for {el:.1f} s, 1 thread"}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# secondary workloads (python bench.py --workload stream | image): BASELINE configs 3 and 4, single GPU
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_reference(kind):
+    """The reference's own code (oracle/_ref/libsavgol_ref.so, gcc -O2, 1 thread) on a bounded sample of the same
+    workload, timed on this host; falls back to the oracle port if the compiled reference did not travel."""
+    import ctypes as C
+    from oracle import sgo
+    ref = os.path.join(ROOT, "oracle", "_ref", "libsavgol_ref.so")
+    have_ref = os.path.exists(ref)
+    if have_ref:
+        from tests.golden import make_golden as mg
+        L = mg.load()
+    if kind == "stream":
+        exe = os.path.join(os.path.dirname(ref), "cpu_stream_bench")
+        if os.path.exists(exe):
+            import subprocess
+            n_push = 20_000_000
+            v = float(subprocess.run([exe, "16", "2", "1", "0.001", str(n_push)], capture_output=True, text=True, check=True).stdout)
+            return {"kind": "reference", "cores": 1, "unit": "Msamples/s", "value": v,
+                    "sample": f"the reference's savgol_stream_push in a C loop, 1 stream, {n_push} samples, best of 5 (oracle/cpu_stream_bench.c)"}
+        n_push = 2_000_000
+        x = sgo.synth_f32(0, 1, n_push)[0]
+        f = sgo.Filter(16, 2, 1, 1e-3)
+        o = sgo.Stream(f)
+        t0 = time.perf_counter()
+        for v in x[:200000]:
+            o.push(v)
+        el = time.perf_counter() - t0
+        return {"kind": "port", "cores": 1, "unit": "Msamples/s", "value": round(200000 / el / 1e6, 3),
+                "sample": "oracle push loop through ctypes (call-overhead bound)"}
+    size = 1024
+    img = sgo.synth_f32(0, size, size)
+    out = np.zeros_like(img)
+    res = {}
+    for name, b in (("VALID", 0), ("CONSTANT", 1), ("REFLECT", 2)):
+        if have_ref:
+            cfg = mg.Cfg2(7, 7, 3, 0, 0, 1.0, 1.0)
+            f = L.savgol2d_create(C.byref(cfg))
+            t0 = time.perf_counter()
+            L.savgol2d_apply(f, mg.fptr(img), size, size, size, mg.fptr(out), size, b)
+            el = time.perf_counter() - t0
+        else:
+            f = sgo.Filter2D(7, 7, 3)
+            t0 = time.perf_counter(); f.apply(img, size, b); el = time.perf_counter() - t0
+        res[name] = round(size * size / el / 1e6, 2)
+    return {"kind": "reference" if have_ref else "port", "cores": 1, "unit": "Mpix/s", "value": res,
+            "sample": f"savgol2d_apply on one {size}x{size} fp32 frame, n=7, order 3, per boundary mode"}
+
+
+def ev():
+    return torch.cuda.Event(enable_timing=True)
+
+
+def bench_stream(sg, a):
+    S, T, n = a.streams, a.ticks, 16
+    x = torch.empty((T, S), dtype=torch.float32, device="cuda")
+    sg.synth(x)
+    out = torch.empty((T, S), dtype=torch.float32, device="cuda")
+    bank = sg.StreamBank(S, n, 2, 1, 1e-3)
+    # (a) per-tick launches: wall latency per tick measured on the host around launch + sync
+    o1 = torch.empty(S, dtype=torch.float32, device="cuda")
+    for t in range(64):
+        bank.push(x[t], o1)
+    torch.cuda.synchronize()
+    lat = []
+    for t in range(64, 64 + 2000):
+        t0 = time.perf_counter()
+        bank.push(x[t % T], o1)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e6)
+    lat = np.sort(np.array(lat))
+    # (b) back-to-back ticks without host sync (device time per tick)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for t in range(1000):
+        bank.push(x[t % T], o1)
+    e1.record(); torch.cuda.synchronize()
+    tick_us = e0.elapsed_time(e1)
+    # (c) block push: T ticks in one launch, ring in LDS
+    bank2 = sg.StreamBank(S, n, 2, 1, 1e-3)
+    bank2.push_block(x, T, out); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = ev(), ev()
+        e0.record(); bank2.push_block(x, T, out); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = float(np.median(ts))
+    samples = S * T
+    print(json.dumps({
+        "workload": f"BASELINE config 3: {S} streams, n=16, m=2, d=1, dt=1e-3",
+        "per_tick_launch": {"wall_latency_us_p50": round(float(lat[len(lat) // 2]), 2), "wall_latency_us_p99": round(float(lat[int(len(lat) * 0.99)]), 2),
+                            "device_us_per_tick_back_to_back": round(tick_us, 3), "ns_per_sample": round(tick_us * 1e3 / S, 4),
+                            "Msamples_per_s": round(S / tick_us, 1)},
+        "block_push": {"ticks_per_launch": T, "ms": round(ms, 3), "ns_per_sample": round(ms * 1e6 / samples, 5),
+                       "Msamples_per_s": round(samples / ms / 1e3, 1),
+                       "roofline": {"bound": "hbm", "achieved": round(8.0 * samples / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(8.0 * samples / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sample": 8}},
+        **({} if a.no_cpu else {"cpu_baseline": cpu_reference("stream")}),
+    }))
+
+
+def bench_image(sg, a):
+    N, size, n = a.images, a.size, 7
+    x = torch.empty((N * size, size), dtype=torch.float32, device="cuda")
+    sg.synth(x)
+    y = torch.empty_like(x)
+    f = sg.Filter2D(n, n, 3)
+    res = {}
+    for name, b in (("VALID", 0), ("CONSTANT", 1), ("REFLECT", 2)):
+        f.apply_batch(x, y, size, size, N, boundary=b, method=a.method); torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            e0, e1 = ev(), ev()
+            e0.record(); f.apply_batch(x, y, size, size, N, boundary=b, method=a.method); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ms = float(np.median(ts))
+        pix = N * size * size
+        res[name] = {"ms": round(ms, 3), "Mpix_per_s": round(pix / ms / 1e3, 1),
+                     "roofline": {"bound": "hbm", "achieved": round(8.0 * pix / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(8.0 * pix / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_pixel": 8}}
+    print(json.dumps({"workload": f"BASELINE config 4 (subset): {N} images x {size}x{size} fp32, n=7, order 3, method {a.method}", "modes": res,
+                      **({} if a.no_cpu else {"cpu_baseline": cpu_reference("image")})}))
+
+
+
 def pmc_traffic(ch, length):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of the same command
     (FETCH_SIZE x2 for gfx950 + WRITE_SIZE, separate passes; see profiles/*_pmc_summary.json).  bench.py cannot
@@ -83,7 +210,19 @@ def main():
     ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
     ap.add_argument("--length", type=int, default=1 << 20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--workload", choices=["batch1d", "stream", "image"], default="batch1d",
+                    help="batch1d = the headline (BASELINE config 2); stream / image = configs 3 / 4, single GPU, extra JSON")
+    ap.add_argument("--streams", type=int, default=65536)
+    ap.add_argument("--ticks", type=int, default=4096)
+    ap.add_argument("--images", type=int, default=64)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--method", type=int, default=2, help="2-D: 1 = dense (bit-exact), 2 = separable")
     args = ap.parse_args()
+    args.no_cpu = args.no_cpu
+    if args.workload != "batch1d":
+        sg = load_package()
+        (bench_stream if args.workload == "stream" else bench_image)(sg, args)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -137,16 +276,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    # parity spot check of what was just timed (last mode run = CONSTANT), against the CPU oracle
-    checked = None
-    if rank == 0:
-        from oracle import sgo
-        sample = [0, ch // 2, ch - 1]
-        got = y[sample].cpu().numpy()
-        ref = sgo.Filter(N, M, D, 1.0, 3).apply_f64(x[sample].cpu().numpy().astype(np.float64))
-        checked = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
-        assert checked < 1e-6, f"parity lost: normwise error {checked}"
-
     if rank == 0:
         launches_ms = [a.elapsed_time(b) for a, b in events]
         avg_ms = float(np.mean(launches_ms))
@@ -175,10 +304,17 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(ch, length),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
                          "launches_timed": len(launches_ms)},
-            "parity_normwise_vs_fp64_oracle": checked,
         }
         if world == 1 and not args.no_cpu:
+            # CPU leg (rank 0, N=1 only): the reference timed on this host + a parity spot check of what was just
+            # timed (last mode run = CONSTANT) against the CPU oracle -- the only place bench.py touches oracle/
             out["cpu_baseline"] = cpu_baseline(length)
+            from oracle import sgo
+            sample = [0, ch // 2, ch - 1]
+            ref = sgo.Filter(N, M, D, 1.0, 3).apply_f64(x[sample].cpu().numpy().astype(np.float64))
+            checked = float(np.max(np.abs(y[sample].cpu().numpy() - ref)) / np.max(np.abs(ref)))
+            assert checked < 1e-6, f"parity lost: normwise error {checked}"
+            out["parity_normwise_vs_fp64_oracle"] = checked
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

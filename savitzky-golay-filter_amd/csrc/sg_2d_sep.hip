@@ -87,7 +87,8 @@ struct Sep {
     static constexpr int PH = 64 + 4;                       // intermediate pitch: 68 -> conflict-free column reads
 };
 
-template <int N>
+// NOUT = number of output frames (compile time: the single-output kernel must not pay for the multi-output loop)
+template <int N, int NOUT>
 __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, const SepPlan plan, const float *__restrict__ factors,
                                                              unsigned total_tiles)
 {
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
     const unsigned tiles_per_image = (unsigned)(job.tiles_x * job.tiles_y);
 
     int all_terms = 0;
-    for (int o = 0; o < plan.outputs; ++o) all_terms += plan.terms[o];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) all_terms += plan.terms[o];
     for (int i = tid; i < all_terms * 2 * (2 * N + 2); i += 256) wl[i] = factors[i];
 
     // input tile of tile id t: frame rows y0-N .. y0+TH+N-1, columns x0-N .. x0+63+N, remapped at the frame
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
         if (next < total_tiles) prefetch(next);
 
         int tbase = 0;
-        for (int o = 0; o < plan.outputs; ++o) {          // every output re-uses the tile that is already in LDS
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {                  // every output re-uses the tile that is already in LDS
         f32x2 acc[S::RYP / 2];
 #pragma unroll
         for (int j = 0; j < S::RYP / 2; ++j) acc[j] = f32x2{0.0f, 0.0f};
@@ -237,7 +240,9 @@ static void launch_sep(const Job2D &job, const SepPlan &plan, const float *d_fac
     unsigned grid = (unsigned)cu_count * (per_cu ? per_cu : 1u);
     if (grid > total) grid = (unsigned)total;
     grid = (grid + 7u) & ~7u;
-    hipLaunchKernelGGL((sg2d_separable_kernel<N>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total);
+    if (plan.outputs == 1)      hipLaunchKernelGGL((sg2d_separable_kernel<N, 1>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total);
+    else if (plan.outputs == 2) hipLaunchKernelGGL((sg2d_separable_kernel<N, 2>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total);
+    else                        hipLaunchKernelGGL((sg2d_separable_kernel<N, 3>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total);
 }
 
 template <int N>
