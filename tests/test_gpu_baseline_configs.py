@@ -1,0 +1,124 @@
+"""BASELINE.json's configurations as parity cases at (or near) their full sizes.
+
+config 1: 1 ch x 1e6 fp32, n=5, m=3, d=0, POLYNOMIAL (the reference's own CPU-runnable case) -- host API, whole signal
+config 2: covered by test_gpu_1d.py::test_full_size_config2_properties
+config 3: covered by test_gpu_stream.py::test_stream_bank_config3_shape
+config 4: 4096 x 4096 fp32 frames, n=7, order 3 -- crops of full-size frames vs the oracle, all modes, both kernels
+config 5: fp64, n=32, d=2, 2^22-sample channels -- sampled channels vs the fp64 oracle + linearity at scale
+Size-independent properties (linearity, constant/ramp preservation) cover what the oracle cannot recompute in seconds."""
+import numpy as np
+import pytest
+
+from tests._util import normwise
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_gpu(sg):
+    import torch
+    assert torch.cuda.is_available() and sg.device_count() > 0, sg.last_error()
+    return torch
+
+
+def test_config1_reference_cpu_case_through_host_api(sg, sgo, torch_gpu):
+    x = sgo.synth_f32(0, 1, 1_000_000)[0]
+    y = sg.Filter(5, 3, 0, 1.0, 0).apply(x)
+    ref32 = sgo.Filter(5, 3).apply(x)                          # the reference's own fp32 result (bit-exact restatement)
+    hi = sgo.Filter(5, 3).apply_f64(x.astype(np.float64))
+    assert normwise(y, hi) < 1e-6 and normwise(y, ref32) < 2e-6
+    v = sg.Filter(5, 3).apply_valid(x)
+    assert v.size == 1_000_000 - 10 and normwise(v, hi[5:-5]) < 1e-6
+
+
+def test_config4_full_size_frames(sg, sgo, torch_gpu):
+    torch = torch_gpu
+    size, images, n = 4096, 4, 7
+    x = torch.empty((images * size, size), dtype=torch.float32, device="cuda")
+    sg.synth(x)
+    x = x.view(images, size, size)
+    f = sg.Filter2D(n, n, 3)
+    o = sgo.Filter2D(n, n, 3)
+    rng = np.random.default_rng(3)
+    crops = [(0, 0), (0, size - 200), (size - 200, 0), (size - 200, size - 200)] + [tuple(rng.integers(100, size - 300, 2)) for _ in range(3)]
+    for b in range(3):
+        outs = {}
+        for method in (1, 2):
+            out = torch.full_like(x, -2.0)
+            f.apply_batch(x, out, size, size, images, boundary=b, method=method)
+            outs[method] = out
+        torch.cuda.synchronize()
+        for k in (0, images - 1):
+            xh = x[k].cpu().numpy()
+            for (r0, c0) in crops:
+                r0, c0 = int(r0), int(c0)
+                # oracle on the crop + its halo: interior of the crop does not depend on how the crop's own edge is padded,
+                # except where the crop touches the frame edge -- there the padded mode itself is what is compared
+                ra, rb = max(r0 - n, 0), min(r0 + 200 + n, size)
+                ca, cb = max(c0 - n, 0), min(c0 + 200 + n, size)
+                sub = np.ascontiguousarray(xh[ra:rb, ca:cb])
+                mode = b if b != 0 else 1
+                want32 = o.apply(sub, sub.shape[1], mode)
+                want64 = o.apply_f64acc(sub, sub.shape[1], mode)
+                # rows/cols of the sub-result that are exact for the full frame: everything not within n of an ARTIFICIAL edge
+                t = 0 if ra == 0 else n; l = 0 if ca == 0 else n
+                bt = sub.shape[0] - (0 if rb == size else n); rt = sub.shape[1] - (0 if cb == size else n)
+                if b == 0:                       # VALID: frame border rows are not produced at all
+                    t = max(t, n - ra) if ra < n else t; l = max(l, n - ca) if ca < n else l
+                    bt = min(bt, size - n - ra); rt = min(rt, size - n - ca)
+                g1 = outs[1][k, ra + t:ra + bt, ca + l:ca + rt].cpu().numpy()
+                g2 = outs[2][k, ra + t:ra + bt, ca + l:ca + rt].cpu().numpy()
+                assert np.array_equal(g1, want32[t:bt, l:rt]), (b, k, r0, c0)                    # dense kernel: bit-exact
+                assert normwise(g2, want64[t:bt, l:rt]) < 1e-6, (b, k, r0, c0)                   # separable: fp32 rounding
+        if b == 0:
+            assert torch.all(outs[1][:, :n] == -2.0) and torch.all(outs[2][:, :, -n:] == -2.0)   # VALID leaves the border alone
+    # a constant frame stays constant (weights sum to 1) under both padded modes
+    c = torch.full((1, size, size), 3.25, dtype=torch.float32, device="cuda")
+    out = torch.empty_like(c)
+    for b in (1, 2):
+        f.apply_batch(c, out, size, size, 1, boundary=b, method=2)
+        assert (out - 3.25).abs().max().item() < 1e-5
+
+
+def test_config5_fp64_second_derivative_long_channels(sg, sgo, torch_gpu):
+    torch = torch_gpu
+    ch, length = 192, 1 << 22                                   # per-GPU slice of config 5 is 4096 such channels
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3 * ch * length * 8 + (2 << 30):
+        pytest.skip("not enough HBM free")
+    x = torch.empty((ch, length), dtype=torch.float64, device="cuda")
+    sg.synth(x, channel0=1000)
+    f = sg.Filter(32, 4, 2, 1.0, 0)
+    y = f.apply_tensor(x)
+    sample = [0, 1, 95, 191]
+    ref = sgo.Filter(32, 4, 2, 1.0, 0).apply_f64(x[sample].cpu().numpy())
+    assert normwise(y[sample].cpu().numpy(), ref) < 1e-12
+    # linearity at scale: F(a x + b t) = a F(x) + b F(t), t a ramp (the fp32 tables do not annihilate a ramp exactly,
+    # so F(t) is taken from the kernel too)
+    t = torch.arange(length, dtype=torch.float64, device="cuda").expand(ch, length).contiguous()
+    ft = f.apply_tensor(t)
+    z = f.apply_tensor(2.5 * x + 1e-3 * t)
+    d = (z - (2.5 * y + 1e-3 * ft)).abs().max().item()
+    assert d < 1e-10 * max(1.0, z.abs().max().item()), d
+
+
+def test_batch_call_is_graph_capturable(sg, sgo, torch_gpu):
+    """savgol_hip.h promises that the batch calls only enqueue (after a warm-up that uploads the tables)."""
+    torch = torch_gpu
+    x = torch.empty((64, 20000), dtype=torch.float32, device="cuda")
+    sg.synth(x)
+    y = torch.zeros_like(x)
+    f = sg.Filter(32, 4, 0, 1.0, 0)
+    f.apply_batch(x, y, 64, 20000)                             # warm-up: uploads the edge table
+    torch.cuda.synchronize()
+    want = y.clone()
+    y.zero_()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            f.apply_batch(x, y, 64, 20000, stream=s)
+    y.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
