@@ -34,6 +34,13 @@ int         savgol_hip_get_device(void);
 int         savgol_hip_synchronize(void *stream);
 const char *savgol_hip_last_error(void);            /* thread-local, never NULL            */
 const char *savgol_hip_version(void);
+/* Process-wide switches; defaults reproduce the reference bit for bit in behaviour, quirks included.
+ * SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1: in POLYNOMIAL mode the first n outputs of an ODD derivative get the
+ * mathematically correct sign.  (The reference applies the trailing-edge rows to reversed data, which negates odd
+ * derivatives on the leading edge -- src/savgolFilter.c:773-777)  Affects the 1-D batch / apply
+ * entry points only; the streaming path keeps the reference behaviour.                                           */
+enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1 };
+int         savgol_hip_set_option(int option, int value);
 
 /* ---------------------------------------------------------------- 1-D batch ----------- *
  * channels independent signals, row-major: sample i of channel c at base[c*ld + i].

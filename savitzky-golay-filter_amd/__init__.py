@@ -23,6 +23,7 @@ SAVGOL_MAX_POLY_ORDER = 10
 SAVGOL_MAX_DERIVATIVE = 4
 SAVGOL_BOUNDARY_POLYNOMIAL, SAVGOL_BOUNDARY_REFLECT, SAVGOL_BOUNDARY_PERIODIC, SAVGOL_BOUNDARY_CONSTANT = 0, 1, 2, 3
 SAVGOL2D_BOUNDARY_VALID, SAVGOL2D_BOUNDARY_CONSTANT, SAVGOL2D_BOUNDARY_REFLECT = 0, 1, 2
+SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1
 
 
 class SavgolConfig(C.Structure):
@@ -94,6 +95,7 @@ SIGNATURES = {
     "savgol_hip_synchronize": (C.c_int, [_vp]),
     "savgol_hip_last_error": (C.c_char_p, []),
     "savgol_hip_version": (C.c_char_p, []),
+    "savgol_hip_set_option": (C.c_int, [C.c_int, C.c_int]),
     # savgol_hip.h: 1-D batch
     "savgol_apply_batch_f32": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "savgol_apply_batch_f64": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),

@@ -1,6 +1,7 @@
 // sg_api_1d.cpp -- host side of the 1-D path: the five drop-in entry points of savgolFilter.h and
 // the device-pointer batch entry points of savgol_hip.h.  All arithmetic on samples happens in the
 // HIP kernels (sg_k1d.hpp); this file validates, picks tile geometry and enqueues.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,6 +60,8 @@ extern "C" void savgol_destroy(SavgolFilter *filter) { free(filter); }
 // enqueue one batch
 // ------------------------------------------------------------------------------------------------
 namespace {
+
+std::atomic<int> g_correct_leading_edge{0};
 
 enum Variant { FULL = 0, VALID = 1, FULL_POLY_EDGES = 2 /* strided: polynomial edges whatever the mode */ };
 
@@ -148,8 +151,10 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         if (sg::launch_center<T>(n, job, taps, blocks, st) != 0) return -1;
     }
     if (d_edges) {
+        // bit 0: multiply by dt_inv; bit 1: negate the leading-edge outputs (SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE, odd d only)
+        const int eflags = (job.dt_inv != 1.0f ? 1 : 0) | ((g_correct_leading_edge.load() && (f->config.derivative & 1)) ? 2 : 0);
         const int rc = sg::launch_edges<T>(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_edges,
-                                           job.dt_inv, job.dt_inv != 1.0f, channels, st);
+                                           job.dt_inv, eflags, channels, st);
         if (rc != 0) { sg_set_error("%s: edge kernel launch failed", who); return -1; }
     }
     return 0;
@@ -158,6 +163,13 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
 }  // namespace
 
 extern "C" {
+
+int savgol_hip_set_option(int option, int value)
+{
+    if (option == SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE) { g_correct_leading_edge.store(value != 0); return 0; }
+    sg_set_error("savgol_hip_set_option: unknown option %d", option);
+    return -1;
+}
 
 int savgol_apply_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out, size_t channels, size_t length,
                            size_t in_ld, size_t out_ld, void *stream)

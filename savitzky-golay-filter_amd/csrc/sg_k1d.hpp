@@ -485,7 +485,7 @@ template <typename T>
 __global__ __launch_bounds__(64) void sg1d_edges_kernel(const T *__restrict__ in, T *__restrict__ out,
                                                         long long in_ld, long long out_ld, long long L,
                                                         int n, const float *__restrict__ ew,
-                                                        float dt_inv, int apply_scale)
+                                                        float dt_inv, int flags)
 {
     const int lane = threadIdx.x;
     const long long c = blockIdx.x;
@@ -505,7 +505,8 @@ __global__ __launch_bounds__(64) void sg1d_edges_kernel(const T *__restrict__ in
         if (k0 < ws) p = (T)w[k0] * x0;
         if (k1 < ws) p = fma_t((T)w[k1], x1, p);
         p = wave_sum(p);
-        if (apply_scale) p *= (T)dt_inv;
+        if (flags & 1) p *= (T)dt_inv;
+        if ((flags & 2) && !trailing) p = -p;           // opt-in sign fix of the reference's reversed leading edge (odd derivatives)
         if (lane == 0) orow[trailing ? (L - 1 - e) : (long long)e] = p;
     }
 }

@@ -238,3 +238,23 @@ def test_full_size_config2_properties(sg, sgo, torch_gpu):
     s2 = z.double().sum(dim=1)
     rel = ((s2 - (2.0 * s1 + length)).abs().max() / s2.abs().max()).item()
     assert rel < 1e-6, rel
+
+
+def test_opt_in_corrected_leading_edge_sign(sg, sgo, torch_gpu):
+    """SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE: odd derivatives get the right sign on the first n samples; everything else,
+    and the default behaviour (the reference's quirk), is unchanged."""
+    x = (3.0 * np.arange(60) + 7.0).astype(np.float32)
+    L = sg.lib()
+    try:
+        base = sg.Filter(5, 2, 1).apply(x)
+        assert np.allclose(base[:5], -3.0, atol=1e-3)                       # reference behaviour
+        assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE, 1) == 0
+        fixed = sg.Filter(5, 2, 1).apply(x)
+        assert np.allclose(fixed, 3.0, atol=1e-3)
+        assert np.array_equal(fixed[5:], base[5:]) and np.array_equal(fixed[:5], -base[:5])
+        even = sg.Filter(5, 2, 2).apply(x)                                   # even derivative: nothing to fix
+        L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE, 0)
+        assert np.array_equal(even, sg.Filter(5, 2, 2).apply(x))
+        assert L.savgol_hip_set_option(99, 1) == -1
+    finally:
+        L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE, 0)
