@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 N, M, D = 32, 4, 0
 
 
-def cpu_baseline(length, budget_s=12.0):
+def cpu_baseline(length, deriv=D, budget_s=12.0):
     """The reference's own savgol_apply (oracle/_ref, gcc -O2, 1 thread -- the reference has no threading)
     on a bounded sample of the same workload: as many 2^20-sample channels of config 2 as fit in ~12 s."""
     import ctypes as C
@@ -40,12 +40,12 @@ def cpu_baseline(length, budget_s=12.0):
     if os.path.exists(ref_lib):
         from tests.golden import make_golden as mg
         L = mg.load()
-        cfg = mg.Cfg(N, M, D, 1.0, 0)
+        cfg = mg.Cfg(N, M, deriv, 1.0, 0)
         f = L.savgol_create(C.byref(cfg))
         run = lambda: L.savgol_apply(f, mg.fptr(x), mg.fptr(y), length)
         kind = "reference"
     else:
-        f = sgo.Filter(N, M, D)
+        f = sgo.Filter(N, M, deriv)
         run = lambda: f.apply(x)
         kind = "port"
     run()
@@ -56,7 +56,7 @@ def cpu_baseline(length, budget_s=12.0):
         if el > budget_s:
             break
     return {"value": round(n_done * length / el / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
-            "sample": f"{n_done} channels x {length} fp32 samples of config 2 (n={N}, m={M}, POLYNOMIAL), "
+            "sample": f"{n_done} channels x {length} fp32 samples (the reference is fp32 only; n={N}, m={M}, d={deriv}, POLYNOMIAL), "
                       f"savgol_apply back to back for {el:.1f} s, 1 thread"}
 
 
@@ -210,8 +210,10 @@ def main():
     ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
     ap.add_argument("--length", type=int, default=1 << 20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--workload", choices=["batch1d", "stream", "image"], default="batch1d",
-                    help="batch1d = the headline (BASELINE config 2); stream / image = configs 3 / 4, single GPU, extra JSON")
+    ap.add_argument("--workload", choices=["batch1d", "batch1d_f64", "stream", "image"], default="batch1d",
+                    help="batch1d = the headline (BASELINE config 2); batch1d_f64 = config 5's per-GPU shape (fp64, n=32, d=2, "
+                         "2^22-sample channels, POLYNOMIAL; 1024 channels per GPU by default); stream / image = configs 3 / 4, "
+                         "single GPU, extra JSON")
     ap.add_argument("--streams", type=int, default=65536)
     ap.add_argument("--ticks", type=int, default=4096)
     ap.add_argument("--images", type=int, default=64)
@@ -219,7 +221,7 @@ def main():
     ap.add_argument("--method", type=int, default=2, help="2-D: 1 = dense (bit-exact), 2 = separable")
     args = ap.parse_args()
     args.no_cpu = args.no_cpu
-    if args.workload != "batch1d":
+    if args.workload in ("stream", "image"):
         sg = load_package()
         (bench_stream if args.workload == "stream" else bench_image)(sg, args)
         return
@@ -239,11 +241,18 @@ def main():
     sg = load_package()
     assert sg.lib().savgol_hip_set_device(local) == 0, sg.last_error()
 
+    f64 = args.workload == "batch1d_f64"
+    if f64:                                               # config 5 shape unless overridden on the command line
+        if args.channels == 4096: args.channels = 1024
+        if args.length == 1 << 20: args.length = 1 << 22
     ch, length = args.channels, args.length
-    x = torch.empty((ch, length), dtype=torch.float32, device=dev)
+    deriv = 2 if f64 else D
+    modes = [0] if f64 else [0, 1, 2, 3]
+    esize = 8 if f64 else 4
+    x = torch.empty((ch, length), dtype=torch.float64 if f64 else torch.float32, device=dev)
     y = torch.empty_like(x)
     sg.synth(x, channel0=rank * ch)                       # generated in HBM, never crosses PCIe
-    filters = [sg.Filter(N, M, D, 1.0, mode) for mode in range(4)]
+    filters = [sg.Filter(N, M, deriv, 1.0, mode) for mode in modes]
     torch.cuda.synchronize()
 
     def step(events=None):
@@ -251,7 +260,7 @@ def main():
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            f.apply_batch(x, y, ch, length)
+            f.apply_batch(x, y, ch, length, dtype="f64" if f64 else "f32")
             if events is not None:
                 e1.record(); events.append((e0, e1))
 
@@ -279,11 +288,12 @@ def main():
     if rank == 0:
         launches_ms = [a.elapsed_time(b) for a, b in events]
         avg_ms = float(np.mean(launches_ms))
-        alg_bytes = 8.0 * ch * length                      # 4 B read + 4 B written per sample
+        alg_bytes = 2.0 * esize * ch * length               # sizeof(T) read + sizeof(T) written per sample
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        samples = 4.0 * ch * length * args.steps * world
+        samples = float(len(modes)) * ch * length * args.steps * world
         out = {
-            "metric": "Msamples/s filtered (1D batch, hw=32, poly=4) + % HBM roofline",
+            "metric": "Msamples/s filtered (1D batch, hw=32, poly=4) + % HBM roofline" if not f64 else
+                      "Msamples/s filtered (1D batch fp64, hw=32, poly=4, derivative=2) + % HBM roofline",
             "value": round(samples / elapsed / 1e6, 1),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -293,27 +303,29 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f64" if f64 else "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: {ch} channels x {length} fp32 samples per GPU, half_window={N}, "
-                                   f"poly_order={M}, derivative={D}, one pass per boundary mode "
-                                   "(POLYNOMIAL, REFLECT, PERIODIC, CONSTANT) per step",
+            "config": {"workload": (f"BASELINE config 2: {ch} channels x {length} fp32 samples per GPU, half_window={N}, "
+                                    f"poly_order={M}, derivative={D}, one pass per boundary mode "
+                                    "(POLYNOMIAL, REFLECT, PERIODIC, CONSTANT) per step") if not f64 else
+                                   (f"BASELINE config 5 shape: {ch} channels x {length} fp64 samples per GPU (the full config is 4096 per "
+                                    f"GPU, processed in such chunks), half_window={N}, poly_order={M}, derivative=2, POLYNOMIAL"),
                        "channels_per_gpu": ch, "length": length, "sharding": "channels, no collective"},
-            "roofline": {"bound": "hbm", "kernel": f"sg1d_center_kernel<float,{N}>",
+            "roofline": {"bound": "hbm", "kernel": f"sg1d_center_kernel<{'double' if f64 else 'float'},{N}>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(ch, length),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if f64 else pmc_traffic(ch, length),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
                          "launches_timed": len(launches_ms)},
         }
         if world == 1 and not args.no_cpu:
             # CPU leg (rank 0, N=1 only): the reference timed on this host + a parity spot check of what was just
             # timed (last mode run = CONSTANT) against the CPU oracle -- the only place bench.py touches oracle/
-            out["cpu_baseline"] = cpu_baseline(length)
+            out["cpu_baseline"] = cpu_baseline(length, deriv)
             from oracle import sgo
             sample = [0, ch // 2, ch - 1]
-            ref = sgo.Filter(N, M, D, 1.0, 3).apply_f64(x[sample].cpu().numpy().astype(np.float64))
+            ref = sgo.Filter(N, M, deriv, 1.0, modes[-1]).apply_f64(x[sample].cpu().numpy().astype(np.float64))
             checked = float(np.max(np.abs(y[sample].cpu().numpy() - ref)) / np.max(np.abs(ref)))
-            assert checked < 1e-6, f"parity lost: normwise error {checked}"
+            assert checked < (1e-12 if f64 else 1e-6), f"parity lost: normwise error {checked}"
             out["parity_normwise_vs_fp64_oracle"] = checked
         print(json.dumps(out), flush=True)
     if dist is not None:
