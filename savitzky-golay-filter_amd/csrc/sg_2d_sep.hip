@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *tin = lds;                                   // [ROWS][PIN]
     float *hbuf = tin + S::ROWS * S::PIN;               // [ROWS][PH]
-    float *wl = hbuf + S::ROWS * S::PH;                 // per term: Q_t (2N+2 floats) then G_t (2N+2 floats)
+    float *wl = hbuf + (S::ROWS + 4) * S::PH;           // (4 spare rows, see the column pass) per term: Q_t, G_t (2N+2 floats each)
 
     const int tid = threadIdx.x;
     constexpr int TCOLS = 64 + 2 * N;
@@ -200,10 +200,17 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
                 const float *col = hbuf + crow * S::PH + ccol;
                 WinConv<N, S::RYP>::template quads<0>(
                     [&](int q) {
-                        // rows beyond the tile (only touched by the padded accumulator of an odd RY) read row ROWS-1
                         const int r0 = 4 * q;
-                        auto rd = [&](int r) { return col[(crow + r < S::ROWS ? r : S::ROWS - 1 - crow) * S::PH]; };
-                        return make_float4(rd(r0), rd(r0 + 1), rd(r0 + 2), rd(r0 + 3));
+                        if constexpr (S::RYP == S::RY) {
+                            // every needed row is inside the tile; the last quad may run up to 3 rows past it, into the
+                            // spare rows kept behind hbuf (their values only meet taps that do not exist)
+                            return make_float4(col[r0 * S::PH], col[(r0 + 1) * S::PH], col[(r0 + 2) * S::PH], col[(r0 + 3) * S::PH]);
+                        } else {
+                            // rows beyond the tile (touched only by the padded accumulator of an odd RY or by the last,
+                            // partly unused quad) read row ROWS-1 instead
+                            auto rd = [&](int r) { return col[(crow + r < S::ROWS ? r : S::ROWS - 1 - crow) * S::PH]; };
+                            return make_float4(rd(r0), rd(r0 + 1), rd(r0 + 2), rd(r0 + 3));
+                        }
                     },
                     acc, Wg, f32x2{0.0f, 0.0f});
             }
@@ -234,7 +241,7 @@ static void launch_sep(const Job2D &job, const SepPlan &plan, const float *d_fac
     Job2D j = job;
     j.tiles_x = (job.cols + S::TW - 1) / S::TW;
     j.tiles_y = (job.rows + S::TH - 1) / S::TH;
-    const size_t lds = sizeof(float) * (S::ROWS * S::PIN + S::ROWS * S::PH + SEP_MAX_OUTPUTS * SEP_MAX_TERMS * 2 * (2 * N + 2));
+    const size_t lds = sizeof(float) * (S::ROWS * S::PIN + (S::ROWS + 4) * S::PH + SEP_MAX_OUTPUTS * SEP_MAX_TERMS * 2 * (2 * N + 2));
     const unsigned long long total = (unsigned long long)images * j.tiles_x * j.tiles_y;      // caller keeps this < 2^32
     const unsigned per_cu = (unsigned)(160 * 1024 / lds) < 4u ? (unsigned)(160 * 1024 / lds) : 4u;
     unsigned grid = (unsigned)cu_count * (per_cu ? per_cu : 1u);

@@ -19,3 +19,13 @@ def test_reference_program(name, expect):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert expect in r.stdout, r.stdout[-2000:]
+
+
+def test_plain_c_program_against_the_c_abi():
+    """examples/c_api_demo.c: C host code -> C ABI -> HIP kernels (drop-in call, device batch, stream bank latency)."""
+    exe = os.path.join(ROOT, "savitzky-golay-filter_amd", "lib", "c_api_demo")
+    assert os.path.exists(exe), "build it with `make -C savitzky-golay-filter_amd`"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "c_api_demo: OK" in r.stdout
+    print(r.stdout)
