@@ -258,3 +258,44 @@ def test_opt_in_corrected_leading_edge_sign(sg, sgo, torch_gpu):
         assert L.savgol_hip_set_option(99, 1) == -1
     finally:
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE, 0)
+
+
+def test_shared_filter_from_many_threads(sg, sgo, torch_gpu):
+    """The reference documents savgol_apply as thread-safe on a shared, read-only filter (savgolFilter.h:16-19);
+    ctypes drops the GIL during the calls, so these really overlap."""
+    import threading
+    torch = torch_gpu
+    f = sg.Filter(8, 3, 0, 1.0, sg.SAVGOL_BOUNDARY_REFLECT)
+    rng = np.random.default_rng(77)
+    inputs = [signal(rng, (4000 + 13 * k,)).astype(np.float32) for k in range(8)]
+    want = [f.apply(x) for x in inputs]
+    errors = []
+
+    def host_worker(k):
+        try:
+            for _ in range(25):
+                if not np.array_equal(f.apply(inputs[k]), want[k]):
+                    errors.append(("host", k))
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(("host", k, repr(e)))
+
+    def device_worker(k):
+        try:
+            s = torch.cuda.Stream()
+            x = torch.from_numpy(np.tile(inputs[k], (16, 1))).cuda()
+            y = torch.empty_like(x)
+            for _ in range(25):
+                f.apply_batch(x, y, 16, x.shape[1], stream=s)
+            s.synchronize()
+            if not np.array_equal(y[3].cpu().numpy(), want[k]):
+                errors.append(("device", k))
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(("device", k, repr(e)))
+
+    threads = [threading.Thread(target=host_worker, args=(k,)) for k in range(4)]
+    threads += [threading.Thread(target=device_worker, args=(k,)) for k in range(4, 8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
