@@ -209,6 +209,47 @@ static int dispatch_block(int n, const float *ring, const float *samples, float 
     else return 0;
 }
 
+// One tick with every load in flight at once: half window known at compile time, so the 2n ring rows a stream needs
+// are 2n independent loads (the newest sample comes straight from `samples`), then the strictly ordered multiply-add
+// chain.  The generic kernel above waits for the ring in batches of 8.
+template <int N>
+__global__ __launch_bounds__(256) void sg_bank_tick_n_kernel(float *__restrict__ ring, const float *__restrict__ samples,
+                                                             float *__restrict__ out, size_t streams, const StreamTaps taps,
+                                                             int wp_old, float dt_inv)
+{
+    constexpr int WS = 2 * N + 1;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= streams) return;
+    const float xnew = samples[s];
+    ring[(size_t)wp_old * streams + s] = xnew;
+    float v[WS];
+    int slot = wp_old + 1;                                  // oldest sample
+    if (slot >= WS) slot = 0;
+#pragma unroll
+    for (int i = 0; i < WS - 1; ++i) {
+        v[i] = ring[(size_t)slot * streams + s];
+        if (++slot >= WS) slot = 0;
+    }
+    v[WS - 1] = xnew;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < WS; ++i) acc = __fadd_rn(acc, __fmul_rn(taps.w[i], v[i]));
+    out[s] = __fmul_rn(acc, dt_inv);
+}
+
+template <int N>
+static int dispatch_tick(int n, float *ring, const float *samples, float *out, size_t streams, const StreamTaps &taps, int wp_old,
+                         float dt_inv, hipStream_t st)
+{
+    if (n == N) {
+        hipLaunchKernelGGL((sg_bank_tick_n_kernel<N>), dim3((unsigned)((streams + 255) / 256)), dim3(256), 0, st, ring, samples, out,
+                           streams, taps, wp_old, dt_inv);
+        return 1;
+    }
+    if constexpr (N < SAVGOL_MAX_HALF_WINDOW) return dispatch_tick<N + 1>(n, ring, samples, out, streams, taps, wp_old, dt_inv, st);
+    else return 0;
+}
+
 // single stream (host drop-in API): the ring sits in pinned host memory (the caller-visible POD is the
 // state), results go back to pinned host memory; thread r computes output row r
 __global__ __launch_bounds__(64) void sg_stream_rows_kernel(const float *__restrict__ ring, float *__restrict__ out,
@@ -495,8 +536,16 @@ int savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float
     if (!bank || !d_samples || !d_out) { sg_set_error("savgol_streambank_push: NULL pointer"); return -1; }
     const int ws = bank->filter->window_size;
     const int emit = (bank->received + 1 >= (unsigned long long)ws) ? 1 : 0;
-    hipLaunchKernelGGL(sg::sg_bank_tick_kernel, dim3(sg::bank_blocks(bank)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       bank->d_ring, d_samples, d_out, bank->streams, bank->d_table, ws, bank->wp, bank->dt_inv, emit);
+    if (emit) {
+        sg::StreamTaps taps;
+        memset(&taps, 0, sizeof(taps));
+        memcpy(taps.w, bank->filter->center_weights, sizeof(float) * ws);
+        sg::dispatch_tick<1>(bank->filter->config.half_window, bank->d_ring, d_samples, d_out, bank->streams, taps, bank->wp,
+                             bank->dt_inv, static_cast<hipStream_t>(stream));
+    } else {
+        hipLaunchKernelGGL(sg::sg_bank_tick_kernel, dim3(sg::bank_blocks(bank)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           bank->d_ring, d_samples, d_out, bank->streams, bank->d_table, ws, bank->wp, bank->dt_inv, 0);
+    }
     if (!sg::hip_ok(hipGetLastError(), "savgol_streambank_push launch")) return -1;
     bank->wp = (bank->wp + 1) % ws;
     bank->received++;
