@@ -230,11 +230,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # test hooks (tests/test_gpu_bench_contract.py): run the N>1 plumbing on a 1-GPU box with every rank on one device
+    backend = os.environ.get("SAVGOL_BENCH_BACKEND", "nccl")
+    if "SAVGOL_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["SAVGOL_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
