@@ -187,20 +187,6 @@ __device__ __forceinline__ f32x2 pk_straddle(const f32x2 a, const f32x2 b)
     return o;
 }
 
-#ifndef SG_ODD_FROM_LDS
-#define SG_ODD_FROM_LDS 0   /* measured: 7.72 ms vs 7.40 ms at N=32 -- the extra LDS latency costs more than the v_pk_mov_b32 it saves */
-#endif
-// window elements I and I+1 of this lane, as an aligned register pair (the slab is padded by one 16-B
-// vector after every 8, hence the index arithmetic; both offsets are literals)
-template <int I, int VPL = 8>
-__device__ __forceinline__ f32x2 lds_pair(const char *win)
-{
-    constexpr int a = slab_vec_off<VPL>(I >> 2) / 4 + (I & 3);
-    constexpr int b = slab_vec_off<VPL>((I + 1) >> 2) / 4 + ((I + 1) & 3);
-    const float *w = reinterpret_cast<const float *>(win);
-    return f32x2{w[a], w[b]};
-}
-
 template <int N>
 struct Conv<float, N> {
     typedef K1D<float, N> K;
@@ -215,27 +201,18 @@ struct Conv<float, N> {
         }
     }
     template <int Q>
-    static __device__ __forceinline__ void quads(const char *win, const char *win_odd, f32x2 (&A)[K::R / 2], const f32x2 (&W)[33], f32x2 prev)
+    static __device__ __forceinline__ void quads(const char *win, f32x2 (&A)[K::R / 2], const f32x2 (&W)[33], f32x2 prev)
     {
         if constexpr (Q < K::WQ) {
             const float4 v = *reinterpret_cast<const float4 *>(win + slab_vec_off<K::VPL>(Q));
             const f32x2 e0 = {v.x, v.y}, e1 = {v.z, v.w};
-#if SG_ODD_FROM_LDS
-            // pairs that start at an odd index are read straight from the slab (ds_read2_b32: the LDS pipe has
-            // slack, the VALU does not) instead of being assembled with v_pk_mov_b32
-            if constexpr (Q > 0) feed<4 * Q - 1>(A, W, lds_pair<4 * Q - 1, K::VPL>(win_odd));
-            feed<4 * Q>(A, W, e0);
-            feed<4 * Q + 1>(A, W, lds_pair<4 * Q + 1, K::VPL>(win_odd));
-            feed<4 * Q + 2>(A, W, e1);
-#else
-            if constexpr (Q > 0) {
-                feed<4 * Q - 1>(A, W, pk_straddle(prev, e0));
-            }
+            // pairs that start at an odd index are assembled from the registers already loaded (one v_pk_mov_b32 each);
+            // reading them from LDS instead (ds_read2_b32) was measured 4 % slower
+            if constexpr (Q > 0) feed<4 * Q - 1>(A, W, pk_straddle(prev, e0));
             feed<4 * Q>(A, W, e0);
             feed<4 * Q + 1>(A, W, pk_straddle(e0, e1));
             feed<4 * Q + 2>(A, W, e1);
-#endif
-            quads<Q + 1>(win, win_odd, A, W, e1);
+            quads<Q + 1>(win, A, W, e1);
         }
     }
     static __device__ __forceinline__ void run(const char *win, const Taps &taps, float (&acc)[K::R])
@@ -246,12 +223,7 @@ struct Conv<float, N> {
         f32x2 A[K::R / 2];
 #pragma unroll
         for (int j = 0; j < K::R / 2; ++j) A[j] = f32x2{0.0f, 0.0f};
-        // same address, but opaque to the compiler: otherwise it forwards the odd pairs out of the quad registers
-        // (two v_mov each) instead of reading them from LDS
-        int delta = 0;
-        asm("" : "+v"(delta));                        // 0 at run time; keeps win_odd an LDS pointer
-        const char *win_odd = win + delta;
-        quads<0>(win, win_odd, A, W, f32x2{0.0f, 0.0f});
+        quads<0>(win, A, W, f32x2{0.0f, 0.0f});
 #pragma unroll
         for (int j = 0; j < K::R / 2; ++j) { acc[2 * j] = A[j].x; acc[2 * j + 1] = A[j].y; }
     }
