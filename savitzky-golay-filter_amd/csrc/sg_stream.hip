@@ -108,6 +108,8 @@ __global__ __launch_bounds__(256) void sg_bank_rows_kernel(const float *__restri
 // Every accumulator still sees its taps in ascending order with separate multiply and add -> bit-identical to the
 // per-tick kernel and to the reference; 16 independent chains per lane hide the add latency.  HBM traffic = the
 // samples and the outputs (8 B/sample); afterwards sg_bank_store_tail_kernel writes the newest 2n+1 samples back.
+constexpr int BLOCK_TT = 64;         // ticks per block of the time-tiled push (4 lane groups x 16 consecutive ticks); 128 spills and is 6x slower
+
 struct alignas(8) StreamTaps { float w[SAVGOL_MAX_WINDOW + 1]; };     // by-value kernarg -> 33 aligned SGPR pairs
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void sg_bank_block_kernel(const float *__restr
                                                             float *__restrict__ out, size_t streams, const StreamTaps taps,
                                                             int wp0, unsigned long long received0, size_t ticks, float dt_inv)
 {
-    constexpr int WS = 2 * N + 1, TT = 64, PER = 16, ROWS = TT + WS - 1;
+    constexpr int WS = 2 * N + 1, TT = BLOCK_TT, PER = TT / 4, ROWS = TT + WS - 1;
     __shared__ float tile[ROWS * 64];                           // [row][stream]: conflict free both ways
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const size_t s = (size_t)blockIdx.x * 64 + lane;
@@ -192,9 +194,9 @@ static int dispatch_block(int n, const float *ring, const float *samples, float 
 {
     if (n == N) {
         const unsigned gx = (unsigned)((streams + 63) / 64);
-        for (size_t done = 0; done < ticks; done += (size_t)65535 * 64) {       // gridDim.y limit
-            const size_t part = ticks - done < (size_t)65535 * 64 ? ticks - done : (size_t)65535 * 64;
-            hipLaunchKernelGGL((sg_bank_block_kernel<N>), dim3(gx, (unsigned)((part + 63) / 64)), dim3(256), 0, st, ring,
+        for (size_t done = 0; done < ticks; done += (size_t)65535 * BLOCK_TT) {       // gridDim.y limit
+            const size_t part = ticks - done < (size_t)65535 * BLOCK_TT ? ticks - done : (size_t)65535 * BLOCK_TT;
+            hipLaunchKernelGGL((sg_bank_block_kernel<N>), dim3(gx, (unsigned)((part + BLOCK_TT - 1) / BLOCK_TT)), dim3(256), 0, st, ring,
                                samples + done * streams, out + done * streams, streams, taps,
                                (int)((wp0 + done) % (size_t)(2 * N + 1)), received0 + done, part, dt_inv);
             // rows of a later part that reach back before it come out of `samples` only if the ring is current:
