@@ -299,3 +299,23 @@ def test_shared_filter_from_many_threads(sg, sgo, torch_gpu):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_nan_and_inf_propagate_like_the_reference(sg, sgo, torch_gpu, dtype):
+    """A NaN/Inf sample must poison exactly the outputs whose window (after the boundary remap) contains it -- no more
+    (padding lanes, masked outputs), no fewer."""
+    torch = torch_gpu
+    rng = np.random.default_rng(31)
+    n, length, ch = 9, 5000, 4
+    ndt, tdt = (np.float32, torch.float32) if dtype == "f32" else (np.float64, torch.float64)
+    xh = signal(rng, (ch, length)).astype(ndt)
+    xh[0, 0] = np.nan; xh[1, length - 1] = np.inf; xh[2, 2500] = np.nan; xh[3, 3] = -np.inf; xh[3, 2047] = np.nan; xh[3, 2048] = np.inf
+    x = torch.from_numpy(xh).cuda()
+    for mode in range(4):
+        y = sg.Filter(n, 3, 0, 1.0, mode).apply_tensor(x).cpu().numpy()
+        ref = sgo.Filter(n, 3, 0, 1.0, mode).apply_f64(xh.astype(np.float64))
+        assert np.array_equal(np.isnan(y), np.isnan(ref)), mode
+        assert np.array_equal(np.isposinf(y), np.isposinf(ref)) and np.array_equal(np.isneginf(y), np.isneginf(ref)), mode
+        ok = np.isfinite(ref)
+        assert normwise(y[ok], ref[ok]) < (1e-6 if dtype == "f32" else 1e-12)
