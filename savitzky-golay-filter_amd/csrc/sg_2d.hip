@@ -135,7 +135,7 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
     job.scale = f->scale;
     job.tiles_x = (cols + T2_W - 1) / T2_W;
     job.tiles_y = (rows + T2_H - 1) / T2_H;
-    // method: 1 = dense window (bit-identical to the reference), 2 = separable passes, 0 = separable when available
+    // method: 1 = dense window (bit-identical to the reference), 2 = separable passes (3 = its tile kernel only), 0 = separable when available
     if (method != 1) {
         float factors[SEP_MAX_TERMS * 2 * (2 * SAVGOL2D_MAX_HALF_WINDOW + 2)];
         const int terms = sep_factors_cached(&f->config, factors);
@@ -149,6 +149,10 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
                 const size_t ni = images - i0 < max_img ? images - i0 : max_img;
                 job.in = d_in + (long long)i0 * in_pitch;
                 job.out = d_out + (long long)i0 * out_pitch;
+                if (method != 3) {                       // rolling-window kernel where it applies (n <= 8), else the tile kernel
+                    const int rc = sg2d_launch_rolling(nx, terms, job, factors, f->scale, (unsigned)ni, ctx->cu_count, st);
+                    if (rc == 0) continue;
+                }
                 SepPlan plan;
                 memset(&plan, 0, sizeof(plan));
                 plan.outputs = 1; plan.terms[0] = terms; plan.scale[0] = f->scale; plan.out[0] = job.out;
@@ -156,7 +160,7 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
             }
             return hip_ok(hipGetLastError(), who) ? 0 : -1;
         }
-        if (method == 2) { sg_set_error("%s: separable method needs a square window of rank <= %d", who, SEP_MAX_TERMS); return -1; }
+        if (method >= 2) { sg_set_error("%s: separable method needs a square window of rank <= %d", who, SEP_MAX_TERMS); return -1; }
     }
     const size_t lds = sizeof(float) * (size_t)(((f->window_area + 3) & ~3) + (T2_W + 2 * nx) * (T2_H + 2 * ny));
     for (size_t i0 = 0; i0 < images; i0 += 65535) {

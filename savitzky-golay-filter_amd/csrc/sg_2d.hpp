@@ -40,6 +40,16 @@ struct SepPlan {
     float *out[SEP_MAX_OUTPUTS];        // same row stride / image pitch for all
 };
 
+// sg_2d_roll.hip: rolling-window kernel, single output, half windows SEP_ROLL_MIN_N..SEP_ROLL_MAX_N
+#ifndef SEP_ROLL_MIN_N
+#define SEP_ROLL_MIN_N 1
+#endif
+#ifndef SEP_ROLL_MAX_N
+#define SEP_ROLL_MAX_N 8
+#endif
+int sg2d_launch_rolling(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count,
+                        hipStream_t st);      // 0 = launched, 1 = not covered (caller uses the tile kernel)
+
 // sg_2d_sep.hip
 int sg2d_kernel_double(const Savgol2DConfig *cfg, double *Wd);                           // W in double, [2n+1][2n+1]; 0 on success
 int sg2d_factors_from_kernel(const double *Wd, int n, int order, float *factors, int max_terms);   // #terms, 0 = failed

@@ -1,0 +1,383 @@
+// sg_2d_roll.hip -- the 2-D fast path for half windows <= 8: rolling column windows in registers.
+//
+// Same exact low-rank factorisation as sg_2d_sep.hip,  W(x,y) = sum_t G_t(y) Q_t(x)  (reference kernel:
+// src/savgol2d.c:188-265), applied vertical pass first:
+//      v_t = G_t (*)y in        out = sum_t Q_t (*)x v_t
+// One WAVE owns a 256-column strip (a lane owns 4 adjacent columns = one 16-byte load per row) and walks
+// down a band of rows.  The last 2N+1 input rows of its columns stay in registers (a ring that the fully
+// unrolled loop indexes with literals), so the vertical pass costs no LDS traffic and no halo rows; only
+// the r vertical results of the current row cross lanes, through a wave-private LDS row (no
+// __syncthreads anywhere: LDS operations of one wave execute in order).  The 2*HL outermost lanes of a
+// strip are halo (their columns are recomputed by the neighbouring strip): 240 of 256 columns are stored.
+//
+// Every term of one kernel has the same parity in y ((-1)^dy) and in x ((-1)^dx), so both passes fold
+//      sum_k w[k] s[k]  =  sum_{k<N} w[k] (s[k] +- s[2N-k])  +  w[N] s[N]
+// which halves the taps held in SGPRs (N+1 per vector, passed by value in the kernarg) and lets all terms
+// share the folded vertical window.  Arithmetic is v_pk_fma_f32 throughout (two columns per instruction).
+//
+// Rounding differs from the reference's dense sum at the 1e-7 level, like the tile kernel of sg_2d_sep.hip
+// (tests bound both at 1e-6 normwise of the double-accumulation oracle).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <type_traits>
+#include <utility>
+
+#include "sg_2d.hpp"
+#include "sg_runtime.hpp"
+
+namespace sg {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+struct Roll {
+    static constexpr int HL = (N + 3) / 4;                  // halo lanes on each side of a strip
+    static constexpr int OUTL = 64 - 2 * HL;                // lanes whose columns are stored
+    static constexpr int SW = 4 * OUTL;                     // stored columns per strip
+    static constexpr int NQ = 2 * HL + 1;                   // 16-byte quads a lane reads back per term
+    static constexpr int D = 4 * HL - N;                    // window index of the first tap of output 0
+    static constexpr int P = 1;                             // rows loaded ahead of the arithmetic (odd: U must be even)
+    static constexpr int U = 2 * N + 1 + P;                 // ring slots = unroll factor of the row loop
+    static constexpr int BUFW = 256 + 8 * HL;               // LDS floats per term row (strip + pad both sides)
+    static constexpr int NP = N / 2 + 1;                    // SGPR pairs holding taps 0..N
+};
+
+// taps 0..N of every vector (the mirrored half follows from the parity), Q already multiplied by the output scale
+template <int N, int NT>
+struct RollTaps {
+    f32x2 g[NT][Roll<N>::NP];
+    f32x2 q[NT][Roll<N>::NP];
+    f32x2 sy, sx;                                           // +1 / -1 (both halves equal)
+};
+
+// acc += w[SEL] * x      (w: SGPR pair, broadcast to both halves)
+template <int SEL>
+__device__ __forceinline__ void pk_fma_s(f32x2 &acc, const f32x2 w, const f32x2 x)
+{
+    if constexpr (SEL == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(w), "v"(x));
+    else                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(w), "v"(x));
+}
+template <int SEL>
+__device__ __forceinline__ f32x2 pk_mul_s(const f32x2 w, const f32x2 x)
+{
+    f32x2 o;
+    if constexpr (SEL == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(o) : "s"(w), "v"(x));
+    else                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(o) : "s"(w), "v"(x));
+    return o;
+}
+// a + s * b, s = {+-1, +-1} in an SGPR pair.  Deliberately NOT inline asm: the hazard recogniser counts no wait
+// states for inline asm, so a chain of asm multiply-adds gets an s_nop per step unless compiler-visible
+// instructions (these folds) sit between a result and its use.
+__device__ __forceinline__ f32x2 pk_fold(const f32x2 s, const f32x2 b, const f32x2 a)
+{
+    return __builtin_elementwise_fma(s, b, a);
+}
+__device__ __forceinline__ f32x2 pk_cross(const f32x2 a, const f32x2 b)      // (a.y, b.x)
+{
+    f32x2 o;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+__device__ __forceinline__ void wave_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// f(integral_constant<0>) && f(<1>) && ... : a loop whose index is a literal in every iteration; false = break
+template <int... I, typename F>
+__device__ __forceinline__ bool static_for(std::integer_sequence<int, I...>, F &&f)
+{
+    return (f(std::integral_constant<int, I>{}) && ...);
+}
+
+// fix_index (sg_2d.hpp) without branches: the row index is wave-uniform, so this is a handful of SALU selects
+__device__ __forceinline__ int fix_row(int i, int n, bool reflect)
+{
+    const int below = reflect ? ~i : 0;                      // i < 0:  -i-1 | 0
+    const int above = reflect ? 2 * n - 1 - i : n - 1;       // i >= n
+    int a = i < 0 ? below : (i >= n ? above : i);
+    a = a < 0 ? 0 : a;                                       // frames smaller than the window: one reflection, then clamp
+    return a >= n ? n - 1 : a;
+}
+
+// One item: the strip of SW stored columns at sx, output rows yb .. yb+nout-1 of one frame.  VEC: the strip's 256
+// input columns are inside the frame, all its SW output columns are stored and rows are 16-byte aligned (one
+// dwordx4 load and store per lane per row); otherwise four remapped scalar loads and masked scalar stores (the
+// strips at the left / right frame edge, odd strides).
+// Row r of the band's input (frame row yb-N+r, remapped at the frame border) lives in ring slot r % U.  Output row m
+// needs rows m .. m+2N; while it is computed, row m+2N+P is already being loaded into the slot row m-1 left.
+// The two passes are skewed by one row: iteration m first issues the LDS reads of row m-1's horizontal window
+// (written one iteration earlier), runs the vertical pass of row m while they are in flight, writes its results to
+// the other LDS row, then does row m-1's horizontal arithmetic and store -- no pass waits for its own LDS round trip.
+template <int N, int NT, bool VEC>
+__device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT> &taps, float *mine, const float *in, float *out,
+                                          int sx, int yb, int nout, int lane, int xlo, int xhi, int ylo, int yhi)
+{
+    typedef Roll<N> R;
+    static_assert(R::U % 2 == 0, "the LDS row alternates with the ring slot: U must be even");
+    const int c0 = sx - 4 * R::HL + 4 * lane;                // this lane's first column (frame coordinates)
+    int ix0 = 0, ix1 = 0, ix2 = 0, ix3 = 0;
+    if constexpr (!VEC) {
+        ix0 = fix_index(c0, job.cols, job.boundary); ix1 = fix_index(c0 + 1, job.cols, job.boundary);
+        ix2 = fix_index(c0 + 2, job.cols, job.boundary); ix3 = fix_index(c0 + 3, job.cols, job.boundary);
+    }
+    const bool reflect = job.boundary == SAVGOL2D_BOUNDARY_REFLECT;
+    auto load_row = [&](int r) -> f32x4 {                    // rows past the band are clamped re-reads that are never used
+        const float *row = in + (long long)fix_row(yb - N + r, job.rows, reflect) * job.in_stride;
+        if constexpr (VEC) return *reinterpret_cast<const f32x4 *>(row + c0);
+        else return f32x4{row[ix0], row[ix1], row[ix2], row[ix3]};
+    };
+    const bool out_lane = lane >= R::HL && lane < 64 - R::HL;
+    float *const wr = mine + 4 * R::HL + 4 * lane;           // where this lane's vertical results go
+    const float *const rd = mine + 4 * lane;                 // where its horizontal window starts
+
+    f32x4 win[R::U];
+
+    // vertical pass of the output row whose first input row sits in slot u0 -> LDS row `par`
+    auto vertical = [&](auto u0c, int par) {
+        constexpr int u0 = decltype(u0c)::value;
+        // Instruction order matters: the assembler pads an inline-asm result that is consumed within the next two
+        // instructions with s_nop, so the fold of tap k+1 is issued before the multiply-adds of tap k and the
+        // accumulator chains (2 column pairs x NT terms) are interleaved.
+        f32x2 v[NT][2], f[2][N + 1];
+        auto fold = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const f32x4 a = win[(u0 + k) % R::U], b = win[(u0 + 2 * N - k) % R::U];
+            if constexpr (k < N) {
+                f[0][k] = pk_fold(taps.sy, f32x2{b.x, b.y}, f32x2{a.x, a.y});
+                f[1][k] = pk_fold(taps.sy, f32x2{b.z, b.w}, f32x2{a.z, a.w});
+            } else {
+                f[0][N] = f32x2{a.x, a.y};
+                f[1][N] = f32x2{a.z, a.w};
+            }
+        };
+        fold(std::integral_constant<int, 0>{});
+        static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if constexpr (k == 0) v[t][c] = pk_mul_s<0>(taps.g[t][0], f[c][0]);
+                    else pk_fma_s<(k & 1)>(v[t][c], taps.g[t][k >> 1], f[c][k]);
+                }
+            return true;
+        });
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            *reinterpret_cast<f32x4 *>(wr + (par * NT + t) * R::BUFW) = f32x4{v[t][0].x, v[t][0].y, v[t][1].x, v[t][1].y};
+    };
+    // horizontal pass, part 1: this lane's window of every term's strip row, from LDS row `par`
+    f32x4 hq[NT][R::NQ];
+    auto fetch = [&](int par) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < R::NQ; ++q) hq[t][q] = *reinterpret_cast<const f32x4 *>(rd + (par * NT + t) * R::BUFW + 4 * q);
+    };
+    // part 2: the arithmetic on the fetched window and the store of frame row yo
+    auto horizontal = [&](int yo) {
+        f32x2 o[2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x2 e[2 * R::NQ + 1];
+#pragma unroll
+            for (int q = 0; q < R::NQ; ++q) {
+                e[2 * q] = f32x2{hq[t][q].x, hq[t][q].y};
+                e[2 * q + 1] = f32x2{hq[t][q].z, hq[t][q].w};
+            }
+            f32x2 pr[2 * N + 3];                             // pr[j] = window floats (D+j, D+j+1)
+#pragma unroll
+            for (int j = 0; j < 2 * N + 3; ++j) {
+                const int idx = R::D + j;
+                pr[j] = (idx & 1) ? pk_cross(e[idx >> 1], e[(idx >> 1) + 1]) : e[idx >> 1];
+            }
+            f32x2 f[2][N + 1];
+            auto fold = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < N) {
+                    f[0][k] = pk_fold(taps.sx, pr[2 * N - k], pr[k]);
+                    f[1][k] = pk_fold(taps.sx, pr[2 + 2 * N - k], pr[2 + k]);
+                } else {
+                    f[0][N] = pr[N];
+                    f[1][N] = pr[2 + N];
+                }
+            };
+            fold(std::integral_constant<int, 0>{});
+            static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
+                if (k == 0 && t == 0) { o[0] = pk_mul_s<0>(taps.q[0][0], f[0][0]); o[1] = pk_mul_s<0>(taps.q[0][0], f[1][0]); }
+                else { pk_fma_s<(k & 1)>(o[0], taps.q[t][k >> 1], f[0][k]); pk_fma_s<(k & 1)>(o[1], taps.q[t][k >> 1], f[1][k]); }
+                return true;
+            });
+        }
+        if (yo >= ylo && yo < yhi) {                         // uniform
+            float *orow = out + (long long)yo * job.out_stride;
+            if constexpr (VEC) {
+                if (out_lane)
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, f32x4{o[0].x, o[0].y, o[1].x, o[1].y}),
+                                                reinterpret_cast<u32x4 *>(orow + c0));
+            } else if (out_lane) {
+                if (c0 >= xlo && c0 < xhi) orow[c0] = o[0].x;
+                if (c0 + 1 >= xlo && c0 + 1 < xhi) orow[c0 + 1] = o[0].y;
+                if (c0 + 2 >= xlo && c0 + 2 < xhi) orow[c0 + 2] = o[1].x;
+                if (c0 + 3 >= xlo && c0 + 3 < xhi) orow[c0 + 3] = o[1].y;
+            }
+        }
+    };
+
+#pragma unroll
+    for (int r = 0; r < R::U - 1; ++r) win[r] = load_row(r);
+    win[R::U - 1] = load_row(R::U - 1);
+    vertical(std::integral_constant<int, 0>{}, 0);
+    int done = 1;                                            // rows whose vertical pass has run
+    for (int base = 1; base < nout; base += R::U) {
+        static_for(std::make_integer_sequence<int, R::U>{}, [&](auto uuc) -> bool {
+            constexpr int uu = decltype(uuc)::value;
+            const int m = base + uu;                         // base = 1 mod U: row m starts in slot (uu+1) % U
+            if (m >= nout) return false;                     // uniform
+            win[uu] = load_row(m + R::U - 1);                // slot of row m-1, which no later row needs
+            vertical(std::integral_constant<int, (uu + 1) % R::U>{}, (uu + 1) & 1);
+            wave_order();                                    // row m-1's LDS row was written one iteration ago
+            fetch(uu & 1);
+            horizontal(yb + m - 1);
+            done = m + 1;
+            return true;
+        });
+    }
+    wave_order();
+    fetch((done - 1) & 1);
+    horizontal(yb + done - 1);
+    wave_order();                                            // the next item's first write must stay behind these reads
+}
+
+template <int N, int NT>
+__global__ __launch_bounds__(256, (NT >= 3 && N >= 6) ? 3 : 4) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT> taps, unsigned strips, unsigned bands,
+                                                           int band_rows, unsigned total_items, int aligned)
+{
+    typedef Roll<N> R;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *mine = lds + wv * (2 * NT * R::BUFW);             // two LDS rows per term, private to this wave
+
+    // persistent waves; blocks that share an XCD (blockIdx % 8) take neighbouring items (halo columns meet in L2)
+    const unsigned nblk = gridDim.x;
+    const unsigned blk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const unsigned nwaves = nblk * 4u;
+
+    const bool valid = job.boundary == SAVGOL2D_BOUNDARY_VALID;
+    const int xlo = valid ? N : 0, xhi = valid ? job.cols - N : job.cols;
+    const int ylo = valid ? N : 0, yhi = valid ? job.rows - N : job.rows;
+
+    for (unsigned item = blk * 4u + (unsigned)wv; item < total_items; item += nwaves) {
+        const unsigned strip = item % strips, ib = item / strips;
+        const unsigned band = ib % bands, img = ib / bands;
+        const int sx = (int)strip * R::SW, yb = (int)band * band_rows;
+        const int nout = job.rows - yb < band_rows ? job.rows - yb : band_rows;
+        const float *in = job.in + (long long)img * job.in_pitch;
+        float *out = job.out + (long long)img * job.out_pitch;
+        // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
+        if (aligned == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
+            roll_item<N, NT, true>(job, taps, mine, in, out, sx, yb, nout, lane, xlo, xhi, ylo, yhi);
+        else
+            roll_item<N, NT, false>(job, taps, mine, in, out, sx, yb, nout, lane, xlo, xhi, ylo, yhi);
+    }
+}
+
+// ---- host ----
+// factors: per term Q_t[0..2N], pad, G_t[0..2N], pad (sg2d_factors_from_kernel).  Returns false when a vector has no
+// definite parity (cannot happen for a least-squares kernel on a symmetric window; arbitrary kernels may).
+static bool vector_parity(const float *v, int n, float *sign)
+{
+    float vmax = 0.0f;
+    for (int k = 0; k <= 2 * n; ++k) vmax = fmaxf(vmax, fabsf(v[k]));
+    const float tol = 4e-6f * vmax;
+    bool even = true, odd = true;
+    for (int k = 0; k < n; ++k) {
+        if (fabsf(v[k] - v[2 * n - k]) > tol) even = false;
+        if (fabsf(v[k] + v[2 * n - k]) > tol) odd = false;
+    }
+    if (fabsf(v[n]) > tol) odd = false;
+    if (even) { *sign = 1.0f; return true; }
+    if (odd) { *sign = -1.0f; return true; }
+    return false;
+}
+
+template <int N, int NT>
+static int launch_roll(const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
+{
+    typedef Roll<N> R;
+    RollTaps<N, NT> taps;
+    memset(&taps, 0, sizeof(taps));
+    float sy = 0.0f, sx = 0.0f;
+    for (int t = 0; t < NT; ++t) {
+        const float *q = factors + (size_t)t * 2 * (2 * N + 2), *g = q + (2 * N + 2);
+        float s1, s2;
+        if (!vector_parity(g, N, &s1) || !vector_parity(q, N, &s2)) return 1;
+        if (t > 0 && (s1 != sy || s2 != sx)) return 1;
+        sy = s1; sx = s2;
+        for (int k = 0; k <= N; ++k) {
+            const float gk = (k == N && sy < 0.0f) ? 0.0f : g[k];
+            const float qk = (k == N && sx < 0.0f) ? 0.0f : (float)((double)q[k] * (double)scale);
+            if (k & 1) { taps.g[t][k >> 1].y = gk; taps.q[t][k >> 1].y = qk; }
+            else       { taps.g[t][k >> 1].x = gk; taps.q[t][k >> 1].x = qk; }
+        }
+    }
+    taps.sy = f32x2{sy, sy};
+    taps.sx = f32x2{sx, sx};
+
+    const unsigned strips = (unsigned)((job.cols + R::SW - 1) / R::SW);
+    static int per_cu = 0;                                   // resident blocks per CU of this instantiation
+    const size_t lds = sizeof(float) * 4 * 2 * NT * R::BUFW;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT>, 256, lds) != hipSuccess || nb < 1) nb = 2;
+        per_cu = nb > 4 ? 4 : nb;
+    }
+    const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
+    // bands of about 256 rows (warm-up of 2N rows per band), more and thinner ones when the job is small
+    unsigned bands = (unsigned)((job.rows + 128) / 256);
+    if (bands < 1) bands = 1;
+    while ((unsigned long long)images * strips * bands < 4ull * nwaves && (unsigned)job.rows / bands > 8u * (unsigned)N) bands *= 2;
+    const int band_rows = (int)((job.rows + (int)bands - 1) / (int)bands);
+    bands = (unsigned)((job.rows + band_rows - 1) / band_rows);
+    const unsigned long long total = (unsigned long long)images * strips * bands;     // caller keeps this < 2^32
+    unsigned grid = (unsigned)cu_count * (unsigned)per_cu;
+    if ((unsigned long long)grid * 4ull > total) grid = (unsigned)((total + 3) / 4);
+    grid = (grid + 7u) & ~7u;
+    int aligned = 0;
+    if (job.in_stride % 4 == 0 && job.in_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.in) & 15u) == 0) aligned |= 1;
+    if (job.out_stride % 4 == 0 && job.out_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.out) & 15u) == 0) aligned |= 2;
+    hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT>), dim3(grid), dim3(256), lds, st, job, taps, strips, bands, band_rows, (unsigned)total,
+                       aligned);
+    return 0;
+}
+
+template <int N, int NT>
+static int dispatch_roll(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
+{
+    if (n == N && terms == NT) return launch_roll<N, NT>(job, factors, scale, images, cu_count, st);
+    if constexpr (NT < SEP_MAX_TERMS) return dispatch_roll<N, NT + 1>(n, terms, job, factors, scale, images, cu_count, st);
+    else if constexpr (N < SEP_ROLL_MAX_N) return dispatch_roll<N + 1, 1>(n, terms, job, factors, scale, images, cu_count, st);
+    else return 1;
+}
+
+// 0 = launched, 1 = this kernel does not cover the case (half window > 8, no definite parity): use the tile kernel
+int sg2d_launch_rolling(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count,
+                        hipStream_t st)
+{
+    if (n < 1 || n > SEP_ROLL_MAX_N || terms < 1 || terms > SEP_MAX_TERMS) return 1;
+    return dispatch_roll<SEP_ROLL_MIN_N, 1>(n, terms, job, factors, scale, images, cu_count, st);
+}
+
+}  // namespace sg

@@ -151,6 +151,72 @@ def test_separable_method_vs_double_oracle(sg, sgo, torch_gpu, cfg):
                 assert normwise(got[k][sel], hi[sel]) < (TOL_SEP if dx + dy == 0 else TOL_SEP_DERIV), (cfg, dx, dy, b, normwise(got[k][sel], hi[sel]))
 
 
+@pytest.mark.parametrize("n", range(1, 9))
+def test_rolling_window_kernel_all_half_windows(sg, sgo, torch_gpu, n):
+    """The n <= 8 fast path (sg_2d_roll.hip): 16-byte aligned frames wide and tall enough for interior strips, several
+    row bands and both frame-edge strips; every rank 1..4 (orders 2..6 x derivative pairs); all boundary modes.
+    Against the double-accumulation oracle, and against the tile kernel (method 3) that shares its factors."""
+    torch = torch_gpu
+    rng = np.random.default_rng(100 + n)
+    images, rows, cols, stride = 2, 300 + n, 617, 624
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    x = np.zeros((images, rows, stride), np.float32)
+    for k in range(images):
+        x[k, :, :cols] = (np.sin(0.05 * xx + k) * np.cos(0.03 * yy) + 0.001 * yy + rng.normal(0, 0.1, (rows, cols))).astype(np.float32)
+    d = torch.from_numpy(x).cuda()
+    cases = [(2, 0, 0), (3, 1, 0), (3, 0, 1), (4, 0, 0), (4, 1, 1), (5, 2, 0), (6, 0, 0), (6, 0, 2), (6, 1, 1)]
+    for order, dx, dy in cases:
+        if order > 2 * n:
+            continue
+        f = sg.Filter2D(n, n, order, dx, dy, 0.5, 2.0)
+        o = sgo.Filter2D(n, n, order, dx, dy, 0.5, 2.0)
+        tol = TOL_SEP if dx + dy == 0 and order <= 4 else TOL_SEP_DERIV
+        for b in range(3):
+            got, tile = torch.full_like(d, -5.0), torch.full_like(d, -5.0)
+            f.apply_batch(d, got, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=2)
+            f.apply_batch(d, tile, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=3)
+            g, t = got.cpu().numpy(), tile.cpu().numpy()
+            assert np.array_equal(g == -5.0, t == -5.0), "stored region differs from the tile kernel's"
+            assert normwise(g, t) < tol, (n, order, dx, dy, b, normwise(g, t))
+            if (order, dx, dy) in ((3, 1, 0), (4, 0, 0), (6, 0, 2)):
+                hi = o.apply_f64acc(x[1], cols, b)
+                sel = np.zeros((rows, stride), bool)
+                if b == 0:
+                    sel[n:rows - n, n:cols - n] = True
+                else:
+                    sel[:, :cols] = True
+                assert np.all(g[1][~sel] == -5.0)
+                assert normwise(g[1][sel], hi[sel]) < tol, (n, order, dx, dy, b, normwise(g[1][sel], hi[sel]))
+
+
+def test_rolling_window_kernel_small_and_odd_frames(sg, sgo, torch_gpu):
+    """Frames smaller than the window (padded modes), one-row / one-column frames, unaligned strides and bases."""
+    torch = torch_gpu
+    rng = np.random.default_rng(77)
+    for (n, rows, cols, stride, off) in [(7, 5, 9, 9, 0), (7, 1, 40, 41, 1), (3, 33, 1, 3, 0), (8, 17, 300, 301, 3), (5, 11, 11, 12, 0),
+                                         (7, 40, 263, 264, 0), (2, 700, 20, 20, 0)]:
+        flat = np.zeros(rows * stride + 8, np.float32)
+        img = flat[off:off + rows * stride].reshape(rows, stride)
+        img[:, :cols] = rng.normal(0, 1, (rows, cols)).astype(np.float32)
+        dflat = torch.from_numpy(flat).cuda()
+        d = dflat[off:off + rows * stride]
+        o = sgo.Filter2D(n, n, 3)
+        f = sg.Filter2D(n, n, 3)
+        for b in (1, 2) + ((0,) if rows > 2 * n and cols > 2 * n else ()):
+            out = torch.full((rows * stride + 8,), -5.0, device="cuda")
+            f.apply_batch(d, out[off:off + rows * stride], rows, cols, 1, in_stride=stride, out_stride=stride, boundary=b, method=2)
+            g = out.cpu().numpy()
+            hi = o.apply_f64acc(img, cols, b)
+            sel = np.zeros((rows, stride), bool)
+            if b == 0:
+                sel[n:rows - n, n:cols - n] = True
+            else:
+                sel[:, :cols] = True
+            gi = g[off:off + rows * stride].reshape(rows, stride)
+            assert np.all(g[:off] == -5.0) and np.all(g[off + rows * stride:] == -5.0) and np.all(gi[~sel] == -5.0), (n, rows, cols, b)
+            assert normwise(gi[sel], hi[sel]) < TOL_SEP, (n, rows, cols, b, normwise(gi[sel], hi[sel]))
+
+
 def test_separable_rank4_and_rectangular_fallback(sg, sgo, torch_gpu):
     torch = torch_gpu
     rng = np.random.default_rng(8)
@@ -197,8 +263,9 @@ def test_row_bands_on_gpu_equal_whole_frame(sg, torch_gpu):
 
 def test_fused_gradient_hessian_laplacian_batch(sg, sgo, torch_gpu):
     """Device entry points that produce all requested derivative frames from one read of the input
-    (SURVEY 8f-1).  Gradient / Hessian frames must equal the single-filter separable outputs bit for bit (same
-    factors, same order of operations); the Laplacian (one summed kernel) is checked against the double oracle."""
+    (SURVEY 8f-1).  Gradient / Hessian frames must equal the single-filter outputs of the same (tile) kernel bit for
+    bit (method 3: same factors, same order of operations) and agree with the rolling-window kernel (method 2) to
+    rounding; the Laplacian (one summed kernel) is checked against the double oracle."""
     torch = torch_gpu
     rng = np.random.default_rng(12)
     images, rows, cols, stride = 2, 90, 140, 144
@@ -223,9 +290,12 @@ def test_fused_gradient_hessian_laplacian_batch(sg, sgo, torch_gpu):
         for name, (dx, dy) in (("gx", (1, 0)), ("gy", (0, 1)), ("xx", (2, 0)), ("xy", (1, 1)), ("yy", (0, 2))):
             f = sg.Filter2D(n, n, order, dx, dy, ddx, ddy)
             o = torch.full_like(d, -3.0)
-            f.apply_batch(d, o, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=2)
+            f.apply_batch(d, o, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=3)
             single[name] = o
             assert torch.equal(outs[name], o), (b, name)
+            o2 = torch.full_like(d, -3.0)
+            f.apply_batch(d, o2, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=2)
+            assert torch.equal(o2 == -3.0, o == -3.0) and normwise(o2.cpu().numpy(), o.cpu().numpy()) < TOL_SEP_DERIV, (b, name)
         sel = np.zeros((rows, stride), bool)
         if b == 0:
             sel[n:rows - n, n:cols - n] = True
