@@ -110,16 +110,20 @@ int    savgol_streambank_load(SavgolStreamBank *bank, const void *host_blob, voi
 /* ---------------------------------------------------------------- 2-D batch ----------- *
  * `images` frames, image k at base + k*image_pitch (elements), row pitch in elements.
  * Arithmetic of savgol2d_apply / savgol2d_apply_valid (src/savgol2d.c:356-456).
- * method: 0 = auto, 1 = direct dense window, 2 = exact low-rank separable passes.            */
+ * method: 0 = auto, 1 = direct dense window (bit-identical to the reference), 2 = exact low-rank
+ * separable passes (rolling-window kernel for half windows <= 8, tile kernel above), 3 = the
+ * separable tile kernel for any half window (diagnostic).                                      */
 int savgol2d_apply_batch_f32(const Savgol2DFilter *filter,
                              const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,
                              float *d_out, int out_stride, size_t out_image_pitch,
                              size_t images, Savgol2DBoundary boundary, int method, void *stream);
 
-/* Fused derivative frames (arithmetic of savgol2d_gradient / _hessian / _laplacian, src/savgol2d.c:462-618): every
- * requested output is produced from ONE read of each input tile; the Laplacian uses the single summed kernel
- * (scale_xx*Wxx + scale_yy*Wyy), no temporary frame.  Outputs may be NULL (skipped), like the reference.  Square
- * windows use the separable kernel (fp32 rounding only vs the reference); others one dense pass per output.      */
+/* Derivative frames (arithmetic of savgol2d_gradient / _hessian / _laplacian, src/savgol2d.c:462-618).  The Laplacian
+ * uses the single summed kernel (scale_xx*Wxx + scale_yy*Wyy): no temporary frame, no add pass.  Outputs may be NULL
+ * (skipped), like the reference.  Square windows use the separable kernels (fp32 rounding only vs the reference):
+ * three Hessian frames, and any call with a half window above 8, come from ONE read of each input tile; one or two
+ * frames with a half window <= 8 are one rolling-window launch each (faster).  Other window shapes:
+ * one dense pass per output.                                                                                      */
 int savgol2d_gradient_batch_f32(int half_win_x, int half_win_y, int poly_order,
                                 const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,
                                 float *d_grad_x, float *d_grad_y, int out_stride, size_t out_image_pitch,

@@ -263,9 +263,9 @@ def test_row_bands_on_gpu_equal_whole_frame(sg, torch_gpu):
 
 def test_fused_gradient_hessian_laplacian_batch(sg, sgo, torch_gpu):
     """Device entry points that produce all requested derivative frames from one read of the input
-    (SURVEY 8f-1).  Gradient / Hessian frames must equal the single-filter outputs of the same (tile) kernel bit for
-    bit (method 3: same factors, same order of operations) and agree with the rolling-window kernel (method 2) to
-    rounding; the Laplacian (one summed kernel) is checked against the double oracle."""
+    (SURVEY 8f-1).  Gradient / Hessian frames must equal the single-filter output of the kernel that produced them
+    bit for bit (same factors, same order of operations) and agree with the other separable kernel to rounding; the
+    Laplacian (one summed kernel) is checked against the double oracle."""
     torch = torch_gpu
     rng = np.random.default_rng(12)
     images, rows, cols, stride = 2, 90, 140, 144
@@ -286,15 +286,15 @@ def test_fused_gradient_hessian_laplacian_batch(sg, sgo, torch_gpu):
         assert L.savgol2d_laplacian_batch_f32(n, n, order, d.data_ptr(), rows, cols, stride, pitch, outs["lap"].data_ptr(),
                                               stride, pitch, images, ddx, ddy, b, None) == 0
         torch.cuda.synchronize()
-        single = {}
         for name, (dx, dy) in (("gx", (1, 0)), ("gy", (0, 1)), ("xx", (2, 0)), ("xy", (1, 1)), ("yy", (0, 2))):
             f = sg.Filter2D(n, n, order, dx, dy, ddx, ddy)
             o = torch.full_like(d, -3.0)
             f.apply_batch(d, o, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=3)
-            single[name] = o
-            assert torch.equal(outs[name], o), (b, name)
             o2 = torch.full_like(d, -3.0)
             f.apply_batch(d, o2, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=2)
+            # the library picks the kernel (rolling-window launches for <= 2 frames, the fused tile kernel for 3):
+            # bit-identical to that kernel's single-filter output, and within rounding of the other one
+            assert torch.equal(outs[name], o) or torch.equal(outs[name], o2), (b, name)
             assert torch.equal(o2 == -3.0, o == -3.0) and normwise(o2.cpu().numpy(), o.cpu().numpy()) < TOL_SEP_DERIV, (b, name)
         sel = np.zeros((rows, stride), bool)
         if b == 0:
