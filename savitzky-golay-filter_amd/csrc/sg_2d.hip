@@ -8,11 +8,11 @@
 // Kernel 1 (sg2d_direct_kernel, method 1): the dense window, LDS tile + halo, the SAME summation order
 // and rounding as the reference (__fmul_rn/__fadd_rn) -> bit-identical outputs.  225 taps at n=7 make it
 // VALU/LDS bound (it is the exact path, not the fast one).
-// Kernel 2 (sg2d_separable_kernel, method 2): W is exactly low rank -- W(x,y) = sum_j y^j p_j(x), the
-// p_j read off the least-squares solution vector -- so the frame is filtered as a sum of r <= order+1
-// row*column passes fused in one kernel (rows into LDS intermediates, columns out of them): 2 r (2n+1)
-// FMAs per pixel instead of (2n+1)^2, back in HBM-bound territory.  Differs from the reference by fp32
-// rounding only (1e-7 level).
+// Kernels 2 and 3 (method 2 / auto): W is exactly low rank, W(x,y) = sum_t G_t(y) Q_t(x) with r <= 4 terms, so the
+// frame is filtered as r column passes and r row passes: 2 r (2n+1) FMAs per pixel instead of (2n+1)^2, back in
+// HBM-bound territory; fp32 rounding only (1e-7 level) against the reference.  sg_2d_roll.hip (half windows <= 8:
+// rolling column windows in registers, one launch per output frame) and sg_2d_sep.hip (any half window, up to three
+// output frames from one read of each LDS tile).
 #include <hip/hip_runtime.h>
 
 #include <cmath>

@@ -40,15 +40,19 @@ struct SepPlan {
     float *out[SEP_MAX_OUTPUTS];        // same row stride / image pitch for all
 };
 
-// sg_2d_roll.hip: rolling-window kernel, single output, half windows SEP_ROLL_MIN_N..SEP_ROLL_MAX_N
-#ifndef SEP_ROLL_MIN_N
-#define SEP_ROLL_MIN_N 1
-#endif
-#ifndef SEP_ROLL_MAX_N
-#define SEP_ROLL_MAX_N 8
-#endif
-int sg2d_launch_rolling(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count,
-                        hipStream_t st);      // 0 = launched, 1 = not covered (caller uses the tile kernel)
+// sg_2d_roll.hip: rolling-window kernel, single output, half windows 1..8.  The file is compiled once per
+// half-window group (SEP_ROLL_MIN_N..SEP_ROLL_MAX_N under the name SEP_ROLL_FN, see the Makefile) so the groups
+// build in parallel; each returns 0 = launched, 1 = not covered (other group, or the caller uses the tile kernel).
+int sg2d_launch_rolling_g0(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling_g1(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling_g2(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
+inline int sg2d_launch_rolling(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count,
+                               hipStream_t st)
+{
+    if (sg2d_launch_rolling_g0(n, terms, job, factors, scale, images, cu_count, st) == 0) return 0;
+    if (sg2d_launch_rolling_g1(n, terms, job, factors, scale, images, cu_count, st) == 0) return 0;
+    return sg2d_launch_rolling_g2(n, terms, job, factors, scale, images, cu_count, st);
+}
 
 // sg_2d_sep.hip
 int sg2d_kernel_double(const Savgol2DConfig *cfg, double *Wd);                           // W in double, [2n+1][2n+1]; 0 on success

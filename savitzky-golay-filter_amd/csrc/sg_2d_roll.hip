@@ -372,11 +372,11 @@ static int dispatch_roll(int n, int terms, const Job2D &job, const float *factor
     else return 1;
 }
 
-// 0 = launched, 1 = this kernel does not cover the case (half window > 8, no definite parity): use the tile kernel
-int sg2d_launch_rolling(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count,
-                        hipStream_t st)
+// 0 = launched, 1 = this object does not cover the case (half window outside SEP_ROLL_MIN_N..SEP_ROLL_MAX_N, no
+// definite parity).  Built once per half-window group (Makefile), each under its own name SEP_ROLL_FN.
+int SEP_ROLL_FN(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
 {
-    if (n < 1 || n > SEP_ROLL_MAX_N || terms < 1 || terms > SEP_MAX_TERMS) return 1;
+    if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > SEP_MAX_TERMS) return 1;
     return dispatch_roll<SEP_ROLL_MIN_N, 1>(n, terms, job, factors, scale, images, cu_count, st);
 }
 
