@@ -24,6 +24,7 @@
 
 #include "sg_internal.h"
 #include "sg_runtime.hpp"
+#include "sg_stream.hpp"
 
 namespace sg {
 
@@ -581,6 +582,13 @@ int savgol_streambank_push_full(SavgolStreamBank *bank, const float *d_samples, 
     return rows.count;
 }
 
+// SAVGOL_HIP_STREAM_BLOCK_KERNEL=1 forces the LDS-tiled block kernel (diagnostics / A-B timing)
+static int method_env()
+{
+    static const int v = [] { const char *e = getenv("SAVGOL_HIP_STREAM_BLOCK_KERNEL"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 int savgol_streambank_push_block(SavgolStreamBank *bank, const float *d_samples, size_t ticks, float *d_out, void *stream)
 {
     if (!bank || !d_samples || !d_out) { sg_set_error("savgol_streambank_push_block: NULL pointer"); return -1; }
@@ -589,8 +597,17 @@ int savgol_streambank_push_block(SavgolStreamBank *bank, const float *d_samples,
     sg::StreamTaps taps;
     memset(&taps, 0, sizeof(taps));
     memcpy(taps.w, bank->filter->center_weights, sizeof(float) * ws);
-    if (!sg::dispatch_block<1>(bank->filter->config.half_window, bank->d_ring, d_samples, d_out, bank->streams, taps, bank->wp,
-                               bank->received, ticks, bank->dt_inv, static_cast<hipStream_t>(stream))) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    sg::DeviceCtx *ctx = sg::ctx_get();
+    if (!ctx) return -1;
+    if (method_env() != 1 &&
+        sg::sg_bank_roll_launch(bank->filter->config.half_window, bank->filter->center_weights, bank->d_ring, d_samples, d_out,
+                                bank->streams, bank->wp, bank->received, ticks, bank->dt_inv, ctx->cu_count, st) == 0) {
+        // rolling-window kernel (n <= 16) wrote the outputs; the newest samples still have to reach the ring
+        hipLaunchKernelGGL(sg::sg_bank_store_tail_kernel, dim3((unsigned)((bank->streams + 255) / 256), 8), dim3(256), 0, st,
+                           bank->d_ring, d_samples, bank->streams, ws, bank->wp, ticks);
+    } else if (!sg::dispatch_block<1>(bank->filter->config.half_window, bank->d_ring, d_samples, d_out, bank->streams, taps, bank->wp,
+                               bank->received, ticks, bank->dt_inv, st)) {
         sg_set_error("savgol_streambank_push_block: no kernel for half_window %d", bank->filter->config.half_window);
         return -1;
     }

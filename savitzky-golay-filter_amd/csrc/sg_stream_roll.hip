@@ -1,0 +1,187 @@
+// sg_stream_roll.hip -- savgol_streambank_push_block for half windows <= 16: rolling time windows in registers.
+//
+// A block push is a convolution down the time axis of a [tick][stream] array (history = ring contents, then this
+// call's samples).  One WAVE owns 128 adjacent streams (a lane owns 2 = one 8-byte load per tick) and walks down a
+// band of ticks with the last 2n+1 samples of its streams in registers -- a ring of slots that the fully unrolled
+// tick loop indexes with literals.  No LDS, no __syncthreads, no halo re-reads except the 2n warm-up rows of a band.
+// Per output the arithmetic is the reference's (src/savgol_stream.c:166-185): one fp32 accumulator starting at 0,
+// taps in ascending order, multiply and add rounded separately (v_pk_mul_f32 + v_pk_add_f32: two streams per
+// instruction) -> bit-identical to savgol_stream_push for every stream.  Taps sit in SGPR pairs (by-value kernarg).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <type_traits>
+#include <utility>
+
+#include "sg_internal.h"
+#include "sg_runtime.hpp"
+#include "sg_stream.hpp"
+
+namespace sg {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int N>
+struct SRoll {
+    static constexpr int WS = 2 * N + 1;
+    static constexpr int P = 3;                              // rows loaded ahead of the arithmetic
+    static constexpr int U = WS + P;                         // ring slots = unroll factor of the tick loop
+    static constexpr int NP = N + 1;                         // SGPR pairs holding taps 0..2N
+};
+
+template <int N>
+struct SRollTaps { f32x2 w[SRoll<N>::NP]; };
+
+// w[SEL] * x, the tap broadcast out of an aligned SGPR pair
+template <int SEL>
+__device__ __forceinline__ f32x2 pk_mul_tap(const f32x2 w, const f32x2 x)
+{
+    f32x2 p;
+    if constexpr (SEL == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(w), "v"(x));
+    else                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(p) : "s"(w), "v"(x));
+    return p;
+}
+
+template <int... I, typename F>
+__device__ __forceinline__ bool static_for_s(std::integer_sequence<int, I...>, F &&f)
+{
+    return (f(std::integral_constant<int, I>{}) && ...);
+}
+
+struct BankJob {
+    const float *ring;               // [WS][streams], slot (wp0 - k) mod WS = sample -k of the history
+    const float *samples;            // [ticks][streams]
+    float       *out;                // [ticks][streams]
+    size_t       streams, ticks;
+    unsigned long long received0;    // samples per stream before this call
+    int          wp0;
+    float        dt_inv;
+    unsigned     strips, bands;
+    int          band_ticks;
+    int          aligned;            // rows of samples / ring / out start 8-byte aligned (streams even, bases aligned)
+};
+
+// One item: streams s0, s0+1 of every lane, output ticks t0 .. t0+nt-1.  Row r of the band = history index
+// t0 - 2N + r; output tick m needs rows m .. m+2N, row r lives in ring slot r % U.
+template <int N, bool VEC>
+__device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTaps<N> &taps, size_t s0, size_t t0, int nt)
+{
+    typedef SRoll<N> R;
+    const bool live0 = s0 < job.streams, live1 = s0 + 1 < job.streams;
+    auto load_row = [&](int r) -> f32x2 {
+        long long h = (long long)t0 - 2 * N + r;
+        if (h >= (long long)job.ticks) h = (long long)job.ticks - 1;            // past the call: loaded, never used
+        int slot = job.wp0 + (int)(h < 0 ? h : 0);
+        slot = slot < 0 ? slot + R::WS : slot;
+        const float *row = h >= 0 ? job.samples + (size_t)h * job.streams : job.ring + (size_t)slot * job.streams;
+        if constexpr (VEC) return *reinterpret_cast<const f32x2 *>(row + s0);
+        else return f32x2{live0 ? row[s0] : 0.0f, live1 ? row[s0 + 1] : 0.0f};
+    };
+    f32x2 win[R::U];
+#pragma unroll
+    for (int r = 0; r < R::U - 1; ++r) win[r] = load_row(r);
+
+    for (int base = 0; base < nt; base += R::U) {
+        static_for_s(std::make_integer_sequence<int, R::U>{}, [&](auto uc) -> bool {
+            constexpr int u = decltype(uc)::value;
+            const int m = base + u;
+            if (m >= nt) return false;                                           // uniform
+            win[(u + R::U - 1) % R::U] = load_row(m + R::U - 1);                 // the slot row m-1 left
+            // sum = 0; sum += w[k] * x[k], k ascending, separate roundings.  The product of tap k+1 is issued before
+            // the add of tap k so that no instruction consumes the result of the one just before it.
+            f32x2 acc = f32x2{0.0f, 0.0f};
+            f32x2 p = pk_mul_tap<0>(taps.w[0], win[u % R::U]);
+            static_for_s(std::make_integer_sequence<int, R::WS>{}, [&](auto kc) -> bool {
+                constexpr int k = decltype(kc)::value;
+                f32x2 pn = p;
+                if constexpr (k + 1 < R::WS) pn = pk_mul_tap<((k + 1) & 1)>(taps.w[(k + 1) >> 1], win[(u + k + 1) % R::U]);
+                acc = acc + p;
+                p = pn;
+                return true;
+            });
+            const size_t t = t0 + (size_t)m;
+            if (job.received0 + t + 1 >= (unsigned long long)R::WS) {            // uniform: an output exists (reference :166-170)
+                const f32x2 y = acc * f32x2{job.dt_inv, job.dt_inv};
+                float *orow = job.out + t * job.streams;
+                if constexpr (VEC) *reinterpret_cast<f32x2 *>(orow + s0) = y;
+                else { if (live0) orow[s0] = y.x; if (live1) orow[s0 + 1] = y.y; }
+            }
+            return true;
+        });
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void sg_bank_roll_kernel(const BankJob job, const SRollTaps<N> taps)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // persistent waves; the 4 waves of a block take adjacent strips (2 KB contiguous per tick row)
+    const unsigned nblk = gridDim.x;
+    const unsigned blk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const unsigned long long total = (unsigned long long)job.strips * job.bands;
+    for (unsigned long long item = (unsigned long long)blk * 4u + (unsigned)wv; item < total; item += (unsigned long long)nblk * 4u) {
+        const unsigned strip = (unsigned)(item % job.strips), band = (unsigned)(item / job.strips);
+        const size_t s0 = (size_t)strip * 128 + 2 * (size_t)lane;
+        const size_t t0 = (size_t)band * (size_t)job.band_ticks;
+        const int nt = job.ticks - t0 < (size_t)job.band_ticks ? (int)(job.ticks - t0) : job.band_ticks;
+        if (job.aligned && (size_t)strip * 128 + 128 <= job.streams) bank_roll_item<N, true>(job, taps, s0, t0, nt);
+        else bank_roll_item<N, false>(job, taps, s0, t0, nt);
+    }
+}
+
+template <int N>
+static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipStream_t st)
+{
+    typedef SRoll<N> R;
+    SRollTaps<N> taps;
+    memset(&taps, 0, sizeof(taps));
+    for (int k = 0; k < R::WS; ++k) {
+        if (k & 1) taps.w[k >> 1].y = center[k]; else taps.w[k >> 1].x = center[k];
+    }
+    static int per_cu = 0;                                   // resident blocks per CU of this instantiation
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg_bank_roll_kernel<N>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+        per_cu = nb > 4 ? 4 : nb;
+    }
+    const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
+    job.strips = (unsigned)((job.streams + 127) / 128);
+    // one item per resident wave when the call is long enough (a band re-reads 2n warm-up rows: keep it >= 8 windows)
+    size_t bands = (nwaves + job.strips - 1) / job.strips;
+    const size_t max_bands = job.ticks / (size_t)(8 * R::WS) > 0 ? job.ticks / (size_t)(8 * R::WS) : 1;
+    if (bands > max_bands) bands = max_bands;
+    job.band_ticks = (int)((job.ticks + bands - 1) / bands);
+    job.bands = (unsigned)((job.ticks + (size_t)job.band_ticks - 1) / (size_t)job.band_ticks);
+    const unsigned long long total = (unsigned long long)job.strips * job.bands;
+    unsigned grid = (unsigned)cu_count * (unsigned)per_cu;
+    if ((unsigned long long)grid * 4ull > total) grid = (unsigned)((total + 3) / 4);
+    grid = (grid + 7u) & ~7u;
+    job.aligned = (job.streams % 2 == 0 && ((reinterpret_cast<uintptr_t>(job.samples) | reinterpret_cast<uintptr_t>(job.out) |
+                                              reinterpret_cast<uintptr_t>(job.ring)) & 7u) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((sg_bank_roll_kernel<N>), dim3(grid), dim3(256), 0, st, job, taps);
+    return 0;
+}
+
+template <int N>
+static int dispatch_bank_roll(int n, const float *center, const BankJob &job, int cu_count, hipStream_t st)
+{
+    if (n == N) return launch_bank_roll<N>(center, job, cu_count, st);
+    if constexpr (N < STREAM_ROLL_MAX_N) return dispatch_bank_roll<N + 1>(n, center, job, cu_count, st);
+    else return 1;
+}
+
+// 0 = launched, 1 = half window not covered (the caller uses the LDS-tiled kernel).  ticks per call < 2^31 * band.
+int sg_bank_roll_launch(int n, const float *center_weights, const float *ring, const float *samples, float *out, size_t streams,
+                        int wp0, unsigned long long received0, size_t ticks, float dt_inv, int cu_count, hipStream_t st)
+{
+    if (n < 1 || n > STREAM_ROLL_MAX_N || ticks == 0 || ticks > (size_t)0x7fffffff) return 1;
+    BankJob job;
+    memset(&job, 0, sizeof(job));
+    job.ring = ring; job.samples = samples; job.out = out;
+    job.streams = streams; job.ticks = ticks; job.received0 = received0; job.wp0 = wp0; job.dt_inv = dt_inv;
+    return dispatch_bank_roll<1>(n, center_weights, job, cu_count, st);
+}
+
+}  // namespace sg

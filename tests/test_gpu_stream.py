@@ -160,6 +160,45 @@ def test_stream_bank_bit_exact_vs_oracle(sg, sgo, torch_gpu, cfg):
         assert same_bits(np.array([v for v, ok in seq if ok], np.float32), centre[:, s])
 
 
+@pytest.mark.parametrize("n", list(range(1, 18)) + [32])
+def test_block_push_equals_tick_pushes_every_half_window(sg, torch_gpu, n):
+    """push_block (rolling-window kernel for n <= 16, LDS-tiled kernel above) against the per-tick push kernel, which the
+    test above pins to the oracle: every stream, bit for bit.  Odd stream counts and a misaligned sample pointer take
+    the scalar path; a partly filled ring, a wrapped ring and several row bands per call are all in the sequence."""
+    torch = torch_gpu
+    m = min(3, 2 * n)
+    for S, off in ((777, 1), (1024, 0)):
+        T = 40 * (2 * n + 1) + 7
+        g = torch.Generator(device="cuda").manual_seed(n * 1000 + S)
+        flat = torch.randn(T * S + 4, generator=g, device="cuda", dtype=torch.float32)
+        xd = flat[off:off + T * S].view(T, S)
+        ref = sg.StreamBank(S, n, m, 0, 1.0)
+        o1 = torch.zeros(S, dtype=torch.float32, device="cuda")
+        want = torch.full((T, S), float("nan"), device="cuda")
+        for t in range(T):
+            if ref.push(xd[t], o1) == 1:
+                want[t] = o1
+        bank = sg.StreamBank(S, n, m, 0, 1.0)
+        got = torch.full((T, S), float("nan"), device="cuda")
+        cuts = [0, 3, n + 2, 2 * n + 2, 2 * n + 3, 9 * (2 * n + 1), T]           # filling / just full / wrapped / long
+        total = 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b == a:
+                continue
+            if b - a == 1:
+                r = bank.push(xd[a], o1)
+                if r == 1:
+                    got[a] = o1
+                total += r
+            else:
+                total += bank.push_block(xd[a:b], b - a, got[a:b])
+        torch.cuda.synchronize()
+        assert total == T - 2 * n
+        assert torch.isnan(got[:2 * n]).all() and torch.isnan(want[:2 * n]).all()
+        assert torch.equal(got[2 * n:].view(torch.int32), want[2 * n:].view(torch.int32)), (n, S)
+        assert bank.counters == ref.counters
+
+
 def test_stream_bank_config3_shape(sg, sgo, torch_gpu):
     """BASELINE config 3: 65 536 streams, n=16, m=2, d=1, dt=1e-3 -- sampled streams, bit-exact."""
     torch = torch_gpu
