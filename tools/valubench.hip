@@ -33,10 +33,9 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float w)
 }
 
 template <int KIND>
-void run(const char *name, float *buf)
+void run(const char *name, float *buf, int iters)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    const int iters = 2000;
     for (int wps : {1, 2, 4, 8}) {                        // waves per SIMD: blocks of 256 threads = 1 wave per SIMD each
         const int grid = 256 * wps;
         hipLaunchKernelGGL(k<KIND>, dim3(grid), dim3(256), 0, 0, buf, 10, 1.0f);
@@ -51,13 +50,14 @@ void run(const char *name, float *buf)
     }
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const int iters = argc > 1 ? atoi(argv[1]) : 2000;          // 100000+ = long enough to see the sustained (power-managed) clock
     float *buf; CK(hipMalloc(&buf, 4096)); CK(hipMemset(buf, 0, 4096));
-    run<0>("v_fmac_f32 (sgpr tap)", buf);
-    run<1>("v_pk_fma_f32 (sgpr pair)", buf);
-    run<4>("v_pk_fma_f32 (vgpr pair)", buf);
-    run<2>("v_fmac_f64 (vgpr tap)", buf);
-    run<3>("v_fma_f64 (sgpr tap)", buf);
+    run<0>("v_fmac_f32 (sgpr tap)", buf, iters);
+    run<1>("v_pk_fma_f32 (sgpr pair)", buf, iters);
+    run<4>("v_pk_fma_f32 (vgpr pair)", buf, iters);
+    run<2>("v_fmac_f64 (vgpr tap)", buf, iters);
+    run<3>("v_fma_f64 (sgpr tap)", buf, iters);
     return 0;
 }
