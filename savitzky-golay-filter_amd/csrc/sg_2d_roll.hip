@@ -26,13 +26,10 @@
 #include <utility>
 
 #include "sg_2d.hpp"
+#include "sg_pk.hpp"
 #include "sg_runtime.hpp"
 
 namespace sg {
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int N>
 struct Roll {
@@ -55,21 +52,6 @@ struct RollTaps {
     f32x2 sy, sx;                                           // +1 / -1 (both halves equal)
 };
 
-// acc += w[SEL] * x      (w: SGPR pair, broadcast to both halves)
-template <int SEL>
-__device__ __forceinline__ void pk_fma_s(f32x2 &acc, const f32x2 w, const f32x2 x)
-{
-    if constexpr (SEL == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(w), "v"(x));
-    else                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(w), "v"(x));
-}
-template <int SEL>
-__device__ __forceinline__ f32x2 pk_mul_s(const f32x2 w, const f32x2 x)
-{
-    f32x2 o;
-    if constexpr (SEL == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(o) : "s"(w), "v"(x));
-    else                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(o) : "s"(w), "v"(x));
-    return o;
-}
 // a + s * b, s = {+-1, +-1} in an SGPR pair.  Deliberately NOT inline asm: the hazard recogniser counts no wait
 // states for inline asm, so a chain of asm multiply-adds gets an s_nop per step unless compiler-visible
 // instructions (these folds) sit between a result and its use.
@@ -77,26 +59,6 @@ __device__ __forceinline__ f32x2 pk_fold(const f32x2 s, const f32x2 b, const f32
 {
     return __builtin_elementwise_fma(s, b, a);
 }
-__device__ __forceinline__ f32x2 pk_cross(const f32x2 a, const f32x2 b)      // (a.y, b.x)
-{
-    f32x2 o;
-    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
-__device__ __forceinline__ void wave_order()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// f(integral_constant<0>) && f(<1>) && ... : a loop whose index is a literal in every iteration; false = break
-template <int... I, typename F>
-__device__ __forceinline__ bool static_for(std::integer_sequence<int, I...>, F &&f)
-{
-    return (f(std::integral_constant<int, I>{}) && ...);
-}
-
 // fix_index (sg_2d.hpp) without branches: the row index is wave-uniform, so this is a handful of SALU selects
 __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
 {
@@ -166,8 +128,8 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    if constexpr (k == 0) v[t][c] = pk_mul_s<0>(taps.g[t][0], f[c][0]);
-                    else pk_fma_s<(k & 1)>(v[t][c], taps.g[t][k >> 1], f[c][k]);
+                    if constexpr (k == 0) v[t][c] = pk_mul_sgpr<0>(taps.g[t][0], f[c][0]);
+                    else pk_fma_sgpr<(k & 1)>(v[t][c], taps.g[t][k >> 1], f[c][k]);
                 }
             return true;
         });
@@ -198,7 +160,7 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 #pragma unroll
             for (int j = 0; j < 2 * N + 3; ++j) {
                 const int idx = R::D + j;
-                pr[j] = (idx & 1) ? pk_cross(e[idx >> 1], e[(idx >> 1) + 1]) : e[idx >> 1];
+                pr[j] = (idx & 1) ? pk_straddle(e[idx >> 1], e[(idx >> 1) + 1]) : e[idx >> 1];
             }
             f32x2 f[2][N + 1];
             auto fold = [&](auto kc) {
@@ -215,8 +177,8 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
                 constexpr int k = decltype(kc)::value;
                 if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
-                if (k == 0 && t == 0) { o[0] = pk_mul_s<0>(taps.q[0][0], f[0][0]); o[1] = pk_mul_s<0>(taps.q[0][0], f[1][0]); }
-                else { pk_fma_s<(k & 1)>(o[0], taps.q[t][k >> 1], f[0][k]); pk_fma_s<(k & 1)>(o[1], taps.q[t][k >> 1], f[1][k]); }
+                if (k == 0 && t == 0) { o[0] = pk_mul_sgpr<0>(taps.q[0][0], f[0][0]); o[1] = pk_mul_sgpr<0>(taps.q[0][0], f[1][0]); }
+                else { pk_fma_sgpr<(k & 1)>(o[0], taps.q[t][k >> 1], f[0][k]); pk_fma_sgpr<(k & 1)>(o[1], taps.q[t][k >> 1], f[1][k]); }
                 return true;
             });
         }
@@ -247,17 +209,17 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             if (m >= nout) return false;                     // uniform
             win[uu] = load_row(m + R::U - 1);                // slot of row m-1, which no later row needs
             vertical(std::integral_constant<int, (uu + 1) % R::U>{}, (uu + 1) & 1);
-            wave_order();                                    // row m-1's LDS row was written one iteration ago
+            wave_lds_sync();                                    // row m-1's LDS row was written one iteration ago
             fetch(uu & 1);
             horizontal(yb + m - 1);
             done = m + 1;
             return true;
         });
     }
-    wave_order();
+    wave_lds_sync();
     fetch((done - 1) & 1);
     horizontal(yb + done - 1);
-    wave_order();                                            // the next item's first write must stay behind these reads
+    wave_lds_sync();                                            // the next item's first write must stay behind these reads
 }
 
 template <int N, int NT>

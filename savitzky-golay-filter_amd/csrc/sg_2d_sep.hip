@@ -25,27 +25,10 @@
 #include <cstring>
 
 #include "sg_2d.hpp"
+#include "sg_pk.hpp"
 #include "sg_runtime.hpp"
 
 namespace sg {
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int SEL>
-__device__ __forceinline__ void pk_fma_v(f32x2 &acc, const f32x2 wpair, const f32x2 x)
-{
-    if constexpr (SEL == 0)
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(wpair), "v"(x));
-    else
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(wpair), "v"(x));
-}
-
-__device__ __forceinline__ f32x2 pk_join(const f32x2 a, const f32x2 b)       // (a.y, b.x)
-{
-    f32x2 o;
-    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
 
 // acc[r] += sum_k w[k] * x[r + k], r < R, k <= 2N, over a window of R + 2N inputs delivered as float4 quads.
 // Input stationary, packed: pair j of accumulators takes  w[k] * (x[i], x[i+1])  with i = 2j + k.
@@ -57,7 +40,7 @@ struct WinConv {
     {
         if constexpr (J < R / 2) {
             constexpr int k = I - 2 * J;
-            if constexpr (k >= 0 && k <= 2 * N) pk_fma_v<(k & 1)>(A[J], W[k >> 1], x);
+            if constexpr (k >= 0 && k <= 2 * N) pk_fma_vgpr<(k & 1)>(A[J], W[k >> 1], x);
             feed<I, J + 1>(A, W, x);
         }
     }
@@ -67,9 +50,9 @@ struct WinConv {
         if constexpr (Q < NQ) {
             const float4 v = load(Q);
             const f32x2 e0 = {v.x, v.y}, e1 = {v.z, v.w};
-            if constexpr (Q > 0) feed<4 * Q - 1>(A, W, pk_join(prev, e0));
+            if constexpr (Q > 0) feed<4 * Q - 1>(A, W, pk_straddle(prev, e0));
             feed<4 * Q>(A, W, e0);
-            feed<4 * Q + 1>(A, W, pk_join(e0, e1));
+            feed<4 * Q + 1>(A, W, pk_straddle(e0, e1));
             feed<4 * Q + 2>(A, W, e1);
             quads<Q + 1>(load, A, W, e1);
         }

@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "sg_k1d_host.hpp"
+#include "sg_pk.hpp"
 
 namespace sg {
 
@@ -58,7 +59,6 @@ __device__ __forceinline__ double fma_t(double a, double b, double c) { return _
 #ifndef SG_NT
 #define SG_NT 1
 #endif
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));      // the builtins want a native vector type
 template <typename VT> __device__ __forceinline__ VT ld_stream(const VT *p)
 {
     static_assert(sizeof(VT) == 16, "16-byte vectors only");
@@ -77,14 +77,6 @@ template <typename VT> __device__ __forceinline__ void st_stream(VT *p, const VT
 #else
     *p = v;
 #endif
-}
-
-// lanes of one wave exchanging data through LDS: order the compiler's memory ops, nothing else
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // index remap of the padded boundary modes (reference get_padded_sample, savgolFilter.c:452-476)
@@ -166,27 +158,7 @@ struct Conv {                      // generic form (used for fp64): one v_fma pe
 // inputs as pairs (x[i], x[i+1]), and one instruction does  pair_j += w[k] * (x[i], x[i+1])  with
 // i = 2j + k + OFF.  The tap is broadcast out of an aligned SGPR pair with op_sel, so the 65 taps still
 // occupy 66 SGPRs; pairs that start at an odd i are assembled with one v_pk_mov_b32 each and then
-// shared by up to 16 accumulator pairs.  Written as inline asm because the compiler's own packing of
-// this loop builds (w[k], w[k-1]) SGPR pairs instead and spills hundreds of SGPRs.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int SEL>
-__device__ __forceinline__ void pk_fma_bcast(f32x2 &acc, const f32x2 wpair, const f32x2 x)
-{
-    if constexpr (SEL == 0)
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
-    else
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
-}
-
-// (a.y, b.x): the input pair that straddles two aligned pairs
-__device__ __forceinline__ f32x2 pk_straddle(const f32x2 a, const f32x2 b)
-{
-    f32x2 o;
-    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
-
+// shared by up to 16 accumulator pairs (sg_pk.hpp has the instructions).
 template <int N>
 struct Conv<float, N> {
     typedef K1D<float, N> K;
@@ -196,7 +168,7 @@ struct Conv<float, N> {
     {
         if constexpr (J < K::R / 2) {
             constexpr int k = I - 2 * J - K::OFF;
-            if constexpr (k >= 0 && k <= 2 * N) pk_fma_bcast<(k & 1)>(A[J], W[k >> 1], x);
+            if constexpr (k >= 0 && k <= 2 * N) pk_fma_sgpr<(k & 1)>(A[J], W[k >> 1], x);
             feed<I, J + 1>(A, W, x);
         }
     }

@@ -23,6 +23,7 @@
 #include <mutex>
 
 #include "sg_internal.h"
+#include "sg_pk.hpp"
 #include "sg_runtime.hpp"
 #include "sg_stream.hpp"
 
@@ -113,16 +114,12 @@ constexpr int BLOCK_TT = 64;         // ticks per block of the time-tiled push (
 
 struct alignas(8) StreamTaps { float w[SAVGOL_MAX_WINDOW + 1]; };     // by-value kernarg -> 33 aligned SGPR pairs
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 // acc += w * x for two ticks at once, multiply and add rounded SEPARATELY (v_pk_mul_f32 then v_pk_add_f32: the same
 // two roundings per lane as the reference's `sum += w * x`); the tap is broadcast out of an aligned SGPR pair.
 template <int SEL>
 __device__ __forceinline__ void pk_mul_add(f32x2 &acc, const f32x2 wpair, const f32x2 x)
 {
-    f32x2 p;
-    if constexpr (SEL == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(wpair), "v"(x));
-    else                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(p) : "s"(wpair), "v"(x));
+    const f32x2 p = pk_mul_sgpr<SEL>(wpair, x);
     asm("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
 }
 

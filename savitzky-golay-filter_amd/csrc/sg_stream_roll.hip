@@ -15,12 +15,11 @@
 #include <utility>
 
 #include "sg_internal.h"
+#include "sg_pk.hpp"
 #include "sg_runtime.hpp"
 #include "sg_stream.hpp"
 
 namespace sg {
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int N>
 struct SRoll {
@@ -32,22 +31,6 @@ struct SRoll {
 
 template <int N>
 struct SRollTaps { f32x2 w[SRoll<N>::NP]; };
-
-// w[SEL] * x, the tap broadcast out of an aligned SGPR pair
-template <int SEL>
-__device__ __forceinline__ f32x2 pk_mul_tap(const f32x2 w, const f32x2 x)
-{
-    f32x2 p;
-    if constexpr (SEL == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(w), "v"(x));
-    else                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(p) : "s"(w), "v"(x));
-    return p;
-}
-
-template <int... I, typename F>
-__device__ __forceinline__ bool static_for_s(std::integer_sequence<int, I...>, F &&f)
-{
-    return (f(std::integral_constant<int, I>{}) && ...);
-}
 
 struct BankJob {
     const float *ring;               // [WS][streams], slot (wp0 - k) mod WS = sample -k of the history
@@ -83,7 +66,7 @@ __device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTa
     for (int r = 0; r < R::U - 1; ++r) win[r] = load_row(r);
 
     for (int base = 0; base < nt; base += R::U) {
-        static_for_s(std::make_integer_sequence<int, R::U>{}, [&](auto uc) -> bool {
+        static_for(std::make_integer_sequence<int, R::U>{}, [&](auto uc) -> bool {
             constexpr int u = decltype(uc)::value;
             const int m = base + u;
             if (m >= nt) return false;                                           // uniform
@@ -91,11 +74,11 @@ __device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTa
             // sum = 0; sum += w[k] * x[k], k ascending, separate roundings.  The product of tap k+1 is issued before
             // the add of tap k so that no instruction consumes the result of the one just before it.
             f32x2 acc = f32x2{0.0f, 0.0f};
-            f32x2 p = pk_mul_tap<0>(taps.w[0], win[u % R::U]);
-            static_for_s(std::make_integer_sequence<int, R::WS>{}, [&](auto kc) -> bool {
+            f32x2 p = pk_mul_sgpr<0>(taps.w[0], win[u % R::U]);
+            static_for(std::make_integer_sequence<int, R::WS>{}, [&](auto kc) -> bool {
                 constexpr int k = decltype(kc)::value;
                 f32x2 pn = p;
-                if constexpr (k + 1 < R::WS) pn = pk_mul_tap<((k + 1) & 1)>(taps.w[(k + 1) >> 1], win[(u + k + 1) % R::U]);
+                if constexpr (k + 1 < R::WS) pn = pk_mul_sgpr<((k + 1) & 1)>(taps.w[(k + 1) >> 1], win[(u + k + 1) % R::U]);
                 acc = acc + p;
                 p = pn;
                 return true;
