@@ -45,12 +45,11 @@ __device__ __forceinline__ f32x2 pk_mul_sgpr(const f32x2 wpair, const f32x2 x)
     else                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(p) : "s"(wpair), "v"(x));
     return p;
 }
-// (a.y, b.x): the pair that straddles two aligned pairs
+// (a.y, b.x): the pair that straddles two aligned pairs -- one v_pk_mov_b32, left to the compiler (a shuffle it
+// knows has no forwarding hazard, and a counted wait state between the asm instructions around it)
 __device__ __forceinline__ f32x2 pk_straddle(const f32x2 a, const f32x2 b)
 {
-    f32x2 o;
-    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(o) : "v"(a), "v"(b));
-    return o;
+    return __builtin_shufflevector(a, b, 1, 2);
 }
 
 // lanes of one wave exchanging data through LDS: order the compiler's memory operations, nothing else (LDS
