@@ -122,3 +122,38 @@ def test_batch_call_is_graph_capturable(sg, sgo, torch_gpu):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, want)
+
+
+def test_2d_batch_and_derivative_calls_are_graph_capturable(sg, torch_gpu):
+    """Same promise for the 2-D device entry points (rolling-window kernel, fused tile kernel, dense kernel)."""
+    torch = torch_gpu
+    images, rows, cols = 3, 200, 520
+    x = torch.randn((images, rows, cols), device="cuda")
+    outs = [torch.zeros_like(x) for _ in range(7)]
+    f = sg.Filter2D(7, 7, 3)
+    L = sg.lib()
+    pitch = rows * cols
+
+    def enqueue(stream):
+        h = stream.cuda_stream if stream is not None else None
+        f.apply_batch(x, outs[0], rows, cols, images, boundary=1, method=2, stream=stream)
+        f.apply_batch(x, outs[1], rows, cols, images, boundary=2, method=1, stream=stream)
+        assert L.savgol2d_gradient_batch_f32(7, 7, 3, x.data_ptr(), rows, cols, cols, pitch, outs[2].data_ptr(), outs[3].data_ptr(),
+                                             cols, pitch, images, 1.0, 1.0, 1, h) == 0
+        assert L.savgol2d_hessian_batch_f32(7, 7, 3, x.data_ptr(), rows, cols, cols, pitch, outs[4].data_ptr(), outs[5].data_ptr(),
+                                            outs[6].data_ptr(), cols, pitch, images, 1.0, 1.0, 1, h) == 0
+
+    enqueue(None)                                              # warm-up: uploads weight / factor tables
+    torch.cuda.synchronize()
+    want = [o.clone() for o in outs]
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            enqueue(s)
+    for o in outs:
+        o.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for o, w in zip(outs, want):
+        assert torch.equal(o, w)
