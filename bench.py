@@ -55,9 +55,32 @@ def cpu_baseline(length, deriv=D, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s:
             break
-    return {"value": round(n_done * length / el / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
-            "sample": f"{n_done} channels x {length} fp32 samples (the reference is fp32 only; n={N}, m={M}, d={deriv}, POLYNOMIAL), "
-                      f"savgol_apply back to back for {el:.1f} s, 1 thread"}
+    out = {"value": round(n_done * length / el / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
+           "sample": f"{n_done} channels x {length} fp32 samples (the reference is fp32 only; n={N}, m={M}, d={deriv}, POLYNOMIAL), "
+                     f"savgol_apply back to back for {el:.1f} s, 1 thread"}
+    # the same call from one thread per host core, each on its own channel (the reference has no threading
+    # of its own; savgol_apply is re-entrant on a shared const filter and ctypes drops the GIL around it)
+    if kind == "reference":
+        import threading
+        cores = os.cpu_count() or 1
+        bufs = [(x.copy(), np.empty_like(x)) for _ in range(cores)]
+        counts, stop = [0] * cores, time.perf_counter() + budget_s / 2
+
+        def worker(i):
+            xi, yi = bufs[i]
+            while time.perf_counter() < stop:
+                L.savgol_apply(f, mg.fptr(xi), mg.fptr(yi), length)
+                counts[i] += 1
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        el2 = time.perf_counter() - t0
+        out["all_cores"] = {"cores": cores, "value": round(sum(counts) * length / el2 / 1e6, 2), "unit": "Msamples/s",
+                            "sample": f"{sum(counts)} channels in {el2:.1f} s, one thread per host core"}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
