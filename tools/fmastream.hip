@@ -81,12 +81,14 @@ void run(const f4 *in, f4 *out, size_t nvec)
            2.0 * nvec * 16 / ms / 1e6, 2.0 * nvec * 16 / ms / 1e6 / 80.0);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool zeros = argc > 1 && argv[1][0] == 'z';          // all-zero input: how much of the time is data-dependent power?
     const size_t nvec = (size_t)4096 * (1 << 20) / 4;       // 16 GiB of fp32
     f4 *in, *out;
     CK(hipMalloc(&in, nvec * 16)); CK(hipMalloc(&out, nvec * 16));
-    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, reinterpret_cast<float *>(in), nvec * 4);
+    if (zeros) CK(hipMemset(in, 0, nvec * 16));
+    else hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, reinterpret_cast<float *>(in), nvec * 4);
     CK(hipDeviceSynchronize());
     run<0, 0>(in, out, nvec);
     run<32, 0>(in, out, nvec);
