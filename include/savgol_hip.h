@@ -50,7 +50,9 @@ int         savgol_hip_set_option(int option, int value);
  * d_in and d_out must not overlap.  length >= 2n+1.
  * f32: fp32 tables, fp32 FMA accumulation (within 1e-6 normwise of the fp64 oracle).
  * f64: the same fp32 tables promoted exactly to double, double accumulation, the reference's
- *      float 1/dt_scale promoted -- there is no fp64 path in the reference.   */
+ *      float 1/dt_scale promoted -- there is no fp64 path in the reference.
+ *      The centre taps must be (anti)symmetric bit for bit, as savgol_create builds them
+ *      (tap[k] == +-tap[2n-k]); a hand-edited table that is not returns -1.                   */
 int savgol_apply_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out,
                            size_t channels, size_t length, size_t in_ld, size_t out_ld,
                            void *stream);

@@ -123,7 +123,24 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
 
     sg::Taps taps;
     memset(&taps, 0, sizeof(taps));
-    memcpy(taps.w, f->center_weights, sizeof(float) * ws);
+    if (sizeof(T) == 8) {
+        // The fp64 kernel keeps taps 0..n as doubles in SGPRs and takes tap 2n-k = +-tap k from them.  Tables built by
+        // savgol_create are (anti)symmetric bit for bit (only Gram terms of the derivative's parity are non-zero at
+        // t = 0); a hand-edited table that is not cannot run on this path.
+        const bool odd = (f->config.derivative & 1) != 0;
+        for (int k = 0; k <= n; ++k) {
+            const float a = f->center_weights[k], b = f->center_weights[2 * n - k];
+            if (!(odd ? (a == -b) : (a == b))) {
+                sg_set_error("%s: fp64 path needs the centre taps savgol_create builds (tap[k] == %stap[2n-k]); tap %d is not", who,
+                             odd ? "-" : "", k);
+                return -1;
+            }
+            taps.wd[k] = (double)a;
+        }
+        if (odd) job.flags |= sg::JOB_ODD_TAPS;
+    } else {
+        memcpy(taps.w, f->center_weights, sizeof(float) * ws);
+    }
 
     const float *d_edges = nullptr;
     if (poly && variant != VALID) {

@@ -113,7 +113,7 @@ struct K1D {
     static constexpr int SLAB = 16 * (SV + (SV + VPL - 1) / VPL);   // bytes: one pad vector after every VPL
     static constexpr int WAVES = 4;                          // waves per block, each with its own slab
     // waves per SIMD the register allocation must allow (the LDS slabs allow as many blocks per CU)
-    static constexpr int MIN_WAVES = sizeof(T) == 8 ? 3 : (VPL <= 4 ? 7 : VPL <= 6 ? 5 : 4);
+    static constexpr int MIN_WAVES = VPL <= 4 ? 7 : VPL <= 6 ? 5 : 4;
     static_assert(2 * HV <= 64, "halo must fit one extra vector per lane");
     static_assert(WQ <= SV - VPL * 63, "lane 63's window must stay inside the slab");
     static_assert(VPL == 4 || VPL == 6 || VPL == 8, "lane stride (VPL+1)*16 B must be conflict free for ds_read_b128");
@@ -201,49 +201,42 @@ struct Conv<float, N> {
     }
 };
 
-// fp64: the taps stay fp32 in SGPRs (65 doubles would not fit the scalar file) and are promoted -- exactly
-// -- with one v_cvt_f64_f32 each at the step where they are first needed.  In input-stationary order step I
-// uses taps I-OFF-r, r = 0..15: a sliding window of 16 taps, kept in 16 register pairs and recycled, so the
-// loop carries 16 accumulators + 16 promoted taps instead of 65 promoted taps (which spilled).  The cvt is
-// an asm that also names the current input, which pins it to its step.
+// fp64: 65 doubles do not fit the scalar register file, but the centre taps savgol_create builds are (anti)symmetric
+// bit for bit (tap[2N-k] = +-tap[k]: only Gram terms of the derivative's parity are non-zero at t = 0), so the host
+// passes taps 0..N as doubles (33 SGPR pairs at N = 32, exact promotions of the fp32 table) and the kernel applies the
+// mirrored half through the sign of the input.  No conversion and no tap in a VGPR inside the loop.
 template <int N>
 struct Conv<double, N> {
     typedef K1D<double, N> K;
+    // taps 0..N as doubles in SGPR pairs (33 x 2 SGPRs at N = 32); tap 2N-k = +-tap k is applied by flipping the
+    // sign of the input instead (xs = +-x, one v_xor_b32 per input), so v_fmac_f64 takes the tap straight from SGPRs
     template <int I, int Rr = 0>
-    static __device__ __forceinline__ void feed(double (&acc)[K::R], const double (&wd)[16], const double x)
+    static __device__ __forceinline__ void feed(double (&acc)[K::R], const Taps &taps, const double x, const double xs)
     {
         if constexpr (Rr < K::R) {
             constexpr int k = I - Rr - K::OFF;
-            if constexpr (k >= 0 && k <= 2 * N) acc[Rr] = __builtin_fma(wd[k & 15], x, acc[Rr]);
-            feed<I, Rr + 1>(acc, wd, x);
+            if constexpr (k >= 0 && k <= N) acc[Rr] = __builtin_fma(taps.wd[k], x, acc[Rr]);
+            else if constexpr (k > N && k <= 2 * N) acc[Rr] = __builtin_fma(taps.wd[2 * N - k], xs, acc[Rr]);
+            feed<I, Rr + 1>(acc, taps, x, xs);
         }
     }
-    template <int I>
-    static __device__ __forceinline__ void step(double (&acc)[K::R], double (&wd)[16], const Taps &taps, const double x)
-    {
-        constexpr int knew = I - K::OFF;
-        if constexpr (knew >= 0 && knew <= 2 * N)
-            asm("v_cvt_f64_f32 %0, %1" : "=v"(wd[knew & 15]) : "s"(taps.w[knew]), "v"(x));
-        feed<I>(acc, wd, x);
-    }
     template <int Q>
-    static __device__ __forceinline__ void vecs(const char *win, double (&acc)[K::R], double (&wd)[16], const Taps &taps)
+    static __device__ __forceinline__ void vecs(const char *win, double (&acc)[K::R], const Taps &taps, const unsigned flip)
     {
         if constexpr (Q < K::WQ) {
             const double2 v = *reinterpret_cast<const double2 *>(win + slab_vec_off<K::VPL>(Q));
-            step<2 * Q>(acc, wd, taps, v.x);
-            step<2 * Q + 1>(acc, wd, taps, v.y);
-            vecs<Q + 1>(win, acc, wd, taps);
+            const double sx = __hiloint2double(__double2hiint(v.x) ^ (int)flip, __double2loint(v.x));
+            const double sy = __hiloint2double(__double2hiint(v.y) ^ (int)flip, __double2loint(v.y));
+            feed<2 * Q>(acc, taps, v.x, sx);
+            feed<2 * Q + 1>(acc, taps, v.y, sy);
+            vecs<Q + 1>(win, acc, taps, flip);
         }
     }
-    static __device__ __forceinline__ void run(const char *win, const Taps &taps, double (&acc)[K::R])
+    static __device__ __forceinline__ void run(const char *win, const Taps &taps, double (&acc)[K::R], unsigned flip)
     {
-        double wd[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) wd[j] = 0.0;
 #pragma unroll
         for (int r = 0; r < K::R; ++r) acc[r] = 0.0;
-        vecs<0>(win, acc, wd, taps);
+        vecs<0>(win, acc, taps, flip);
     }
 };
 
@@ -357,7 +350,8 @@ __global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kerne
 
         // ---- the convolution: lane owns outputs [lane*R, lane*R + R) of the tile ----
         T acc[R];
-        Conv<T, N>::run(slab + 16 * (lane * (VPL + 1)), taps, acc);
+        if constexpr (sizeof(T) == 8) Conv<T, N>::run(slab + 16 * (lane * (VPL + 1)), taps, acc, (job.flags & JOB_ODD_TAPS) ? 0x80000000u : 0u);
+        else Conv<T, N>::run(slab + 16 * (lane * (VPL + 1)), taps, acc);
         if (job.flags & JOB_SCALE) {
             const T s = (T)job.dt_inv;
 #pragma unroll

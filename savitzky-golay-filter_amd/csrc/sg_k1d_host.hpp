@@ -10,7 +10,7 @@ namespace sg {
 
 // by-value kernarg -> s_load -> SGPRs.  66 floats = 33 aligned pairs: the fp32 kernel feeds whole
 // SGPR pairs to v_pk_fma_f32 and picks the tap with op_sel.
-struct alignas(8) Taps { float w[SAVGOL_MAX_WINDOW + 1]; };
+struct alignas(8) Taps { union { float w[SAVGOL_MAX_WINDOW + 1]; double wd[(SAVGOL_MAX_WINDOW + 1) / 2]; }; };
 
 // 16-byte vectors of output each lane owns (tile = 64 lanes x VPL vectors of one channel).  Host and kernels must
 // agree.  The kernel supports 4, 6 and 8 (lane strides of 20 / 28 / 36 banks are all conflict free); 8 -> 8 KiB
@@ -39,6 +39,7 @@ enum : unsigned {
     JOB_SCALE      = 1u << 8,           // multiply by dt_inv (dt_inv != 1)
     JOB_VEC_IN     = 1u << 9,           // input rows are 16-B aligned
     JOB_VEC_OUT    = 1u << 10,          // output rows (after out_shift) are 16-B aligned
+    JOB_ODD_TAPS   = 1u << 11,          // fp64: taps.wd holds taps 0..n, tap 2n-k = -tap k (odd derivative) instead of +tap k
 };
 
 }  // namespace sg

@@ -319,3 +319,30 @@ def test_nan_and_inf_propagate_like_the_reference(sg, sgo, torch_gpu, dtype):
         assert np.array_equal(np.isposinf(y), np.isposinf(ref)) and np.array_equal(np.isneginf(y), np.isneginf(ref)), mode
         ok = np.isfinite(ref)
         assert normwise(y[ok], ref[ok]) < (1e-6 if dtype == "f32" else 1e-12)
+
+
+def test_f64_rejects_hand_edited_asymmetric_centre_taps(sg, sgo, torch_gpu):
+    """The fp64 kernel reads taps 0..n and mirrors the rest (savgol_hip.h): every table savgol_create builds is
+    (anti)symmetric bit for bit, a hand-edited one that is not must be refused, not silently mirrored.  The fp32
+    path takes all 2n+1 taps as they are."""
+    torch = torch_gpu
+    n, length = 8, 4096
+    x32 = torch.randn((2, length), dtype=torch.float32, device="cuda")
+    f = sg.Filter(n, 3, 0, 1.0, 0)
+    w = f.ptr.contents.center_weights
+    assert all(w[k] == w[2 * n - k] for k in range(n))           # as built: symmetric bit for bit
+    f.apply_tensor(x32.double())                                 # fine
+    w[2 * n] = w[2 * n] * 1.5                                    # now tap[0] != tap[2n]
+    with pytest.raises(RuntimeError, match="centre taps"):
+        f.apply_tensor(x32.double())
+    y = f.apply_tensor(x32, valid=True).cpu().numpy()            # fp32: uses the edited table as it is
+    taps = np.array(w[:2 * n + 1], np.float64)
+    xh = x32.cpu().numpy().astype(np.float64)
+    want = np.stack([np.convolve(xh[c], taps[::-1], mode="valid") for c in range(2)])
+    assert normwise(y, want) < 1e-6
+    fo = sg.Filter(n, 3, 1, 0.5, 0)                              # odd derivative: antisymmetric, centre tap 0
+    wo = fo.ptr.contents.center_weights
+    assert all(wo[k] == -wo[2 * n - k] for k in range(n + 1))
+    ref = sgo.Filter(n, 3, 1, 0.5, 0).apply_f64(xh[0])
+    got = fo.apply_tensor(x32.double())[0].cpu().numpy()
+    assert normwise(got, ref) < 1e-12

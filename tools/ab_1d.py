@@ -15,6 +15,8 @@ ap.add_argument("--m", type=int, default=4)
 ap.add_argument("--channels", type=int, default=4096)
 ap.add_argument("--length", type=int, default=1 << 20)
 ap.add_argument("--rounds", type=int, default=12)
+ap.add_argument("--f64", action="store_true", help="savgol_apply_batch_f64 on float64 data")
+ap.add_argument("--deriv", type=int, default=0)
 a = ap.parse_args()
 
 
@@ -22,7 +24,7 @@ class Cfg(C.Structure):
     _fields_ = [("half_window", C.c_uint8), ("poly_order", C.c_uint8), ("derivative", C.c_uint8), ("time_step", C.c_float), ("boundary", C.c_int)]
 
 
-x = torch.randn((a.channels, a.length), dtype=torch.float32, device="cuda")
+x = torch.randn((a.channels, a.length), dtype=torch.float64 if a.f64 else torch.float32, device="cuda")
 y = torch.empty_like(x)
 st = torch.cuda.current_stream().cuda_stream
 libs = []
@@ -30,10 +32,11 @@ for path in a.libs:
     L = C.CDLL(path)
     L.savgol_create.restype = C.c_void_p
     L.savgol_create.argtypes = [C.POINTER(Cfg)]
-    L.savgol_apply_batch_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_size_t] * 4 + [C.c_void_p]
-    cfg = Cfg(a.n, a.m, 0, 1.0, 1)
+    fn = L.savgol_apply_batch_f64 if a.f64 else L.savgol_apply_batch_f32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_size_t] * 4 + [C.c_void_p]
+    cfg = Cfg(a.n, a.m, a.deriv, 1.0, 1)
     f = L.savgol_create(C.byref(cfg))
-    run = lambda L=L, f=f: L.savgol_apply_batch_f32(f, x.data_ptr(), y.data_ptr(), a.channels, a.length, a.length, a.length, st)
+    run = lambda fn=fn, f=f: fn(f, x.data_ptr(), y.data_ptr(), a.channels, a.length, a.length, a.length, st)
     assert run() == 0
     libs.append((path, run, []))
 torch.cuda.synchronize()
