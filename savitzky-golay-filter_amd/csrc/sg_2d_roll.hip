@@ -75,9 +75,9 @@ __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
 // strips at the left / right frame edge, odd strides).
 // Row r of the band's input (frame row yb-N+r, remapped at the frame border) lives in ring slot r % U.  Output row m
 // needs rows m .. m+2N; while it is computed, row m+2N+P is already being loaded into the slot row m-1 left.
-// The two passes are skewed by one row: iteration m first issues the LDS reads of row m-1's horizontal window
-// (written one iteration earlier), runs the vertical pass of row m while they are in flight, writes its results to
-// the other LDS row, then does row m-1's horizontal arithmetic and store -- no pass waits for its own LDS round trip.
+// The two passes are skewed by one row: iteration m runs the vertical pass of row m and writes its results to one LDS
+// row, then reads row m-1's horizontal window from the other LDS row (written one iteration earlier, so the data
+// is there when the reads issue) and does row m-1's horizontal arithmetic and store.
 template <int N, int NT, bool VEC>
 __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT> &taps, float *mine, const float *in, float *out,
                                           int sx, int yb, int nout, int lane, int xlo, int xhi, int ylo, int yhi)
@@ -198,8 +198,7 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     };
 
 #pragma unroll
-    for (int r = 0; r < R::U - 1; ++r) win[r] = load_row(r);
-    win[R::U - 1] = load_row(R::U - 1);
+    for (int r = 0; r < R::U; ++r) win[r] = load_row(r);         // rows 0..2N for the first output row, P more in flight
     vertical(std::integral_constant<int, 0>{}, 0);
     int done = 1;                                            // rows whose vertical pass has run
     for (int base = 1; base < nout; base += R::U) {
@@ -209,7 +208,7 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             if (m >= nout) return false;                     // uniform
             win[uu] = load_row(m + R::U - 1);                // slot of row m-1, which no later row needs
             vertical(std::integral_constant<int, (uu + 1) % R::U>{}, (uu + 1) & 1);
-            wave_lds_sync();                                    // row m-1's LDS row was written one iteration ago
+            wave_lds_sync();                                 // orders this row's LDS writes and the reads below for the compiler
             fetch(uu & 1);
             horizontal(yb + m - 1);
             done = m + 1;
@@ -219,7 +218,7 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     wave_lds_sync();
     fetch((done - 1) & 1);
     horizontal(yb + done - 1);
-    wave_lds_sync();                                            // the next item's first write must stay behind these reads
+    wave_lds_sync();                                         // the next item's first write must stay behind these reads
 }
 
 template <int N, int NT>
