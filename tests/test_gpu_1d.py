@@ -346,3 +346,37 @@ def test_f64_rejects_hand_edited_asymmetric_centre_taps(sg, sgo, torch_gpu):
     ref = sgo.Filter(n, 3, 1, 0.5, 0).apply_f64(xh[0])
     got = fo.apply_tensor(x32.double())[0].cpu().numpy()
     assert normwise(got, ref) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_randomized_configurations_within_the_dot_product_error_bound(sg, sgo, torch_gpu, dtype):
+    """80 random (n, m, d, dt, mode, length, pitch) draws, orders up to 10 and derivatives up to 4 where a fixed
+    normwise tolerance would be meaningless (the weights grow large and cancel): every output must be within the
+    forward error bound of a (2n+1)-term dot product, (2n+2) eps sum|w| max|x| / dt^d, of the double oracle."""
+    torch = torch_gpu
+    rng = np.random.default_rng(20261002 if dtype == "f32" else 20261003)
+    tdt, ndt, eps = (torch.float32, np.float32, 2.0 ** -24) if dtype == "f32" else (torch.float64, np.float64, 2.0 ** -53)
+    for _ in range(80):
+        n = int(rng.integers(1, 33))
+        m = int(rng.integers(0, min(2 * n, 10) + 1))
+        d = int(rng.integers(0, min(m, 4) + 1))
+        dt = float(rng.choice([1.0, 0.5, 2.0, 1e-2]))
+        mode = int(rng.integers(0, 4))
+        length = int(rng.integers(2 * n + 1, 7000))
+        ch = int(rng.integers(1, 4))
+        ld_in, ld_out = length + int(rng.integers(0, 5)), length + int(rng.integers(0, 5))
+        xh = signal(rng, (ch, length)).astype(ndt)
+        xin = torch.zeros((ch, ld_in), dtype=tdt, device="cuda")
+        xin[:, :length] = torch.from_numpy(xh).cuda()
+        out = torch.full((ch, ld_out), -7.0, dtype=tdt, device="cuda")
+        f = sg.Filter(n, m, d, dt, mode)
+        f.apply_batch(xin, out, ch, length, ld_in, ld_out, dtype=dtype)
+        torch.cuda.synchronize()
+        o = sgo.Filter(n, m, d, dt, mode)
+        ref = o.apply_f64(xh.astype(np.float64))
+        rows = np.vstack([f.center_weights[None, :], f.edge_weights]).astype(np.float64)
+        bound = (2 * n + 2) * eps * np.abs(rows).sum(axis=1).max() * np.abs(xh).max() / (np.float32(dt) ** d)
+        got = out.cpu().numpy()
+        err = np.abs(got[:, :length] - ref).max()
+        assert err <= bound, (n, m, d, dt, mode, length, err, bound)
+        assert np.all(got[:, length:] == -7.0)
