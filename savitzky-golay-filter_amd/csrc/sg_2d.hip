@@ -104,6 +104,13 @@ static int sep_factors_cached(const Savgol2DConfig *cfg, float *factors)
     return e.terms;
 }
 
+// SAVGOL_HIP_DENSE_KERNEL=1 forces the one-pixel-per-lane dense kernel (diagnostics / A-B timing)
+static int dense_kernel_env()
+{
+    static const int v = [] { const char *e = getenv("SAVGOL_HIP_DENSE_KERNEL"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_in, int rows, int cols, int in_stride,
                       long long in_pitch, float *d_out, int out_stride, long long out_pitch, size_t images, int boundary,
                       int method, hipStream_t st)
@@ -167,6 +174,11 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
         const size_t ni = images - i0 < 65535 ? images - i0 : 65535;
         job.in = d_in + (long long)i0 * in_pitch;
         job.out = d_out + (long long)i0 * out_pitch;
+        if (dense_kernel_env() != 1) {
+            const int rc = sg2d_launch_dense_rolling(job, f->weights, ctx, (unsigned)ni, st);
+            if (rc < 0) return -1;
+            if (rc == 0) continue;
+        }
         hipLaunchKernelGGL(sg2d_direct_kernel, dim3((unsigned)(job.tiles_x * job.tiles_y), (unsigned)ni), dim3(256), lds, st, job, d_w);
     }
     return hip_ok(hipGetLastError(), who) ? 0 : -1;

@@ -54,6 +54,12 @@ inline int sg2d_launch_rolling(int n, int terms, const Job2D &job, const float *
     return sg2d_launch_rolling_g2(n, terms, job, factors, scale, images, cu_count, st);
 }
 
+// sg_2d_dense.hip: the bit-exact dense kernel on packed math, square windows with half window <= DENSE_ROLL_MAX_N.
+// 0 = launched, 1 = not covered (the caller uses sg2d_direct_kernel of sg_2d.hip), -1 = error.  h_w = the kernel on the host.
+constexpr int DENSE_ROLL_MAX_N = 8;
+struct DeviceCtx;
+int sg2d_launch_dense_rolling(const Job2D &job, const float *h_w, DeviceCtx *ctx, unsigned images, hipStream_t st);
+
 // sg_2d_sep.hip
 int sg2d_kernel_double(const Savgol2DConfig *cfg, double *Wd);                           // W in double, [2n+1][2n+1]; 0 on success
 int sg2d_factors_from_kernel(const double *Wd, int n, int order, float *factors, int max_terms);   // #terms, 0 = failed
