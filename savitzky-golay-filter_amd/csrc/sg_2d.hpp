@@ -40,6 +40,27 @@ struct SepPlan {
     float *out[SEP_MAX_OUTPUTS];        // same row stride / image pitch for all
 };
 
+// Row bands of the strip kernels (sg_2d_roll.hip, sg_2d_dense.hip): an item = one strip x one band, `nwaves` resident
+// waves take items round robin.  Every band pays 2n warm-up rows (weighted `warm`: they cost full work in the dense
+// kernel, loads only in the separable one), and the last round of items may leave waves idle; pick the band count with
+// the smallest cost per wave.
+inline unsigned choose_bands(int rows, unsigned long long images_x_strips, unsigned nwaves, int n, double warm)
+{
+    unsigned best = 1;
+    double best_cost = 1e300;
+    for (unsigned b = 1; b <= 64u && (int)b <= rows; ++b) {
+        const int band_rows = (rows + (int)b - 1) / (int)b;
+        const unsigned real_b = (unsigned)((rows + band_rows - 1) / band_rows);
+        if (real_b != b) continue;
+        if (b > 1 && band_rows < 4 * n) break;
+        const unsigned long long items = images_x_strips * b;
+        const unsigned long long rounds = (items + nwaves - 1) / nwaves;
+        const double cost = (double)rounds * ((double)band_rows + warm * 2.0 * n);
+        if (cost < best_cost * 0.999) { best_cost = cost; best = b; }
+    }
+    return best;
+}
+
 // sg_2d_roll.hip: rolling-window kernel, single output, half windows 1..8.  The file is compiled once per
 // half-window group (SEP_ROLL_MIN_N..SEP_ROLL_MAX_N under the name SEP_ROLL_FN, see the Makefile) so the groups
 // build in parallel; each returns 0 = launched, 1 = not covered (other group, or the caller uses the tile kernel).

@@ -79,7 +79,8 @@ __device__ __forceinline__ void dense_item(const Job2D &job, const float *__rest
     float *const wr = mine + 4 * R::HL + 4 * lane;           // where this lane's 4 columns of the input row go
     const float *const rd = mine + 4 * lane;                 // where its window starts
 
-    // acc[wy][j]: output row (r - wy), column pair j, while input row r is being fed
+    // acc[wy][j]: output row (r - wy), column pair j, while input row r is being fed.  Slots that belong to rows above
+    // the band hold garbage until a real output row starts in slot 0; nothing of them is ever stored.
     f32x2 acc[R::WW][2];
 #pragma unroll
     for (int a = 0; a < R::WW; ++a) { acc[a][0] = f32x2{0.0f, 0.0f}; acc[a][1] = f32x2{0.0f, 0.0f}; }
@@ -122,10 +123,14 @@ __device__ __forceinline__ void dense_item(const Job2D &job, const float *__rest
 #pragma unroll
             for (int i = 0; i < R::WP / 2; ++i) dst[i] = wrow[i];
         };
-        load_taps(wcur, 0, pr[0]);
-#pragma unroll
-        for (int wy = 0; wy < R::WW; ++wy) {
-            if (wy + 1 < R::WW) load_taps(wnext, wy + 1, wy > 0 ? acc[wy - 1][1] : pr[1]);
+        // Output rows are independent, so W's rows are walked from the last one down: the final add of row wy can then
+        // write its sum straight into slot wy+1 (already drained), which is where the next input row expects it -- the
+        // accumulators shift without a single move.  Slot 0 starts each output with 0 + product, as the reference does.
+        f32x2 done0, done1;
+        load_taps(wcur, R::WW - 1, pr[0]);
+        static_for<R::WW>([&](auto wyc) -> bool {
+            constexpr int wy = R::WW - 1 - decltype(wyc)::value;
+            if constexpr (wy > 0) load_taps(wnext, wy - 1, wy + 1 < R::WW ? acc[wy + 1][1] : pr[1]);
             // the products of tap wx+1 are issued before the adds of tap wx (see sg_pk.hpp on asm results and s_nop)
             f32x2 p0 = pk_mul_here<0>(wcur[0], pr[0]), p1 = pk_mul_here<0>(wcur[0], pr[2]);
             static_for<R::WW>([&](auto wxc) -> bool {
@@ -135,19 +140,30 @@ __device__ __forceinline__ void dense_item(const Job2D &job, const float *__rest
                     n0 = pk_mul_here<((wx + 1) & 1)>(wcur[(wx + 1) >> 1], pr[wx + 1]);
                     n1 = pk_mul_here<((wx + 1) & 1)>(wcur[(wx + 1) >> 1], pr[wx + 3]);
                 }
-                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[wy][0]) : "v"(p0));
-                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[wy][1]) : "v"(p1));
+                if constexpr (wx + 1 == R::WW) {              // last tap of this W row: the sum moves on to the next slot
+                    f32x2 &d0 = wy + 1 < R::WW ? acc[wy + 1 < R::WW ? wy + 1 : 0][0] : done0;
+                    f32x2 &d1 = wy + 1 < R::WW ? acc[wy + 1 < R::WW ? wy + 1 : 0][1] : done1;
+                    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d0) : "v"(acc[wy][0]), "v"(p0));
+                    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d1) : "v"(acc[wy][1]), "v"(p1));
+                } else if constexpr (wy == 0 && wx == 0) {    // a new output row: sum = 0 + w * x
+                    asm volatile("v_pk_add_f32 %0, %1, 0 op_sel_hi:[1,0]" : "=v"(acc[0][0]) : "v"(p0));
+                    asm volatile("v_pk_add_f32 %0, %1, 0 op_sel_hi:[1,0]" : "=v"(acc[0][1]) : "v"(p1));
+                } else {
+                    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[wy][0]) : "v"(p0));
+                    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[wy][1]) : "v"(p1));
+                }
                 p0 = n0; p1 = n1;
                 return true;
             });
 #pragma unroll
             for (int i = 0; i < R::WP / 2; ++i) wcur[i] = wnext[i];
-        }
+            return true;
+        });
         // output row r-2N has seen its last input row
         const int yo = yb + r - 2 * N;
         if (r >= 2 * N && yo >= ylo && yo < yhi) {           // uniform
             const f32x2 s2 = f32x2{job.scale, job.scale};
-            const f32x2 o0 = acc[R::WW - 1][0] * s2, o1 = acc[R::WW - 1][1] * s2;
+            const f32x2 o0 = done0 * s2, o1 = done1 * s2;
             float *orow = out + (long long)yo * job.out_stride;
             if constexpr (VEC) {
                 if (out_lane)
@@ -159,10 +175,6 @@ __device__ __forceinline__ void dense_item(const Job2D &job, const float *__rest
                 if (c0 + 3 >= xlo && c0 + 3 < xhi) orow[c0 + 3] = o1.y;
             }
         }
-#pragma unroll
-        for (int a = R::WW - 1; a > 0; --a) { acc[a][0] = acc[a - 1][0]; acc[a][1] = acc[a - 1][1]; }
-        acc[0][0] = f32x2{0.0f, 0.0f};
-        acc[0][1] = f32x2{0.0f, 0.0f};
     }
     wave_lds_sync();                                         // the next item's first write must stay behind these reads
 }
@@ -212,12 +224,8 @@ static int launch_dense(const Job2D &job, const float *d_w, unsigned images, int
         per_cu = nb > 4 ? 4 : nb;
     }
     const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
-    // bands of about 256 rows (2N warm-up rows per band are fed but store nothing), thinner ones when the job is small
-    unsigned bands = (unsigned)((job.rows + 128) / 256);
-    if (bands < 1) bands = 1;
-    while ((unsigned long long)images * strips * bands < 4ull * nwaves && (unsigned)job.rows / bands > 16u * (unsigned)N) bands *= 2;
+    unsigned bands = choose_bands(job.rows, (unsigned long long)images * strips, nwaves, N, 1.0);   // warm-up rows are fed in full
     const int band_rows = (int)((job.rows + (int)bands - 1) / (int)bands);
-    bands = (unsigned)((job.rows + band_rows - 1) / band_rows);
     const unsigned long long total = (unsigned long long)images * strips * bands;     // caller keeps this < 2^32
     unsigned grid = (unsigned)cu_count * (unsigned)per_cu;
     if ((unsigned long long)grid * 4ull > total) grid = (unsigned)((total + 3) / 4);

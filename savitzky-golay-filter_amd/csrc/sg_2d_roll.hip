@@ -306,12 +306,8 @@ static int launch_roll(const Job2D &job, const float *factors, float scale, unsi
         per_cu = nb > 4 ? 4 : nb;
     }
     const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
-    // bands of about 256 rows (warm-up of 2N rows per band), more and thinner ones when the job is small
-    unsigned bands = (unsigned)((job.rows + 128) / 256);
-    if (bands < 1) bands = 1;
-    while ((unsigned long long)images * strips * bands < 4ull * nwaves && (unsigned)job.rows / bands > 8u * (unsigned)N) bands *= 2;
+    unsigned bands = choose_bands(job.rows, (unsigned long long)images * strips, nwaves, N, 0.3);   // warm-up rows are only loaded
     const int band_rows = (int)((job.rows + (int)bands - 1) / (int)bands);
-    bands = (unsigned)((job.rows + band_rows - 1) / band_rows);
     const unsigned long long total = (unsigned long long)images * strips * bands;     // caller keeps this < 2^32
     unsigned grid = (unsigned)cu_count * (unsigned)per_cu;
     if ((unsigned long long)grid * 4ull > total) grid = (unsigned)((total + 3) / 4);
