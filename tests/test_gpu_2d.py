@@ -152,6 +152,36 @@ def test_separable_method_vs_double_oracle(sg, sgo, torch_gpu, cfg):
 
 
 @pytest.mark.parametrize("n", range(1, 9))
+def test_dense_packed_kernel_bit_exact_every_half_window(sg, sgo, torch_gpu, n):
+    """Method 1 on square windows n <= 8 runs sg_2d_dense.hip (packed math, rolling accumulators): frames with interior
+    strips, both edge strips and several row bands, plus small / odd / misaligned ones, must equal the reference order
+    bit for bit (the oracle's restatement of savgol2d_apply, itself pinned to the compiled reference)."""
+    torch = torch_gpu
+    rng = np.random.default_rng(300 + n)
+    for (images, rows, cols, stride, off) in ((2, 150 + n, 617, 624, 0), (1, 2 * n + 3, 2 * n + 5, 2 * n + 6, 1), (1, 700, 40, 40, 0)):
+        flat = np.zeros(images * rows * stride + 4, np.float32)
+        x = flat[off:off + images * rows * stride].reshape(images, rows, stride)
+        x[:, :, :cols] = rng.normal(0, 1, (images, rows, cols)).astype(np.float32)
+        dflat = torch.from_numpy(flat).cuda()
+        d = dflat[off:off + images * rows * stride]
+        for order, dx, dy in ((2, 0, 0), (3, 1, 0), (4, 0, 2)):
+            if order > 2 * n:
+                continue
+            f = sg.Filter2D(n, n, order, dx, dy, 0.5, 2.0)
+            o = sgo.Filter2D(n, n, order, dx, dy, 0.5, 2.0)
+            for b in range(3):
+                out = torch.full((images * rows * stride + 4,), -5.0, device="cuda")
+                f.apply_batch(d, out[off:off + images * rows * stride], rows, cols, images, in_stride=stride, out_stride=stride,
+                              boundary=b, method=1)
+                got = out.cpu().numpy()
+                assert np.all(got[:off] == -5.0) and np.all(got[off + images * rows * stride:] == -5.0)
+                g = got[off:off + images * rows * stride].reshape(images, rows, stride)
+                for k in range(images):
+                    want = o.apply(x[k], cols, b, out=np.full((rows, stride), -5.0, np.float32))
+                    assert same_bits(g[k], want), (n, rows, cols, order, dx, dy, b, k)
+
+
+@pytest.mark.parametrize("n", range(1, 9))
 def test_rolling_window_kernel_all_half_windows(sg, sgo, torch_gpu, n):
     """The n <= 8 fast path (sg_2d_roll.hip): 16-byte aligned frames wide and tall enough for interior strips, several
     row bands and both frame-edge strips; every rank 1..4 (orders 2..6 x derivative pairs); all boundary modes.
