@@ -7,10 +7,13 @@
 
 namespace sg {
 
-constexpr int STREAM_ROLL_MAX_N = 16;   // largest half window of the rolling block-push kernel (its tick loop is unrolled 2n+4 times)
+constexpr int STREAM_ROLL_MAX_N = 32;   // the rolling block-push kernel covers every half window ...
+#ifndef STREAM_RING_MAX_N
+#define STREAM_RING_MAX_N 16             // ... sample ring (tick loop unrolled 2n+4 times) up to here, accumulator ring above
+#endif
 
 // sg_stream_roll.hip: `ticks` pushes of every stream in one launch, outputs only (the caller updates the ring).
-// 0 = launched, 1 = not covered (half window > STREAM_ROLL_MAX_N): use the LDS-tiled kernel of sg_stream.hip.
+// 0 = launched, 1 = not covered (ticks >= 2^31): use the LDS-tiled kernel of sg_stream.hip.
 int sg_bank_roll_launch(int n, const float *center_weights, const float *ring, const float *samples, float *out, size_t streams,
                         int wp0, unsigned long long received0, size_t ticks, float dt_inv, int cu_count, hipStream_t st);
 

@@ -1,12 +1,16 @@
-// sg_stream_roll.hip -- savgol_streambank_push_block for half windows <= 16: rolling time windows in registers.
+// sg_stream_roll.hip -- savgol_streambank_push_block: rolling time windows in registers.
 //
 // A block push is a convolution down the time axis of a [tick][stream] array (history = ring contents, then this
 // call's samples).  One WAVE owns 128 adjacent streams (a lane owns 2 = one 8-byte load per tick) and walks down a
-// band of ticks with the last 2n+1 samples of its streams in registers -- a ring of slots that the fully unrolled
-// tick loop indexes with literals.  No LDS, no __syncthreads, no halo re-reads except the 2n warm-up rows of a band.
-// Per output the arithmetic is the reference's (src/savgol_stream.c:166-185): one fp32 accumulator starting at 0,
-// taps in ascending order, multiply and add rounded separately (v_pk_mul_f32 + v_pk_add_f32: two streams per
-// instruction) -> bit-identical to savgol_stream_push for every stream.  Taps sit in SGPR pairs (by-value kernarg).
+// band of ticks.  No LDS, no __syncthreads, no re-reads except the 2n warm-up rows of a band.  Per output the
+// arithmetic is the reference's (src/savgol_stream.c:166-185): one fp32 accumulator starting at 0, taps in ascending
+// order, multiply and add rounded separately (v_pk_mul_f32 + v_pk_add_f32: two streams per instruction) ->
+// bit-identical to savgol_stream_push for every stream.  Taps sit in SGPR pairs (by-value kernarg).
+//   half windows <= 16: the last 2n+1 SAMPLES of the lane's streams live in a register ring that the fully unrolled
+//                       tick loop indexes with literals; each tick is one 2n+1-term chain (bank_roll_item);
+//   half windows 17-32: the unrolled ring would not fit the instruction cache, so the 2n in-flight ACCUMULATORS live
+//                       in registers instead and every arriving sample advances all of them by one tap
+//                       (bank_accroll_item; A/B at n <= 16: 15-30 % slower than the sample ring, so both stay).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -95,6 +99,60 @@ __device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTa
     }
 }
 
+// The same item, accumulator stationary (half windows above STREAM_RING_MAX_N, where the unrolled ring of the version
+// above would not fit the instruction cache): 2N accumulator pairs instead of 2N+1 samples live in registers.  Slot a
+// holds the output that has seen a samples so far; an arriving sample is tap a for slot a, and the add writes its sum
+// into slot a+1 (walked from the top down, so that slot is already drained): every output still adds its taps in
+// ascending order onto 0, with separate roundings -- and the tick loop is 2(2N+1) instructions, not unrolled.
+template <int N, bool VEC>
+__device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRollTaps<N> &taps, size_t s0, size_t t0, int nt)
+{
+    typedef SRoll<N> R;
+    const bool live0 = s0 < job.streams, live1 = s0 + 1 < job.streams;
+    auto load_row = [&](int r) -> f32x2 {
+        long long h = (long long)t0 - 2 * N + r;
+        if (h >= (long long)job.ticks) h = (long long)job.ticks - 1;            // past the call: loaded, never used
+        int slot = job.wp0 + (int)(h < 0 ? h : 0);
+        slot = slot < 0 ? slot + R::WS : slot;
+        const float *row = h >= 0 ? job.samples + (size_t)h * job.streams : job.ring + (size_t)slot * job.streams;
+        if constexpr (VEC) return *reinterpret_cast<const f32x2 *>(row + s0);
+        else return f32x2{live0 ? row[s0] : 0.0f, live1 ? row[s0 + 1] : 0.0f};
+    };
+    f32x2 acc[R::WS];                                        // acc[a], a = 1..2N; garbage until a real output reaches it
+#pragma unroll
+    for (int a = 0; a < R::WS; ++a) acc[a] = f32x2{0.0f, 0.0f};
+    f32x2 ahead[R::P];
+#pragma unroll
+    for (int p = 0; p < R::P; ++p) ahead[p] = load_row(p);
+    const int nrows = nt + 2 * N;
+    for (int r = 0; r < nrows; ++r) {
+        const f32x2 x = ahead[0];
+#pragma unroll
+        for (int p = 0; p + 1 < R::P; ++p) ahead[p] = ahead[p + 1];
+        ahead[R::P - 1] = load_row(r + R::P);
+        // volatile asm, products and adds alike: left to the compiler the adds sink to the end of the iteration and all
+        // 2N+1 products stay live (see sg_2d_dense.hip)
+        f32x2 done;
+        static_for<R::WS>([&](auto ic) -> bool {
+            constexpr int a = R::WS - 1 - decltype(ic)::value;   // slot = tap index, 2N down to 0
+            f32x2 p;
+            if constexpr ((a & 1) == 0) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(taps.w[a >> 1]), "v"(x));
+            else                        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(p) : "s"(taps.w[a >> 1]), "v"(x));
+            if constexpr (a == R::WS - 1)  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(done) : "v"(acc[a]), "v"(p));
+            else if constexpr (a == 0)     asm volatile("v_pk_add_f32 %0, %1, 0 op_sel_hi:[1,0]" : "=v"(acc[1]) : "v"(p));
+            else                           asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(acc[a + 1]) : "v"(acc[a]), "v"(p));
+            return true;
+        });
+        const long long t = (long long)t0 + r - 2 * N;
+        if (r >= 2 * N && job.received0 + (unsigned long long)t + 1 >= (unsigned long long)R::WS) {      // uniform (reference :166-170)
+            const f32x2 y = done * f32x2{job.dt_inv, job.dt_inv};
+            float *orow = job.out + (size_t)t * job.streams;
+            if constexpr (VEC) *reinterpret_cast<f32x2 *>(orow + s0) = y;
+            else { if (live0) orow[s0] = y.x; if (live1) orow[s0 + 1] = y.y; }
+        }
+    }
+}
+
 template <int N>
 __global__ __launch_bounds__(256) void sg_bank_roll_kernel(const BankJob job, const SRollTaps<N> taps)
 {
@@ -109,8 +167,12 @@ __global__ __launch_bounds__(256) void sg_bank_roll_kernel(const BankJob job, co
         const size_t s0 = (size_t)strip * 128 + 2 * (size_t)lane;
         const size_t t0 = (size_t)band * (size_t)job.band_ticks;
         const int nt = job.ticks - t0 < (size_t)job.band_ticks ? (int)(job.ticks - t0) : job.band_ticks;
-        if (job.aligned && (size_t)strip * 128 + 128 <= job.streams) bank_roll_item<N, true>(job, taps, s0, t0, nt);
-        else bank_roll_item<N, false>(job, taps, s0, t0, nt);
+        const bool vec = job.aligned && (size_t)strip * 128 + 128 <= job.streams;
+        if constexpr (N <= STREAM_RING_MAX_N) {
+            if (vec) bank_roll_item<N, true>(job, taps, s0, t0, nt); else bank_roll_item<N, false>(job, taps, s0, t0, nt);
+        } else {
+            if (vec) bank_accroll_item<N, true>(job, taps, s0, t0, nt); else bank_accroll_item<N, false>(job, taps, s0, t0, nt);
+        }
     }
 }
 

@@ -1,0 +1,20 @@
+"""Times savgol_streambank_push_block for a few half windows (tools, not product)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package
+sg = load_package()
+import torch
+
+S, T = 65536, 4096
+x = torch.randn((T, S), device="cuda")
+out = torch.empty_like(x)
+for n in (4, 8, 16, 17, 24, 32):
+    bank = sg.StreamBank(S, n, 2, 1, 1e-3)
+    bank.push_block(x, T, out); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); bank.push_block(x, T, out); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = min(ts)
+    print(f"n={n:2d}: {ms:.3f} ms per {T} ticks x {S} streams = {S*T/ms/1e6:.0f} Gsamples/s, {8*S*T/ms/1e6:.0f} GB/s")
