@@ -347,3 +347,53 @@ def test_fused_gradient_hessian_laplacian_batch(sg, sgo, torch_gpu):
     torch.cuda.synchronize()
     a = sgo.Filter2D(4, 6, 3, 2, 0).apply(x[0], cols, 1); c = sgo.Filter2D(4, 6, 3, 0, 2).apply(x[0], cols, 1)
     assert np.array_equal(lap[0].cpu().numpy()[:, :cols], (a + c)[:, :cols])
+
+
+def test_randomized_2d_configurations(sg, sgo, torch_gpu):
+    """200 random (n, order, dx, dy, deltas, boundary, frame size, pitch, base alignment) draws.  Method 1 must equal
+    the reference order bit for bit whatever kernel serves it; method 2 / 0 must stay within the forward error bound
+    of a (2n+1)^2-term dot product of the double-accumulation oracle."""
+    torch = torch_gpu
+    rng = np.random.default_rng(20261004)
+    eps = 2.0 ** -24
+    for it in range(200):
+        square = rng.random() < 0.7
+        nx = int(rng.integers(1, 17)); ny = nx if square else int(rng.integers(1, 17))
+        order = int(rng.integers(0, min(6, 2 * min(nx, ny)) + 1))
+        dx = int(rng.integers(0, min(order, 2) + 1)); dy = int(rng.integers(0, min(order - dx, 2) + 1))
+        ddx, ddy = float(rng.choice([1.0, 0.5, 2.0])), float(rng.choice([1.0, 0.25]))
+        b = int(rng.integers(0, 3))
+        rows = int(rng.integers(2 * ny + 1 + (b == 0), 2 * ny + 120)); cols = int(rng.integers(2 * nx + 1 + (b == 0), 2 * nx + 420))
+        stride = cols + int(rng.choice([0, 1, 3, 4])); images = int(rng.integers(1, 4)); off = int(rng.choice([0, 0, 1, 2]))
+        flat = np.zeros(images * rows * stride + 4, np.float32)
+        x = flat[off:off + images * rows * stride].reshape(images, rows, stride)
+        x[:, :, :cols] = rng.normal(0, 1, (images, rows, cols)).astype(np.float32)
+        d = torch.from_numpy(flat).cuda()[off:off + images * rows * stride]
+        try:
+            f = sg.Filter2D(nx, ny, order, dx, dy, ddx, ddy)
+        except ValueError:                                     # more polynomial terms than window points
+            continue
+        o = sgo.Filter2D(nx, ny, order, dx, dy, ddx, ddy)
+        sel = np.zeros((rows, stride), bool)
+        if b == 0:
+            sel[ny:rows - ny, nx:cols - nx] = True
+        else:
+            sel[:, :cols] = True
+        for method in (1, 0):
+            out = torch.full((images * rows * stride + 4,), -5.0, device="cuda")
+            f.apply_batch(d, out[off:off + images * rows * stride], rows, cols, images, in_stride=stride, out_stride=stride,
+                          boundary=b, method=method)
+            got = out.cpu().numpy()
+            assert np.all(got[:off] == -5.0) and np.all(got[off + images * rows * stride:] == -5.0)
+            g = got[off:off + images * rows * stride].reshape(images, rows, stride)
+            for k in range(images):
+                assert np.all(g[k][~sel] == -5.0), (it, method, "wrote outside the output region")
+                if method == 1:
+                    want = o.apply(x[k], cols, b, out=np.full((rows, stride), -5.0, np.float32))
+                    assert same_bits(g[k], want), (it, nx, ny, order, dx, dy, b, rows, cols, stride, off)
+                else:
+                    hi = o.apply_f64acc(x[k], cols, b)
+                    W = f.weights.astype(np.float64)
+                    bound = 4 * (W.size + 2) * eps * np.abs(W).sum() * np.abs(x[k]).max() * abs(float(o.scale))
+                    err = np.abs(g[k][sel] - hi[sel]).max()
+                    assert err <= bound, (it, nx, ny, order, dx, dy, b, rows, cols, err, bound)

@@ -216,3 +216,65 @@ def test_stream_bank_config3_shape(sg, sgo, torch_gpu):
         o = sgo.Stream(f)
         seq = np.array([v for v, ok in (o.push(v) for v in xh[:, s]) if ok], np.float32)
         assert same_bits(out[2 * n:, s].cpu().numpy(), seq)
+
+
+def test_randomized_stream_bank_sequences(sg, sgo, torch_gpu):
+    """80 random banks (n up to 32, any order / derivative / time step, odd and even stream counts) driven by a random
+    sequence of push / push_full / push_block calls, then both flushes: sampled streams must reproduce the oracle's
+    per-stream sequence bit for bit, counters included."""
+    torch = torch_gpu
+    rng = np.random.default_rng(20261005)
+    for it in range(80):
+        n = int(rng.integers(1, 33)); m = int(rng.integers(0, min(2 * n, 8) + 1)); d = int(rng.integers(0, min(m, 3) + 1))
+        dt = float(rng.choice([1.0, 1e-3, 0.5]))
+        S = int(rng.choice([1, 2, 63, 130, 777, 1024])); T = int(rng.integers(1, 6 * (2 * n + 1)))
+        x = rng.normal(0, 1, (T, S)).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        f = sgo.Filter(n, m, d, dt)
+        pick = sorted(set([0, S - 1, S // 2]))
+        oracles = {s: sgo.Stream(f) for s in pick}
+        want = {s: [] for s in pick}
+        got = {s: [] for s in pick}
+        bank = sg.StreamBank(S, n, m, d, dt)
+        rows = torch.zeros((n + 1, S), dtype=torch.float32, device="cuda")
+        t = 0
+        while t < T:
+            kind = int(rng.integers(0, 3)); k = 1 if kind < 2 else int(rng.integers(1, min(T - t, 4 * n + 8) + 1))
+            if kind == 0:
+                r = bank.push(xd[t], rows[0])
+                host = rows[:1].cpu().numpy() if r == 1 else None
+                for s in pick:
+                    v, ok = oracles[s].push(x[t, s])
+                    assert ok == (r == 1)
+                    if ok:
+                        want[s].append(v); got[s].append(host[0, s])
+            elif kind == 1:
+                r = bank.push_full(xd[t], rows, n + 1)
+                host = rows[:r].cpu().numpy() if r else None
+                for s in pick:
+                    w = oracles[s].push_full(x[t, s])
+                    assert w.size == r
+                    want[s].extend(w.tolist()); got[s].extend(host[:, s].tolist() if r else [])
+            else:
+                out = torch.full((k, S), float("nan"), device="cuda")
+                r = bank.push_block(xd[t:t + k], k, out)
+                host = out.cpu().numpy()
+                for s in pick:
+                    seq = [oracles[s].push(v) for v in x[t:t + k, s]]
+                    vals = [v for v, ok in seq if ok]
+                    assert len(vals) == r
+                    want[s].extend(vals); got[s].extend(host[k - r:, s].tolist())
+                    assert np.isnan(host[:k - r, s]).all()
+            t += k
+        for flush_gpu, flush_cpu in ((bank.flush_leading, "flush_leading"), (bank.flush, "flush")):
+            r = flush_gpu(rows, n)
+            host = rows[:max(r, 0)].cpu().numpy()
+            for s in pick:
+                c, w = getattr(oracles[s], flush_cpu)()
+                assert c == r, (it, flush_cpu, c, r)
+                if r > 0:
+                    want[s].extend(np.asarray(w).tolist()); got[s].extend(host[:, s].tolist())
+        for s in pick:
+            a, b2 = np.array(want[s], np.float32), np.array(got[s], np.float32)
+            assert a.shape == b2.shape and same_bits(a, b2), (it, n, m, d, dt, S, T, s)
+        assert tuple(bank.counters) == tuple(oracles[pick[0]].counters[:2])
