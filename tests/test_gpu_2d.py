@@ -397,3 +397,59 @@ def test_randomized_2d_configurations(sg, sgo, torch_gpu):
                     bound = 4 * (W.size + 2) * eps * np.abs(W).sum() * np.abs(x[k]).max() * abs(float(o.scale))
                     err = np.abs(g[k][sel] - hi[sel]).max()
                     assert err <= bound, (it, nx, ny, order, dx, dy, b, rows, cols, err, bound)
+
+
+def test_randomized_derivative_frames(sg, sgo, torch_gpu):
+    """80 random draws of the gradient / Hessian / Laplacian device entry points (square and rectangular windows, any
+    half window, NULL outputs, odd pitches): every frame within the dot-product error bound of the double oracle,
+    nothing written outside the output region."""
+    torch = torch_gpu
+    rng = np.random.default_rng(20261006)
+    eps = 2.0 ** -24
+    L = sg.lib()
+    for it in range(80):
+        square = rng.random() < 0.75
+        nx = int(rng.integers(1, 17)); ny = nx if square else int(rng.integers(1, 17))
+        order = int(rng.integers(2, min(6, 2 * min(nx, ny)) + 1)) if min(nx, ny) >= 1 else 2
+        ddx, ddy = float(rng.choice([1.0, 0.5, 2.0])), float(rng.choice([1.0, 0.25]))
+        b = int(rng.integers(0, 3))
+        rows = int(rng.integers(2 * ny + 1 + (b == 0), 2 * ny + 90)); cols = int(rng.integers(2 * nx + 1 + (b == 0), 2 * nx + 330))
+        stride = cols + int(rng.choice([0, 1, 4])); images = int(rng.integers(1, 3))
+        try:
+            oracles = {k: sgo.Filter2D(nx, ny, order, dx, dy, ddx, ddy) for k, (dx, dy) in
+                       {"gx": (1, 0), "gy": (0, 1), "xx": (2, 0), "xy": (1, 1), "yy": (0, 2)}.items()}
+            sg.Filter2D(nx, ny, order, 2, 0, ddx, ddy)
+        except ValueError:
+            continue
+        x = np.zeros((images, rows, stride), np.float32)
+        x[:, :, :cols] = rng.normal(0, 1, (images, rows, cols)).astype(np.float32)
+        d = torch.from_numpy(x).cuda()
+        pitch = rows * stride
+        outs = {k: torch.full_like(d, -3.0) for k in ("gx", "gy", "xx", "xy", "yy", "lap")}
+        skip = rng.choice(["", "gx", "xy", "yy"])             # one NULL output now and then
+        ptr = lambda k: None if k == skip else outs[k].data_ptr()
+        assert L.savgol2d_gradient_batch_f32(nx, ny, order, d.data_ptr(), rows, cols, stride, pitch, ptr("gx"), ptr("gy"), stride, pitch,
+                                             images, ddx, ddy, b, None) == 0, sg.last_error()
+        assert L.savgol2d_hessian_batch_f32(nx, ny, order, d.data_ptr(), rows, cols, stride, pitch, ptr("xx"), ptr("xy"), ptr("yy"),
+                                            stride, pitch, images, ddx, ddy, b, None) == 0, sg.last_error()
+        assert L.savgol2d_laplacian_batch_f32(nx, ny, order, d.data_ptr(), rows, cols, stride, pitch, outs["lap"].data_ptr(), stride, pitch,
+                                              images, ddx, ddy, b, None) == 0, sg.last_error()
+        torch.cuda.synchronize()
+        sel = np.zeros((rows, stride), bool)
+        if b == 0:
+            sel[ny:rows - ny, nx:cols - nx] = True
+        else:
+            sel[:, :cols] = True
+        hi = {k: [o.apply_f64acc(x[i], cols, b) for i in range(images)] for k, o in oracles.items()}
+        bnd = {k: 4 * (o.W.size + 2) * eps * np.abs(np.asarray(o.W, np.float64)).sum() * np.abs(x).max() * abs(float(o.scale)) for k, o in oracles.items()}
+        for k in ("gx", "gy", "xx", "xy", "yy", "lap"):
+            g = outs[k].cpu().numpy()
+            if k == skip:
+                assert np.all(g == -3.0)
+                continue
+            for i in range(images):
+                assert np.all(g[i][~sel] == -3.0), (it, k, "wrote outside the output region")
+                want = hi["xx"][i] + hi["yy"][i] if k == "lap" else hi[k][i]
+                bound = bnd["xx"] + bnd["yy"] if k == "lap" else bnd[k]
+                err = np.abs(g[i][sel] - want[sel]).max()
+                assert err <= bound, (it, k, nx, ny, order, b, rows, cols, err, bound)
