@@ -14,7 +14,7 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 struct Taps { f2 w[16]; };
 
 // one wave-iteration: 8 vectors per lane (a 2048-sample tile per wave, like the headline kernel), K*8 FMAs
-template <int K, int LDS>
+template <int K, int LDS, int NT = 1>
 __global__ __launch_bounds__(256, 4) void k(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nvec, Taps t)
 {
     __shared__ f4 slab[LDS ? 4 * 64 * 9 : 1];
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256, 4) void k(const f4 *__restrict__ in, f4 *__res
         const f4 *src = in + tile * 512;
         f4 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = __builtin_bit_cast(f4, __builtin_nontemporal_load(reinterpret_cast<const u4 *>(src + j * 64 + lane)));
+        for (int j = 0; j < 8; ++j) v[j] = NT ? __builtin_bit_cast(f4, __builtin_nontemporal_load(reinterpret_cast<const u4 *>(src + j * 64 + lane))) : src[j * 64 + lane];
         if constexpr (LDS) {                         // the staging round trip of the real kernel: coalesced rows in, per-lane rows out
             f4 *mine = slab + wv * 64 * 9;
 #pragma unroll
@@ -50,9 +50,11 @@ __global__ __launch_bounds__(256, 4) void k(const f4 *__restrict__ in, f4 *__res
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[i]) : "s"(t.w[(r + i) & 15]), "v"(x));
         f4 *dst = out + tile * 512;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            __builtin_nontemporal_store(__builtin_bit_cast(u4, f4{acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y}),
-                                        reinterpret_cast<u4 *>(dst + j * 64 + lane));
+        for (int j = 0; j < 8; ++j) {
+            const f4 o = f4{acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y};
+            if (NT) __builtin_nontemporal_store(__builtin_bit_cast(u4, o), reinterpret_cast<u4 *>(dst + j * 64 + lane));
+            else dst[j * 64 + lane] = o;
+        }
     }
 }
 
@@ -65,19 +67,19 @@ __global__ void fill(float *p, size_t n)          // noisy data: realistic bit t
     }
 }
 
-template <int K, int LDS>
+template <int K, int LDS, int NT = 1>
 void run(const f4 *in, f4 *out, size_t nvec)
 {
     Taps t;
     for (int i = 0; i < 16; ++i) t.w[i] = f2{1e-3f * i, -1e-3f * i};
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k<K, LDS>), dim3(1024), dim3(256), 0, 0, in, out, nvec, t);
+    hipLaunchKernelGGL((k<K, LDS, NT>), dim3(1024), dim3(256), 0, 0, in, out, nvec, t);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<K, LDS>), dim3(1024), dim3(256), 0, 0, in, out, nvec, t);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<K, LDS, NT>), dim3(1024), dim3(256), 0, 0, in, out, nvec, t);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 5;
-    printf("pk_fma per 16-B vector = %3d, LDS mode %d : %7.3f ms  -> %6.0f GB/s in+out (%4.1f %% of 8 TB/s)\n", K, LDS, ms,
+    printf("pk_fma per 16-B vector = %3d, LDS mode %d, %s : %7.3f ms  -> %6.0f GB/s in+out (%4.1f %% of 8 TB/s)\n", K, LDS, NT ? "nontemporal" : "plain      ", ms,
            2.0 * nvec * 16 / ms / 1e6, 2.0 * nvec * 16 / ms / 1e6 / 80.0);
 }
 
@@ -99,5 +101,8 @@ int main(int argc, char **argv)
     run<128, 1>(in, out, nvec);
     run<128, 2>(in, out, nvec);
     run<64, 2>(in, out, nvec);       // ~ n=16
+    run<0, 0, 0>(in, out, nvec);     // plain loads / stores instead of nontemporal
+    run<128, 0, 0>(in, out, nvec);
+    run<128, 2, 0>(in, out, nvec);
     return 0;
 }
