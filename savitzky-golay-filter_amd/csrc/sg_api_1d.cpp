@@ -62,6 +62,7 @@ extern "C" void savgol_destroy(SavgolFilter *filter) { free(filter); }
 namespace {
 
 std::atomic<int> g_correct_leading_edge{0};
+std::atomic<int> g_reference_summation{0};      // SAVGOL_HIP_OPT_REFERENCE_SUMMATION: batch f32 calls in the reference's order
 
 enum Variant { FULL = 0, VALID = 1, FULL_POLY_EDGES = 2 /* strided: polynomial edges whatever the mode */ };
 
@@ -83,7 +84,7 @@ bool filter_sane(const SavgolFilter *f, const char *who)
 
 template <typename T>
 int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_out, size_t channels, size_t length,
-                  size_t in_ld, size_t out_ld, Variant variant, hipStream_t st)
+                  size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, bool reference_order = false)
 {
     if (!f || !d_in || !d_out) { sg_set_error("%s: NULL pointer", who); return -1; }
     if (!filter_sane(f, who)) return -1;
@@ -96,6 +97,26 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
 
     DeviceCtx *ctx = sg::ctx_get();
     if (!ctx) return -1;
+
+    if constexpr (sizeof(T) == 4) {
+        if (reference_order) {
+            // one output per thread in the reference's own summation order: bit-identical to its savgol_apply
+            float packed[(SAVGOL_MAX_HALF_WINDOW + 1) * SAVGOL_MAX_WINDOW];
+            memcpy(packed, f->center_weights, sizeof(float) * ws);
+            for (int e = 0; e < n; ++e) memcpy(packed + (size_t)(1 + e) * ws, f->edge_weights[e], sizeof(float) * ws);
+            const float *d_table = sg::ctx_table(ctx, packed, sizeof(float) * (size_t)(n + 1) * ws, 0x1e00u + (unsigned)n);
+            if (!d_table) return -1;
+            const int rmode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
+            const int lo = (variant == VALID) ? n : 0, hi = (variant == VALID) ? (int)length - n : (int)length;
+            const int negate = (rmode == SAVGOL_BOUNDARY_POLYNOMIAL && g_correct_leading_edge.load() && (f->config.derivative & 1)) ? 1 : 0;
+            if (sg1d_launch_reference_order_f32(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_table,
+                                                dt_inverse(f), rmode, lo, hi, lo, negate, channels, st) != 0) {
+                sg_set_error("%s: kernel launch failed", who);
+                return -1;
+            }
+            return 0;
+        }
+    }
 
     constexpr int E = 16 / (int)sizeof(T);
     const int vpl = sg::vectors_per_lane(sizeof(T), f->config.half_window);
@@ -184,6 +205,7 @@ extern "C" {
 int savgol_hip_set_option(int option, int value)
 {
     if (option == SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE) { g_correct_leading_edge.store(value != 0); return 0; }
+    if (option == SAVGOL_HIP_OPT_REFERENCE_SUMMATION) { g_reference_summation.store(value != 0); return 0; }
     sg_set_error("savgol_hip_set_option: unknown option %d", option);
     return -1;
 }
@@ -192,7 +214,7 @@ int savgol_apply_batch_f32(const SavgolFilter *filter, const float *d_in, float 
                            size_t in_ld, size_t out_ld, void *stream)
 {
     return enqueue_batch<float>("savgol_apply_batch_f32", filter, d_in, d_out, channels, length, in_ld, out_ld, FULL,
-                                static_cast<hipStream_t>(stream));
+                                static_cast<hipStream_t>(stream), g_reference_summation.load() != 0);
 }
 
 int savgol_apply_batch_f64(const SavgolFilter *filter, const double *d_in, double *d_out, size_t channels, size_t length,
@@ -206,7 +228,7 @@ int savgol_apply_valid_batch_f32(const SavgolFilter *filter, const float *d_in, 
                                  size_t length, size_t in_ld, size_t out_ld, void *stream)
 {
     return enqueue_batch<float>("savgol_apply_valid_batch_f32", filter, d_in, d_out, channels, length, in_ld, out_ld,
-                                VALID, static_cast<hipStream_t>(stream));
+                                VALID, static_cast<hipStream_t>(stream), g_reference_summation.load() != 0);
 }
 
 int savgol_apply_valid_batch_f64(const SavgolFilter *filter, const double *d_in, double *d_out, size_t channels,
@@ -238,7 +260,7 @@ int savgol_apply_strided_batch_f32(const SavgolFilter *filter, const void *d_in,
         sg_set_error("%s: gather launch failed", who);
         return -1;
     }
-    if (enqueue_batch<float>(who, filter, dense, result, channels, count, ld, ld, FULL_POLY_EDGES, st) != 0) return -1;
+    if (enqueue_batch<float>(who, filter, dense, result, channels, count, ld, ld, FULL_POLY_EDGES, st, g_reference_summation.load() != 0) != 0) return -1;
     if (sg_launch_scatter_f32(result, ld, d_out, out_stride, out_offset, out_channel_pitch, channels, count, st) != 0) {
         sg_set_error("%s: scatter launch failed", who);
         return -1;
@@ -248,7 +270,9 @@ int savgol_apply_strided_batch_f32(const SavgolFilter *filter, const void *d_in,
 }
 
 // ------------------------------------------------------------------------------------------------
-// drop-in host-pointer entry points (reference src/savgolFilter.c:743-934): stage through HBM.
+// drop-in host-pointer entry points (reference src/savgolFilter.c:743-934): stage through HBM.  They run the
+// reference-order kernel (sg1d_reference_order_kernel): the host link bounds them anyway, and a program that switches
+// from the reference library gets the reference's outputs bit for bit.
 // ------------------------------------------------------------------------------------------------
 int savgol_apply(const SavgolFilter *filter, const float *input, float *output, size_t length)
 {
@@ -268,7 +292,7 @@ int savgol_apply(const SavgolFilter *filter, const float *input, float *output, 
     if (!d_in) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
     float *d_out = d_in + ld;
     bool ok = sg::hip_ok(hipMemcpyAsync(d_in, input, length * sizeof(float), hipMemcpyHostToDevice, nullptr), "H2D copy");
-    ok = ok && savgol_apply_batch_f32(filter, d_in, d_out, 1, length, ld, ld, nullptr) == 0;
+    ok = ok && enqueue_batch<float>("savgol_apply", filter, d_in, d_out, 1, length, ld, ld, FULL, nullptr, /*reference order*/ true) == 0;
     ok = ok && sg::hip_ok(hipMemcpy(output, d_out, length * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");
     if (!ok) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
     return 0;
@@ -287,7 +311,7 @@ size_t savgol_apply_valid(const SavgolFilter *filter, const float *input, size_t
     if (!d_in) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
     float *d_out = d_in + ld;
     bool ok = sg::hip_ok(hipMemcpyAsync(d_in, input, input_length * sizeof(float), hipMemcpyHostToDevice, nullptr), "H2D copy");
-    ok = ok && savgol_apply_valid_batch_f32(filter, d_in, d_out, 1, input_length, ld, ld, nullptr) == 0;
+    ok = ok && enqueue_batch<float>("savgol_apply_valid", filter, d_in, d_out, 1, input_length, ld, ld, VALID, nullptr, /*reference order*/ true) == 0;
     ok = ok && sg::hip_ok(hipMemcpy(output, d_out, out_len * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");
     if (!ok) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
     return out_len;
@@ -310,7 +334,7 @@ int savgol_apply_strided(const SavgolFilter *filter, const void *input, size_t i
     const char *ib = static_cast<const char *>(input) + in_offset;
     for (size_t i = 0; i < count; ++i) memcpy(&stage[i], ib + i * in_stride, sizeof(float));
     bool ok = sg::hip_ok(hipMemcpy(d_in, stage, count * sizeof(float), hipMemcpyHostToDevice), "H2D copy");
-    ok = ok && enqueue_batch<float>("savgol_apply_strided", filter, d_in, d_out, 1, count, ld, ld, FULL_POLY_EDGES, nullptr) == 0;
+    ok = ok && enqueue_batch<float>("savgol_apply_strided", filter, d_in, d_out, 1, count, ld, ld, FULL_POLY_EDGES, nullptr, /*reference order*/ true) == 0;
     ok = ok && sg::hip_ok(hipMemcpy(stage, d_out, count * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");
     if (!ok) { fprintf(stderr, "savgol_apply_strided: %s\n", savgol_hip_last_error()); return -1; }
     char *ob = static_cast<char *>(output) + out_offset;

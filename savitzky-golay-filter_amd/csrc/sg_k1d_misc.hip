@@ -55,6 +55,66 @@ __global__ __launch_bounds__(256) void sg_synth_kernel(T *__restrict__ dst, size
     }
 }
 
+// ---- the reference's own summation order (savgol_apply, src/savgolFilter.c:743-804), one output per thread ----
+// convolve_ilp (:547-580) / convolve_ilp_reverse (:593-623): the first ws&3 taps go to chains 0..2, the rest are dealt
+// round robin to four chains, result (c0+c1)+(c2+c3), every multiply and add rounded on its own.  Used by the
+// host-pointer drop-in calls (which are bounded by the host link anyway) and, on request, by the batch entry points:
+// outputs are bit-identical to the reference library's.  x(k) returns tap k's sample.
+template <typename Sample>
+__device__ __forceinline__ float dot_reference_order(const float *__restrict__ w, int ws, Sample x)
+{
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    const int r = ws & 3;                                    // ws is odd: 1 or 3
+    if (r > 0) c0 = __fadd_rn(c0, __fmul_rn(w[0], x(0)));
+    if (r > 1) c1 = __fadd_rn(c1, __fmul_rn(w[1], x(1)));
+    if (r > 2) c2 = __fadd_rn(c2, __fmul_rn(w[2], x(2)));
+    for (int k = r; k < ws; k += 4) {
+        c0 = __fadd_rn(c0, __fmul_rn(w[k], x(k)));
+        c1 = __fadd_rn(c1, __fmul_rn(w[k + 1], x(k + 1)));
+        c2 = __fadd_rn(c2, __fmul_rn(w[k + 2], x(k + 2)));
+        c3 = __fadd_rn(c3, __fmul_rn(w[k + 3], x(k + 3)));
+    }
+    return __fadd_rn(__fadd_rn(c0, c1), __fadd_rn(c2, c3));
+}
+
+// table: row 0 = centre taps, row 1+e = edge row e, ws floats each.  mode = SavgolBoundaryMode (anything else: zeros
+// outside the signal, reference :478-480).  Samples g in [store_lo, store_hi) are written to out[g - out_shift].
+// negate_leading: SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE for odd derivatives (POLYNOMIAL mode only).
+__global__ __launch_bounds__(256) void sg1d_reference_order_kernel(const float *__restrict__ in, float *__restrict__ out, long long in_ld,
+                                                                   long long out_ld, int L, int n, const float *__restrict__ table,
+                                                                   float dt_inv, int mode, int store_lo, int store_hi, int out_shift,
+                                                                   int negate_leading)
+{
+    const int ws = 2 * n + 1;
+    const float *x = in + (long long)blockIdx.y * in_ld;
+    float *y = out + (long long)blockIdx.y * out_ld;
+    for (int j = store_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x); j < store_hi; j += (int)(gridDim.x * blockDim.x)) {
+        float v;
+        if (j >= n && j < L - n) {
+            const float *p = x + (j - n);
+            v = dot_reference_order(table, ws, [&](int k) { return p[k]; });
+        } else if (mode == SAVGOL_BOUNDARY_POLYNOMIAL) {
+            if (j < n) {                                     // leading edge: row j on the first ws samples walked backwards
+                const float *p = x + (ws - 1);
+                v = dot_reference_order(table + (size_t)(1 + j) * ws, ws, [&](int k) { return p[-k]; });
+                if (negate_leading) v = -v;
+            } else {                                         // trailing edge: row L-1-j on the last ws samples
+                const float *p = x + (L - ws);
+                v = dot_reference_order(table + (size_t)(1 + (L - 1 - j)) * ws, ws, [&](int k) { return p[k]; });
+            }
+        } else {                                             // get_padded_sample :442-482
+            v = dot_reference_order(table, ws, [&](int k) {
+                bool zero;
+                int i = j - n + k;
+                if (i >= 0 && i < L) return x[i];
+                i = remap_index(i, L, mode, zero);
+                return zero ? 0.0f : x[i];
+            });
+        }
+        y[j - out_shift] = __fmul_rn(v, dt_inv);
+    }
+}
+
 template <typename T>
 static int enqueue_edges(const T *in, T *out, long long in_ld, long long out_ld, long long L, int n,
                         const float *d_edges, float dt_inv, int apply_scale, size_t channels, hipStream_t st)
@@ -100,6 +160,24 @@ int sg1d_launch_edges_f64(const double *in, double *out, long long in_ld, long l
 {
     return sg::enqueue_edges<double>(in, out, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale, channels,
                                     static_cast<hipStream_t>(st));
+}
+
+int sg1d_launch_reference_order_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
+                                    const float *d_table, float dt_inv, int mode, int store_lo, int store_hi, int out_shift,
+                                    int negate_leading, size_t channels, void *stream)
+{
+    if (store_hi <= store_lo) return 0;
+    unsigned gx = (unsigned)(((size_t)(store_hi - store_lo) + 255) / 256);
+    if (gx > 16384u) gx = 16384u;
+    size_t done = 0;
+    while (done < channels) {                       // gridDim.y limit
+        const size_t chunk = (channels - done) < 65535 ? (channels - done) : 65535;
+        hipLaunchKernelGGL(sg::sg1d_reference_order_kernel, dim3(gx, (unsigned)chunk), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           in + done * in_ld, out + done * out_ld, in_ld, out_ld, (int)L, n, d_table, dt_inv, mode, store_lo, store_hi,
+                           out_shift, negate_leading);
+        done += chunk;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int sg_launch_gather_f32(const void *base, size_t stride, size_t offset, size_t pitch, float *dst, size_t dst_ld,

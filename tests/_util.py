@@ -10,3 +10,9 @@ def normwise(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     den = np.max(np.abs(b))
     return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+def same_bits(a, b):
+    """fp32 arrays equal bit for bit (so -0.0 != +0.0 and NaN payloads count), shapes included"""
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))

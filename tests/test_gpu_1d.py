@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from tests._util import normwise
+from tests._util import normwise, same_bits
 from tests.golden.make_golden import APPLY_CASES
 
 pytestmark = pytest.mark.gpu
@@ -43,28 +43,53 @@ def signal(rng, shape):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ci", range(len(APPLY_CASES)))
 def test_savgol_apply_matches_reference_golden(sg, sgo, golden, torch_gpu, ci):
+    """The host-pointer drop-in calls run the reference's own summation order: their outputs equal the compiled
+    reference's (the golden fixtures) bit for bit -- all four modes, VALID, strided, time steps other than 1."""
     g = golden("apply1d")
     n, m, d, length = (int(v) for v in g[f"c{ci}_cfg"])
     dt = float(g[f"c{ci}_dt"])
     x = g[f"c{ci}_in"]
-    hard = (m >= 8)            # (32,10,4): the reference's own output is ~1e-5 from the oracle
     for mode in range(4):
         f = sg.Filter(n, m, d, dt, mode)
         y = f.apply(x)
-        want = g[f"c{ci}_mode{mode}_out"]
-        hi = sgo.Filter(n, m, d, dt, mode).apply_f64(x.astype(np.float64))
-        assert normwise(y, hi) < (2e-5 if hard else TOL_F32 if d == 0 else TOL_F32_DERIV), (ci, mode, normwise(y, hi))
-        assert normwise(y, want) < (4e-5 if hard else TOL_GOLD), (ci, mode, normwise(y, want))
+        assert same_bits(y, g[f"c{ci}_mode{mode}_out"]), (ci, mode)
     f = sg.Filter(n, m, d, dt, 0)
     v = f.apply_valid(x)
-    assert v.shape == g[f"c{ci}_valid_out"].shape
-    assert normwise(v, g[f"c{ci}_valid_out"]) < (4e-5 if hard else TOL_GOLD)
+    assert v.shape == g[f"c{ci}_valid_out"].shape and same_bits(v, g[f"c{ci}_valid_out"])
     src = g[f"c{ci}_strided_in"].copy()
     dst = src.copy()
     assert f.apply_strided(src, 12, 4, dst, 12, 4, length) == 0
-    want = g[f"c{ci}_strided_out"]
-    assert np.array_equal(dst[:, 0], want[:, 0]) and np.array_equal(dst[:, 2], want[:, 2])   # other fields untouched
-    assert normwise(dst[:, 1], want[:, 1]) < (4e-5 if hard else TOL_GOLD)
+    assert same_bits(dst, g[f"c{ci}_strided_out"])               # the filtered field and the untouched ones
+
+
+@pytest.mark.parametrize("ci", range(len(APPLY_CASES)))
+def test_batch_kernels_vs_reference_golden(sg, sgo, golden, torch_gpu, ci):
+    """The device batch entry points on the same cases: the default FMA kernel within tolerance of the reference's
+    output and of the double oracle; with SAVGOL_HIP_OPT_REFERENCE_SUMMATION the reference's bits."""
+    torch = torch_gpu
+    g = golden("apply1d")
+    n, m, d, length = (int(v) for v in g[f"c{ci}_cfg"])
+    dt = float(g[f"c{ci}_dt"])
+    x = g[f"c{ci}_in"]
+    xd = torch.from_numpy(np.ascontiguousarray(x[None, :])).cuda()
+    hard = (m >= 8)            # (32,10,4): the reference's own output is ~1e-5 from the oracle
+    L = sg.lib()
+    for mode in range(4):
+        f = sg.Filter(n, m, d, dt, mode)
+        want = g[f"c{ci}_mode{mode}_out"]
+        y = f.apply_tensor(xd)[0].cpu().numpy()
+        hi = sgo.Filter(n, m, d, dt, mode).apply_f64(x.astype(np.float64))
+        assert normwise(y, hi) < (2e-5 if hard else TOL_F32 if d == 0 else TOL_F32_DERIV), (ci, mode, normwise(y, hi))
+        assert normwise(y, want) < (4e-5 if hard else TOL_GOLD), (ci, mode, normwise(y, want))
+        assert L.savgol_hip_set_option(2, 1) == 0
+        try:
+            y = f.apply_tensor(xd)[0].cpu().numpy()
+            v = f.apply_tensor(xd, valid=True)[0].cpu().numpy()
+        finally:
+            assert L.savgol_hip_set_option(2, 0) == 0
+        assert same_bits(y, want), (ci, mode)
+        if mode == 0:
+            assert same_bits(v, g[f"c{ci}_valid_out"])
 
 
 def test_reference_unit_test_scenarios(sg, torch_gpu):
@@ -268,7 +293,8 @@ def test_shared_filter_from_many_threads(sg, sgo, torch_gpu):
     f = sg.Filter(8, 3, 0, 1.0, sg.SAVGOL_BOUNDARY_REFLECT)
     rng = np.random.default_rng(77)
     inputs = [signal(rng, (4000 + 13 * k,)).astype(np.float32) for k in range(8)]
-    want = [f.apply(x) for x in inputs]
+    want = [f.apply(x) for x in inputs]                          # host calls: the reference-order kernel
+    want_dev = [f.apply_tensor(torch.from_numpy(x[None, :]).cuda())[0].cpu().numpy() for x in inputs]   # device calls: the FMA kernel
     errors = []
 
     def host_worker(k):
@@ -287,7 +313,7 @@ def test_shared_filter_from_many_threads(sg, sgo, torch_gpu):
             for _ in range(25):
                 f.apply_batch(x, y, 16, x.shape[1], stream=s)
             s.synchronize()
-            if not np.array_equal(y[3].cpu().numpy(), want[k]):
+            if not np.array_equal(y[3].cpu().numpy(), want_dev[k]):
                 errors.append(("device", k))
         except Exception as e:                                   # noqa: BLE001
             errors.append(("device", k, repr(e)))
