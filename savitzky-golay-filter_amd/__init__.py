@@ -24,6 +24,7 @@ SAVGOL_MAX_DERIVATIVE = 4
 SAVGOL_BOUNDARY_POLYNOMIAL, SAVGOL_BOUNDARY_REFLECT, SAVGOL_BOUNDARY_PERIODIC, SAVGOL_BOUNDARY_CONSTANT = 0, 1, 2, 3
 SAVGOL2D_BOUNDARY_VALID, SAVGOL2D_BOUNDARY_CONSTANT, SAVGOL2D_BOUNDARY_REFLECT = 0, 1, 2
 SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1
+SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2
 
 
 class SavgolConfig(C.Structure):

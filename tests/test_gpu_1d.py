@@ -81,12 +81,12 @@ def test_batch_kernels_vs_reference_golden(sg, sgo, golden, torch_gpu, ci):
         hi = sgo.Filter(n, m, d, dt, mode).apply_f64(x.astype(np.float64))
         assert normwise(y, hi) < (2e-5 if hard else TOL_F32 if d == 0 else TOL_F32_DERIV), (ci, mode, normwise(y, hi))
         assert normwise(y, want) < (4e-5 if hard else TOL_GOLD), (ci, mode, normwise(y, want))
-        assert L.savgol_hip_set_option(2, 1) == 0
+        assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 1) == 0
         try:
             y = f.apply_tensor(xd)[0].cpu().numpy()
             v = f.apply_tensor(xd, valid=True)[0].cpu().numpy()
         finally:
-            assert L.savgol_hip_set_option(2, 0) == 0
+            assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 0) == 0
         assert same_bits(y, want), (ci, mode)
         if mode == 0:
             assert same_bits(v, g[f"c{ci}_valid_out"])

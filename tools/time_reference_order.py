@@ -7,10 +7,10 @@ L = sg.lib()
 for n in (5, 32):
     f = sg.Filter(n, 4, 0, 1.0, 0)
     for opt in (0, 1):
-        L.savgol_hip_set_option(2, opt)
+        L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, opt)
         f.apply_batch(x, y, 1024, 1<<20); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); f.apply_batch(x, y, 1024, 1<<20); e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         print(f"n={n} reference_order={opt}: {ms:.3f} ms = {x.numel()/ms/1e6:.1f} Gsamples/s")
-    L.savgol_hip_set_option(2, 0)
+    L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 0)
