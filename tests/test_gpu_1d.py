@@ -406,3 +406,18 @@ def test_randomized_configurations_within_the_dot_product_error_bound(sg, sgo, t
         err = np.abs(got[:, :length] - ref).max()
         assert err <= bound, (n, m, d, dt, mode, length, err, bound)
         assert np.all(got[:, length:] == -7.0)
+
+
+def test_matlab_pair_and_demo_dataset_through_the_drop_in_call(sg, golden, torch_gpu):
+    """The only golden vector the reference ships (savgolComparison.m: 301 points, n=6, m=3) and its 360-point demo
+    dataset, through savgol_apply on the GPU: the compiled reference's outputs bit for bit, and the values the
+    MATLAB script prints to 6 decimals."""
+    g = golden("matlab_pair")
+    raw, theirs = g["rawData"], g["yourSavgolData"]
+    y = sg.Filter(6, 3, 0).apply(raw.astype(np.float32))
+    assert same_bits(y, g["ref_out_f32"])
+    assert np.max(np.abs(y.astype(np.float64) - theirs)) < 2e-5 and normwise(y, theirs) < 1e-6
+    g = golden("demo360")
+    ds = g["dataset"]
+    assert same_bits(sg.Filter(6, 3, 0).apply(ds), g["smooth_n6_m3"])
+    assert same_bits(sg.Filter(10, 3, 1).apply(ds), g["deriv1_n10_m3"])
