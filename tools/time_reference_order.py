@@ -4,7 +4,7 @@ sg = load_package()
 import torch
 x = torch.randn((1024, 1<<20), device="cuda"); y = torch.empty_like(x)
 L = sg.lib()
-for n in (5, 32):
+for n in (2, 5, 8, 12, 16, 24, 32):
     f = sg.Filter(n, 4, 0, 1.0, 0)
     for opt in (0, 1):
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, opt)
