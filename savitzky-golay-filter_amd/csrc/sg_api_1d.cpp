@@ -109,11 +109,26 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
             const int rmode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
             const int lo = (variant == VALID) ? n : 0, hi = (variant == VALID) ? (int)length - n : (int)length;
             const int negate = (rmode == SAVGOL_BOUNDARY_POLYNOMIAL && g_correct_leading_edge.load() && (f->config.derivative & 1)) ? 1 : 0;
-            if (sg1d_launch_reference_order_f32(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_table,
-                                                dt_inverse(f), rmode, lo, hi, lo, negate, channels, st) != 0) {
-                sg_set_error("%s: kernel launch failed", who);
-                return -1;
+            const bool poly = rmode == SAVGOL_BOUNDARY_POLYNOMIAL;
+            int rc;
+            if (channels * length >= ((size_t)1 << 16) && length >= (size_t)4 * ws) {
+                // long batches: the packed kernel for everything the centre taps produce, the per-thread kernel for
+                // the 2n POLYNOMIAL edge samples of every channel
+                const int clo = (poly || variant == VALID) ? n : 0, chi = (poly || variant == VALID) ? (int)length - n : (int)length;
+                rc = sg1d_launch_refpk_f32(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, f->center_weights,
+                                           dt_inverse(f), rmode, clo, chi, lo, channels, ctx->cu_count, st);
+                if (rc == 0 && poly && variant != VALID) {
+                    rc = sg1d_launch_reference_order_f32(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_table,
+                                                         dt_inverse(f), rmode, 0, n, 0, negate, channels, st);
+                    if (rc == 0)
+                        rc = sg1d_launch_reference_order_f32(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_table,
+                                                             dt_inverse(f), rmode, (int)length - n, (int)length, 0, 0, channels, st);
+                }
+            } else {
+                rc = sg1d_launch_reference_order_f32(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_table,
+                                                     dt_inverse(f), rmode, lo, hi, lo, negate, channels, st);
             }
+            if (rc != 0) { sg_set_error("%s: kernel launch failed", who); return -1; }
             return 0;
         }
     }

@@ -62,6 +62,9 @@ int sg1d_launch_edges_f64(const double *in, double *out, long long in_ld, long l
 int sg1d_launch_reference_order_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
                                     const float *d_table, float dt_inv, int mode, int store_lo, int store_hi, int out_shift,
                                     int negate_leading, size_t channels, void *stream);
+int sg1d_launch_refpk_f32(const float *in, float *out, long long in_ld, long long out_ld, long long length, int n,
+                          const float *center, float dt_inv, int mode, int store_lo, int store_hi, int out_shift,
+                          size_t channels, int cu_count, void *stream);
 int sg_launch_gather_f32(const void *base, size_t stride, size_t offset, size_t pitch, float *dst, size_t dst_ld,
                          size_t channels, size_t count, void *st);
 int sg_launch_scatter_f32(const float *src, size_t src_ld, void *base, size_t stride, size_t offset, size_t pitch,

@@ -421,3 +421,38 @@ def test_matlab_pair_and_demo_dataset_through_the_drop_in_call(sg, golden, torch
     ds = g["dataset"]
     assert same_bits(sg.Filter(6, 3, 0).apply(ds), g["smooth_n6_m3"])
     assert same_bits(sg.Filter(10, 3, 1).apply(ds), g["deriv1_n10_m3"])
+
+
+@pytest.mark.parametrize("n", list(range(1, 33)))
+def test_reference_summation_batch_mode_is_bit_identical(sg, sgo, torch_gpu, n):
+    """SAVGOL_HIP_OPT_REFERENCE_SUMMATION on batches long enough for the packed reference-order kernel
+    (sg_k1d_ref.hip; shorter ones use the one-output-per-thread kernel): every sample equals the oracle's restatement
+    of savgol_apply -- itself pinned bit for bit to the compiled reference -- in all four modes, VALID, odd lengths,
+    pitches and base alignments, time steps other than 1."""
+    torch = torch_gpu
+    rng = np.random.default_rng(4000 + n)
+    m = int(rng.integers(0, min(2 * n, 6) + 1)); d = int(rng.integers(0, min(m, 2) + 1)); dt = float(rng.choice([1.0, 0.5]))
+    L = sg.lib()
+    assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 1) == 0
+    try:
+        for (ch, length, ld_in, ld_out, off) in ((3, 40000, 40000, 40000, 0), (2, 33333, 33335, 33334, 1), (5, 16411, 16412, 16416, 0)):
+            xh = signal(rng, (ch, length)).astype(np.float32)
+            buf_in = torch.zeros(ch * ld_in + 4, dtype=torch.float32, device="cuda")
+            buf_in[off:off + ch * ld_in].view(ch, ld_in)[:, :length] = torch.from_numpy(xh).cuda()
+            for mode in range(4):
+                f = sg.Filter(n, m, d, dt, mode)
+                o = sgo.Filter(n, m, d, dt, mode)
+                buf_out = torch.full((ch * ld_out + 4,), -9.0, dtype=torch.float32, device="cuda")
+                f.apply_batch(buf_in.data_ptr() + 4 * off, buf_out.data_ptr() + 4 * off, ch, length, ld_in, ld_out)
+                got = buf_out.cpu().numpy()
+                g = got[off:off + ch * ld_out].reshape(ch, ld_out)
+                assert same_bits(g[:, :length], o.apply(xh)), (n, m, d, dt, mode, length)
+                assert np.all(g[:, length:] == -9.0) and np.all(got[:off] == -9.0) and np.all(got[off + ch * ld_out:] == -9.0)
+            f = sg.Filter(n, m, d, dt, 0)
+            buf_out = torch.full((ch * ld_out + 4,), -9.0, dtype=torch.float32, device="cuda")
+            f.apply_batch(buf_in.data_ptr() + 4 * off, buf_out.data_ptr() + 4 * off, ch, length, ld_in, ld_out, valid=True)
+            g = buf_out.cpu().numpy()[off:off + ch * ld_out].reshape(ch, ld_out)
+            want = sgo.Filter(n, m, d, dt, 0).apply(xh)[:, n:length - n]
+            assert same_bits(g[:, :length - 2 * n], want) and np.all(g[:, length - 2 * n:] == -9.0), (n, "valid")
+    finally:
+        assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 0) == 0
