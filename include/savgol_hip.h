@@ -42,7 +42,7 @@ const char *savgol_hip_version(void);
 enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1, SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2 };
 /* SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 1: the fp32 1-D batch / valid / strided DEVICE entry points sum each output in
  * the reference's own order (convolve_ilp, src/savgolFilter.c:547-580: four chains, separate multiply and add) and are
- * then bit-identical to the reference's savgol_apply; 1.5x (n=5) to 2.2x (n=32) slower than the default FMA kernel, which
+ * then bit-identical to the reference's savgol_apply; 1.5x (n=5) to 2.1x (n=32) slower than the default FMA kernel, which
  * agrees with it to 1e-6.  The host-pointer drop-in calls of savgolFilter.h always use that order.                             */
 int         savgol_hip_set_option(int option, int value);
 

@@ -34,19 +34,33 @@ __device__ __forceinline__ constexpr int ref_chain(int k, int ch0) { return k < 
 template <int N>
 struct RefConv {
     typedef RefK<N> K;
-    // input pair (x[i], x[i+1]) of the lane's window: tap k = i - 2J - OFF of output pair J, chain ref_chain(k)
+    // input pair (x[i], x[i+1]) of the lane's window: tap k = i - 2J - OFF of output pair J, chain ref_chain(k).
+    // All (up to four) products first, then the adds: an asm result that the next instruction consumes costs an s_nop
+    // (sg_pk.hpp), this way it is one per input pair instead of one per product.
     template <int I, int J = 0>
-    static __device__ __forceinline__ void feed(f32x2 (&A)[4][4], const f32x2 (&W)[N + 1], const f32x2 x)
+    static __device__ __forceinline__ void products(f32x2 (&P)[4], const f32x2 (&W)[N + 1], const f32x2 x)
     {
         if constexpr (J < 4) {
             constexpr int k = I - 2 * J - K::OFF;
-            if constexpr (k >= 0 && k <= 2 * N) {
-                constexpr int c = ref_chain(k, K::CH0);
-                const f32x2 p = pk_mul_sgpr<(k & 1)>(W[k >> 1], x);
-                A[J][c] = A[J][c] + p;
-            }
-            feed<I, J + 1>(A, W, x);
+            if constexpr (k >= 0 && k <= 2 * N) P[J] = pk_mul_sgpr<(k & 1)>(W[k >> 1], x);
+            products<I, J + 1>(P, W, x);
         }
+    }
+    template <int I, int J = 0>
+    static __device__ __forceinline__ void sums(f32x2 (&A)[4][4], const f32x2 (&P)[4])
+    {
+        if constexpr (J < 4) {
+            constexpr int k = I - 2 * J - K::OFF;
+            if constexpr (k >= 0 && k <= 2 * N) A[J][ref_chain(k, K::CH0)] = A[J][ref_chain(k, K::CH0)] + P[J];
+            sums<I, J + 1>(A, P);
+        }
+    }
+    template <int I>
+    static __device__ __forceinline__ void feed(f32x2 (&A)[4][4], const f32x2 (&W)[N + 1], const f32x2 x)
+    {
+        f32x2 P[4];
+        products<I>(P, W, x);
+        sums<I>(A, P);
     }
     template <int Q>
     static __device__ __forceinline__ void quads(const char *win, f32x2 (&A)[4][4], const f32x2 (&W)[N + 1], f32x2 prev)
