@@ -194,12 +194,8 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         job.in = d_in + c0 * in_ld;
         job.out = d_out + c0 * out_ld;
         job.total_tiles = (unsigned)(nc * job.tiles_per_channel);
+        // one tile per wave, four waves per block, blocks dispatched in order (see sg1d_center_kernel)
         unsigned blocks = (job.total_tiles + 3u) / 4u;
-        static const char *env_bpc = getenv("SAVGOL_HIP_BLOCKS_PER_CU");           // tuning knob (default 4: LDS bound)
-        const unsigned bpc_default = vpl <= 4 ? 7u : vpl <= 6 ? 5u : 4u;                 // LDS-bound residency
-        const unsigned bpc = env_bpc ? (unsigned)atoi(env_bpc) : bpc_default;
-        const unsigned resident = (unsigned)ctx->cu_count * (bpc ? bpc : bpc_default);
-        if (blocks > resident) blocks = resident;
         blocks = (blocks + 7u) & ~7u;                                    // the XCD remap wants a multiple of 8
         if (sg::launch_center<T>(n, job, taps, blocks, st) != 0) return -1;
     }

@@ -9,7 +9,7 @@
 // Mapping (one 64-lane wave = one tile, waves never talk to each other, no s_barrier):
 //   * a tile is 64*R consecutive outputs of one channel, R = 128 B / sizeof(T) (32 fp32, 16 fp64);
 //   * the wave copies tile + halo from HBM into its private LDS slab with coalesced 16-B loads
-//     (next tile's loads are issued before this tile's arithmetic: register prefetch);
+//     (a wave handles one tile; the other waves of the SIMD cover its load latency);
 //   * lane l then owns outputs [l*R, l*R+R): it walks its R+2N inputs once with ds_read_b128 and
 //     feeds each input into every accumulator it touches ("input stationary"): R accumulators in
 //     VGPRs, the 2N+1 taps in SGPRs (they arrive as a by-value kernel argument), one v_fmac per
@@ -241,6 +241,14 @@ struct Conv<double, N> {
     }
 };
 
+// Work distribution: ONE TILE PER WAVE, blocks dispatched in order (grid = total_tiles / 4).  Round 1 ran a persistent
+// grid (resident waves striding over the tiles, next tile prefetched into registers); measured on MI355X that shape caps a
+// read+write stream at 5.2-5.5 TB/s, while the same tiles handed out by the hardware dispatcher in block order stream at
+// 5.7-6.2 TB/s (tools/membench2.hip, tools/fmastream2.hip: 7.0 -> 6.5 ms for this kernel's bytes, FMAs and LDS traffic).
+// Latency is hidden across the 4 waves a SIMD holds, not inside a wave.  Blocks that share an XCD (blockIdx % 8, observed
+// round-robin placement) get neighbouring tiles -- each XCD sweeps its own eighth of the batch -- so the halo a tile shares
+// with its neighbour is an L2 hit; placement affects speed only.  Channel-end tiles (slower, see below) are simply tiles
+// that take longer; the dispatcher balances them.
 template <typename T, int N>
 __global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kernel(const Job1D job, const Taps taps)
 {
@@ -253,155 +261,116 @@ __global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kerne
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, lives in an SGPR
     char *slab = smem + wave * K::SLAB;
 
-    // blocks that share an XCD (blockIdx % 8, observed round-robin placement) get neighbouring
-    // tiles, so halos re-read by the next tile are L2 hits; placement affects speed only.
-    const unsigned nblk = gridDim.x;
-    const unsigned blk  = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
-    const unsigned nwaves = nblk * K::WAVES;
+    const unsigned nb8 = gridDim.x >> 3;
+    unsigned blk = blockIdx.x;
+    if (blk < nb8 * 8u) blk = (blk & 7u) * nb8 + (blk >> 3);
+    const unsigned tile = blk * K::WAVES + wave;
+    if (tile >= job.total_tiles) return;                                  // wave-uniform
 
     const T *__restrict__ gin  = static_cast<const T *>(job.in);
     T *__restrict__       gout = static_cast<T *>(job.out);
     const int L = (int)job.length;
     const int mode = (int)(job.flags & JOB_MODE_MASK);
 
-    VT p0, p1, p2, p3, p4, p5, p6, p7, p8;       // next tile, in flight while this one is computed
-
-    // Work distribution.  Round k covers tiles [k*nwaves, (k+1)*nwaves); inside a round a wave takes
-    // the tile at `slot`, and slots rotate by ROT from round to round.  Without the rotation a wave
-    // would always land on the same tile-in-channel index whenever nwaves and tiles_per_channel share
-    // factors, so the few waves that own channel ends (slower, see below) would own ONLY channel ends.
-    constexpr unsigned ROT = 67;
-    unsigned slot = blk * K::WAVES + wave;
-    unsigned base = 0;
-
-    // a tile is "full" when every 16-B vector of tile + halo lies inside the row: the common case
-    auto tile_is_full = [&](int ts) -> bool {
-        return (job.flags & JOB_VEC_IN) && ts - NA >= 0 && ts + TW + NA <= L;
-    };
-    auto prefetch = [&](unsigned t) {
-        const unsigned c = t / job.tiles_per_channel;
-        const int ts = (int)(t - c * job.tiles_per_channel) * TW;
-        if (tile_is_full(ts)) {
-            const VT *src = reinterpret_cast<const VT *>(gin + (long long)c * job.in_ld + (ts - NA));
-            p0 = ld_stream(src + lane);       p1 = ld_stream(src + lane + 64);  p2 = ld_stream(src + lane + 128);
-            p3 = ld_stream(src + lane + 192);
-            if constexpr (VPL > 4) { p4 = ld_stream(src + lane + 256); p5 = ld_stream(src + lane + 320); }
-            if constexpr (VPL > 6) { p6 = ld_stream(src + lane + 384); p7 = ld_stream(src + lane + 448); }
-            if (lane < 2 * HV) p8 = src[TV + lane];           // halo: re-read by the neighbour tile, keep it cached
-        }
-    };
-
-    if (base + slot < job.total_tiles) prefetch(base + slot);
-
 #ifdef SG_STAMPS
     const bool stamp_on = (blockIdx.x == 8 && wave == 1);
-    int stamp_it = -1;
+    const int stamp_it = 0;
 #endif
-    while (base + slot < job.total_tiles) {
-#ifdef SG_STAMPS
-        ++stamp_it;
-#endif
-        SG_STAMP(0);
-        const unsigned tile = base + slot;
-        const unsigned c = tile / job.tiles_per_channel;
-        const int ts = (int)(tile - c * job.tiles_per_channel) * TW;
-        const T *__restrict__ row = gin + (long long)c * job.in_ld;
+    SG_STAMP(0);
+    const unsigned c = tile / job.tiles_per_channel;
+    const int ts = (int)(tile - c * job.tiles_per_channel) * TW;
+    const T *__restrict__ row = gin + (long long)c * job.in_ld;
 
-        // ---- stage tile + halo into the slab ----
-        if (tile_is_full(ts)) {
-            auto put = [&](int s, const VT &v) { *reinterpret_cast<VT *>(slab + slab_vec_off<VPL>(lane + 64 * s)) = v; };
-            put(0, p0); put(1, p1); put(2, p2); put(3, p3);
-            if constexpr (VPL > 4) { put(4, p4); put(5, p5); }
-            if constexpr (VPL > 6) { put(6, p6); put(7, p7); }
-            if (lane < 2 * HV) put(VPL, p8);
-        } else {
-            // Channel ends, short rows, rows without 16-B alignment.  Vectors that lie wholly inside the
-            // row are still moved as vectors; the rest (the part of the halo that sticks out of the row,
-            // remapped per boundary mode; everything if the row is unaligned) goes element by element.
-            const bool vec = (job.flags & JOB_VEC_IN) != 0;
-            const int lim = L + NA;                                      // nothing beyond is ever used
+    // ---- stage tile + halo into the slab ----
+    // a tile is "full" when every 16-B vector of tile + halo lies inside the row: the common case
+    if ((job.flags & JOB_VEC_IN) && ts - NA >= 0 && ts + TW + NA <= L) {
+        const VT *src = reinterpret_cast<const VT *>(row + (ts - NA));
+        VT p[VPL + 1];
 #pragma unroll
-            for (int s = 0; s < VPL + 1; ++s) {
-                const int v = lane + 64 * s;
-                const int g0 = ts - NA + v * E;
-                if (v < K::SV && vec && g0 >= 0 && g0 + E <= L)
-                    *reinterpret_cast<VT *>(slab + slab_vec_off<VPL>(v)) = *reinterpret_cast<const VT *>(row + g0);
-            }
+        for (int s = 0; s < VPL; ++s) p[s] = ld_stream(src + lane + 64 * s);
+        if (lane < 2 * HV) p[VPL] = src[TV + lane];                       // halo: re-read by the neighbour tile, keep it cached
+#pragma unroll
+        for (int s = 0; s < VPL; ++s) *reinterpret_cast<VT *>(slab + slab_vec_off<VPL>(lane + 64 * s)) = p[s];
+        if (lane < 2 * HV) *reinterpret_cast<VT *>(slab + slab_vec_off<VPL>(lane + 64 * VPL)) = p[VPL];
+    } else {
+        // Channel ends, short rows, rows without 16-B alignment.  Vectors that lie wholly inside the
+        // row are still moved as vectors; the rest (the part of the halo that sticks out of the row,
+        // remapped per boundary mode; everything if the row is unaligned) goes element by element.
+        const bool vec = (job.flags & JOB_VEC_IN) != 0;
+        const int lim = L + NA;                                      // nothing beyond is ever used
+#pragma unroll
+        for (int s = 0; s < VPL + 1; ++s) {
+            const int v = lane + 64 * s;
+            const int g0 = ts - NA + v * E;
+            if (v < K::SV && vec && g0 >= 0 && g0 + E <= L)
+                *reinterpret_cast<VT *>(slab + slab_vec_off<VPL>(v)) = *reinterpret_cast<const VT *>(row + g0);
+        }
 #pragma unroll 4
-            for (int e = lane; e < K::SL; e += 64) {
-                int g = ts - NA + e;
-                const int g0 = g - (e % E);
-                const bool direct = vec && g0 >= 0 && g0 + E <= L;
-                if (!direct && g < lim) {
-                    bool zero = false;
-                    if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
-                    const T x = zero ? T(0) : row[g];
-                    *reinterpret_cast<T *>(slab + slab_vec_off<VPL>(e / E) + (e % E) * (int)sizeof(T)) = x;
-                }
+        for (int e = lane; e < K::SL; e += 64) {
+            int g = ts - NA + e;
+            const int g0 = g - (e % E);
+            const bool direct = vec && g0 >= 0 && g0 + E <= L;
+            if (!direct && g < lim) {
+                bool zero = false;
+                if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
+                const T x = zero ? T(0) : row[g];
+                *reinterpret_cast<T *>(slab + slab_vec_off<VPL>(e / E) + (e % E) * (int)sizeof(T)) = x;
             }
         }
-        SG_STAMP(1);
-        // next round
-        unsigned nslot = slot + ROT;
-        if (nslot >= nwaves) nslot -= nwaves;
-        const unsigned nbase = base + nwaves;
-        if (nbase + nslot < job.total_tiles) prefetch(nbase + nslot);
-        wave_lds_sync();
-        SG_STAMP(2);
+    }
+    SG_STAMP(1);
+    wave_lds_sync();
+    SG_STAMP(2);
 
-        // ---- the convolution: lane owns outputs [lane*R, lane*R + R) of the tile ----
-        T acc[R];
-        if constexpr (sizeof(T) == 8) Conv<T, N>::run(slab + 16 * (lane * (VPL + 1)), taps, acc, (job.flags & JOB_ODD_TAPS) ? 0x80000000u : 0u);
-        else Conv<T, N>::run(slab + 16 * (lane * (VPL + 1)), taps, acc);
-        if (job.flags & JOB_SCALE) {
-            const T s = (T)job.dt_inv;
+    // ---- the convolution: lane owns outputs [lane*R, lane*R + R) of the tile ----
+    T acc[R];
+    if constexpr (sizeof(T) == 8) Conv<T, N>::run(slab + 16 * (lane * (VPL + 1)), taps, acc, (job.flags & JOB_ODD_TAPS) ? 0x80000000u : 0u);
+    else Conv<T, N>::run(slab + 16 * (lane * (VPL + 1)), taps, acc);
+    if (job.flags & JOB_SCALE) {
+        const T s = (T)job.dt_inv;
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] *= s;
-        }
-        wave_lds_sync();                                   // all window reads done before overwrite
-        SG_STAMP(3);
+        for (int r = 0; r < R; ++r) acc[r] *= s;
+    }
+    wave_lds_sync();                                   // all window reads done before overwrite
+    SG_STAMP(3);
 
-        // ---- results back through the slab, then coalesced rows to HBM ----
+    // ---- results back through the slab, then coalesced rows to HBM ----
+#pragma unroll
+    for (int s = 0; s < VPL; ++s) {
+        VT o;
+#pragma unroll
+        for (int e = 0; e < E; ++e) vset(o, e, acc[s * E + e]);
+        *reinterpret_cast<VT *>(slab + 16 * (lane * (VPL + 1) + s)) = o;
+    }
+    wave_lds_sync();
+    T *__restrict__ orow = gout + (long long)c * job.out_ld - (long long)job.out_shift;
+    const int lo = (int)job.store_lo, hi = (int)job.store_hi;
+    const bool whole = (job.flags & JOB_VEC_OUT) && ts >= lo && ts + TW <= hi;
+    if (whole) {
 #pragma unroll
         for (int s = 0; s < VPL; ++s) {
-            VT o;
-#pragma unroll
-            for (int e = 0; e < E; ++e) vset(o, e, acc[s * E + e]);
-            *reinterpret_cast<VT *>(slab + 16 * (lane * (VPL + 1) + s)) = o;
+            const int p = lane + 64 * s;
+            const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(p));
+            st_stream(reinterpret_cast<VT *>(orow + ts + p * E), o);
         }
-        wave_lds_sync();
-        T *__restrict__ orow = gout + (long long)c * job.out_ld - (long long)job.out_shift;
-        const int lo = (int)job.store_lo, hi = (int)job.store_hi;
-        const bool whole = (job.flags & JOB_VEC_OUT) && ts >= lo && ts + TW <= hi;
-        if (whole) {
+    } else {
+        // first / last tile of a channel (the stored range ends inside it) or unaligned output rows
+        const bool vec = (job.flags & JOB_VEC_OUT) != 0;
 #pragma unroll
-            for (int s = 0; s < VPL; ++s) {
-                const int p = lane + 64 * s;
-                const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(p));
-                st_stream(reinterpret_cast<VT *>(orow + ts + p * E), o);
-            }
-        } else {
-            // first / last tile of a channel (the stored range ends inside it) or unaligned output rows
-            const bool vec = (job.flags & JOB_VEC_OUT) != 0;
+        for (int s = 0; s < VPL; ++s) {
+            const int p = lane + 64 * s;
+            const int g0 = ts + p * E;
+            const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(p));
+            if (vec && g0 >= lo && g0 + E <= hi) {
+                *reinterpret_cast<VT *>(orow + g0) = o;
+            } else {
 #pragma unroll
-            for (int s = 0; s < VPL; ++s) {
-                const int p = lane + 64 * s;
-                const int g0 = ts + p * E;
-                const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(p));
-                if (vec && g0 >= lo && g0 + E <= hi) {
-                    *reinterpret_cast<VT *>(orow + g0) = o;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < E; ++e)
-                        if (g0 + e >= lo && g0 + e < hi) orow[g0 + e] = vget(o, e);
-                }
+                for (int e = 0; e < E; ++e)
+                    if (g0 + e >= lo && g0 + e < hi) orow[g0 + e] = vget(o, e);
             }
         }
-        wave_lds_sync();                                   // slab is free for the next tile
-        SG_STAMP(4);
-        slot = nslot;
-        base = nbase;
     }
+    SG_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------
