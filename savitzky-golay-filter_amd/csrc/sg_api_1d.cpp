@@ -144,7 +144,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     job.in_ld = (long long)in_ld;
     job.out_ld = (long long)out_ld;
     job.length = (unsigned)length;
-    job.tiles_per_channel = (unsigned)((length + TW - 1) / TW);
+    sg::set_tiles_per_channel(job, (unsigned)((length + TW - 1) / TW));
     job.dt_inv = dt_inverse(f);
     // which samples the centre kernel stores: the interior when edge rows / VALID take the rest
     const bool interior_only = (variant == VALID) || poly;

@@ -169,7 +169,8 @@ struct Conv<float, N> {
     {
         if constexpr (J < K::R / 2) {
             constexpr int k = I - 2 * J - K::OFF;
-            if constexpr (k >= 0 && k <= 2 * N) pk_fma_sgpr<(k & 1)>(A[J], W[k >> 1], x);
+            if constexpr (k == 0) A[J] = pk_mul_sgpr<0>(W[0], x);          // first term of this pair: no zero-initialised accumulator
+            else if constexpr (k > 0 && k <= 2 * N) pk_fma_sgpr<(k & 1)>(A[J], W[k >> 1], x);
             feed<I, J + 1>(A, W, x);
         }
     }
@@ -194,8 +195,6 @@ struct Conv<float, N> {
 #pragma unroll
         for (int p = 0; p < 33; ++p) W[p] = f32x2{taps.w[2 * p], taps.w[2 * p + 1]};
         f32x2 A[K::R / 2];
-#pragma unroll
-        for (int j = 0; j < K::R / 2; ++j) A[j] = f32x2{0.0f, 0.0f};
         quads<0>(win, A, W, f32x2{0.0f, 0.0f});
 #pragma unroll
         for (int j = 0; j < K::R / 2; ++j) { acc[2 * j] = A[j].x; acc[2 * j + 1] = A[j].y; }
@@ -277,9 +276,16 @@ __global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kerne
     const int stamp_it = 0;
 #endif
     SG_STAMP(0);
-    const unsigned c = tile / job.tiles_per_channel;
+    const unsigned c = job.tpc_shift >= 32 ? tile : (__umulhi(tile, job.tpc_magic) >> job.tpc_shift);   // tile / tiles_per_channel, on the scalar unit
     const int ts = (int)(tile - c * job.tiles_per_channel) * TW;
     const T *__restrict__ row = gin + (long long)c * job.in_ld;
+    // slab byte offset of vector lane + 64*s: when VPL divides 64 the pad count splits, (lane + 64 s)/VPL = lane/VPL + s*64/VPL,
+    // so one VGPR holds the lane part and s goes into the instruction's immediate offset
+    char *const slab_row = slab + slab_vec_off<VPL>(lane);
+    auto row_vec = [&](int s) -> VT * {
+        if constexpr (64 % VPL == 0) return reinterpret_cast<VT *>(slab_row + s * (16 * (64 + 64 / VPL)));
+        else return reinterpret_cast<VT *>(slab + slab_vec_off<VPL>(lane + 64 * s));
+    };
 
     // ---- stage tile + halo into the slab ----
     // a tile is "full" when every 16-B vector of tile + halo lies inside the row: the common case
@@ -290,8 +296,8 @@ __global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kerne
         for (int s = 0; s < VPL; ++s) p[s] = ld_stream(src + lane + 64 * s);
         if (lane < 2 * HV) p[VPL] = src[TV + lane];                       // halo: re-read by the neighbour tile, keep it cached
 #pragma unroll
-        for (int s = 0; s < VPL; ++s) *reinterpret_cast<VT *>(slab + slab_vec_off<VPL>(lane + 64 * s)) = p[s];
-        if (lane < 2 * HV) *reinterpret_cast<VT *>(slab + slab_vec_off<VPL>(lane + 64 * VPL)) = p[VPL];
+        for (int s = 0; s < VPL; ++s) *row_vec(s) = p[s];
+        if (lane < 2 * HV) *row_vec(VPL) = p[VPL];
     } else {
         // Channel ends, short rows, rows without 16-B alignment.  Vectors that lie wholly inside the
         // row are still moved as vectors; the rest (the part of the halo that sticks out of the row,
@@ -349,9 +355,8 @@ __global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kerne
     if (whole) {
 #pragma unroll
         for (int s = 0; s < VPL; ++s) {
-            const int p = lane + 64 * s;
-            const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(p));
-            st_stream(reinterpret_cast<VT *>(orow + ts + p * E), o);
+            const VT o = *row_vec(s);
+            st_stream(reinterpret_cast<VT *>(orow + ts) + lane + 64 * s, o);
         }
     } else {
         // first / last tile of a channel (the stored range ends inside it) or unaligned output rows

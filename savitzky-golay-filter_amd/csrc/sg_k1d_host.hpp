@@ -29,11 +29,27 @@ struct Job1D {
     unsigned    length;                 // samples per channel (< 2^31, as in the reference's int indexing)
     unsigned    tiles_per_channel;
     unsigned    total_tiles;            // channels * tiles_per_channel (< 2^31, the host splits bigger jobs)
+    unsigned    tpc_magic, tpc_shift;   // tile / tiles_per_channel == umulhi(tile, tpc_magic) >> tpc_shift  (set_tiles_per_channel)
     unsigned    store_lo, store_hi;     // sample indices g whose result is stored ...
     unsigned    out_shift;              // ... at out[c*out_ld + g - out_shift]
     float       dt_inv;
     unsigned    flags;                  // FLAG_* below; boundary mode in the low byte
 };
+// Division by an invariant on the scalar unit (gfx950 has s_mul_hi_u32 but no scalar divide; left as `/` the compiler
+// runs the float-reciprocal sequence on the VECTOR unit, ~25 instructions per tile in a kernel that is VALU-issue bound).
+// For 0 <= t < 2^31 and 2^(l-1) < d <= 2^l:  floor(t / d) == (t * ceil(2^(31+l) / d)) >> (31 + l), and the multiplier
+// fits 32 bits; d == 1 is flagged with shift 32.
+inline void set_tiles_per_channel(Job1D &job, unsigned d)
+{
+    job.tiles_per_channel = d;
+    if (d <= 1) { job.tpc_magic = 0; job.tpc_shift = 32; return; }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned long long p = 1ull << (31 + l);
+    job.tpc_magic = (unsigned)((p + d - 1) / d);
+    job.tpc_shift = l - 1;
+}
+
 enum : unsigned {
     JOB_MODE_MASK  = 0xffu,             // SavgolBoundaryMode value; 0/unknown: out-of-range reads are 0
     JOB_SCALE      = 1u << 8,           // multiply by dt_inv (dt_inv != 1)
