@@ -39,12 +39,23 @@ const char *savgol_hip_version(void);
  * mathematically correct sign.  (The reference applies the trailing-edge rows to reversed data, which negates odd
  * derivatives on the leading edge -- src/savgolFilter.c:773-777)  Affects the 1-D batch / apply
  * entry points only; the streaming path keeps the reference behaviour.                                           */
-enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1, SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2 };
+enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1, SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2, SAVGOL_HIP_OPT_PLAIN_SUMMATION = 3 };
 /* SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 1: the fp32 1-D batch / valid / strided DEVICE entry points sum each output in
  * the reference's own order (convolve_ilp, src/savgolFilter.c:547-580: four chains, separate multiply and add) and are
  * then bit-identical to the reference's savgol_apply; 1.5x (n=5) to 2.1x (n=32) slower than the default FMA kernel, which
- * agrees with it to 1e-6.  The host-pointer drop-in calls of savgolFilter.h always use that order.                             */
+ * agrees with it to 1e-6.  The host-pointer drop-in calls of savgolFilter.h always use that order.
+ * SAVGOL_HIP_OPT_PLAIN_SUMMATION = 1: the fp32 batch kernel at half_window 32 applies all 65 taps one by one.  By default it
+ * replaces the 32 taps that fall on a lane's own 32-sample block by block moments (the taps are a polynomial of degree
+ * <= poly_order in the tap index; csrc/sg_k1d_moment.hpp): 43 instead of 65 multiply-adds per output at poly_order 4, the same
+ * 1e-6 agreement with the fp64 oracle, different last bits.  Filters whose table is not such a polynomial (hand-edited
+ * center_weights), poly_order > 6 and every other half window always use the plain sum.                                       */
 int         savgol_hip_set_option(int option, int value);
+/* Diagnostic (host only, no device needed): the constant table the half_window = 32 fp32 kernel reads -- SAVGOL_HIP_MOMENT_TABLE_FLOATS
+ * floats: centre taps [0,66), block basis phi[s-1][t] at [80,176), own-block coefficients c[s][J][2] at [176,400); layout in
+ * csrc/sg_k1d_host.hpp.  Returns the number of block moments the kernel will use (3, 5 or 7), 0 when the filter runs the
+ * plain 65-tap sum (other half windows, poly_order > 6, tables that are not a polynomial), -1 on NULL.                        */
+#define SAVGOL_HIP_MOMENT_TABLE_FLOATS 400
+int         savgol_hip_moment_table(const SavgolFilter *filter, float *table);
 
 /* ---------------------------------------------------------------- 1-D batch ----------- *
  * channels independent signals, row-major: sample i of channel c at base[c*ld + i].

@@ -25,6 +25,7 @@ SAVGOL_BOUNDARY_POLYNOMIAL, SAVGOL_BOUNDARY_REFLECT, SAVGOL_BOUNDARY_PERIODIC, S
 SAVGOL2D_BOUNDARY_VALID, SAVGOL2D_BOUNDARY_CONSTANT, SAVGOL2D_BOUNDARY_REFLECT = 0, 1, 2
 SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1
 SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2
+SAVGOL_HIP_OPT_PLAIN_SUMMATION = 3
 
 
 class SavgolConfig(C.Structure):
@@ -97,6 +98,7 @@ SIGNATURES = {
     "savgol_hip_last_error": (C.c_char_p, []),
     "savgol_hip_version": (C.c_char_p, []),
     "savgol_hip_set_option": (C.c_int, [C.c_int, C.c_int]),
+    "savgol_hip_moment_table": (C.c_int, [_F, _fp]),
     # savgol_hip.h: 1-D batch
     "savgol_apply_batch_f32": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "savgol_apply_batch_f64": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "sg_k1d_host.hpp"
 #include "sg_runtime.hpp"
@@ -63,6 +65,24 @@ namespace {
 
 std::atomic<int> g_correct_leading_edge{0};
 std::atomic<int> g_reference_summation{0};      // SAVGOL_HIP_OPT_REFERENCE_SUMMATION: batch f32 calls in the reference's order
+std::atomic<int> g_plain_summation{0};          // SAVGOL_HIP_OPT_PLAIN_SUMMATION: no block moments at half_window 32
+
+// half_window = 32 fast path: the polynomial fit of a filter's centre taps (sg_k1d_moment_fit.cpp), cached per table content
+struct MomentFit { float w[SAVGOL_MAX_WINDOW]; int terms; float table[sg::MOMENT_TABLE_FLOATS]; };
+std::mutex g_moment_mu;
+std::vector<MomentFit *> g_moment_fits;         // never shrinks: one entry (1.9 KB) per distinct n = 32 filter of the process
+
+const MomentFit *moment_fit(const SavgolFilter *f)
+{
+    std::lock_guard<std::mutex> lock(g_moment_mu);
+    for (const MomentFit *m : g_moment_fits)
+        if (memcmp(m->w, f->center_weights, sizeof(float) * SAVGOL_MAX_WINDOW) == 0) return m;
+    MomentFit *m = new MomentFit();
+    memcpy(m->w, f->center_weights, sizeof(float) * SAVGOL_MAX_WINDOW);
+    m->terms = sg1d_moment_prepare(f->center_weights, m->table);
+    g_moment_fits.push_back(m);
+    return m;
+}
 
 enum Variant { FULL = 0, VALID = 1, FULL_POLY_EDGES = 2 /* strided: polynomial edges whatever the mode */ };
 
@@ -187,6 +207,18 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         if (!d_edges) return -1;
     }
 
+    // half_window 32, fp32: block moments replace the 32 taps on each lane's own block when the table is a polynomial
+    const float *d_moment = nullptr;
+    int moment_terms = 0;
+    if (sizeof(T) == 4 && n == SAVGOL_MAX_HALF_WINDOW && !g_plain_summation.load()) {
+        const MomentFit *mf = moment_fit(f);
+        if (mf->terms) {
+            d_moment = sg::ctx_table(ctx, mf->table, sizeof(mf->table), 0x1f00u);
+            if (!d_moment) return -1;
+            moment_terms = mf->terms;
+        }
+    }
+
     // split so that a launch indexes < 2^31 tiles
     const size_t max_ch = (size_t)0x7fffffffu / job.tiles_per_channel;
     for (size_t c0 = 0; c0 < channels; c0 += max_ch) {
@@ -197,7 +229,9 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         // one tile per wave, four waves per block, blocks dispatched in order (see sg1d_center_kernel)
         unsigned blocks = (job.total_tiles + 3u) / 4u;
         blocks = (blocks + 7u) & ~7u;                                    // the XCD remap wants a multiple of 8
-        if (sg::launch_center<T>(n, job, taps, blocks, st) != 0) return -1;
+        if (d_moment) {
+            if (sg1d_launch_f32_moment(moment_terms, &job, d_moment, blocks, st) != 0) return -1;
+        } else if (sg::launch_center<T>(n, job, taps, blocks, st) != 0) return -1;
     }
     if (d_edges) {
         // bit 0: multiply by dt_inv; bit 1: negate the leading-edge outputs (SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE, odd d only)
@@ -217,8 +251,16 @@ int savgol_hip_set_option(int option, int value)
 {
     if (option == SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE) { g_correct_leading_edge.store(value != 0); return 0; }
     if (option == SAVGOL_HIP_OPT_REFERENCE_SUMMATION) { g_reference_summation.store(value != 0); return 0; }
+    if (option == SAVGOL_HIP_OPT_PLAIN_SUMMATION) { g_plain_summation.store(value != 0); return 0; }
     sg_set_error("savgol_hip_set_option: unknown option %d", option);
     return -1;
+}
+
+int savgol_hip_moment_table(const SavgolFilter *filter, float *table)
+{
+    if (!filter || !table) { sg_set_error("savgol_hip_moment_table: NULL pointer"); return -1; }
+    if (filter->config.half_window != SAVGOL_MAX_HALF_WINDOW) return 0;
+    return sg1d_moment_prepare(filter->center_weights, table);
 }
 
 int savgol_apply_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out, size_t channels, size_t length,

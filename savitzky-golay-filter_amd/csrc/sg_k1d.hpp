@@ -248,8 +248,8 @@ struct Conv<double, N> {
 // round-robin placement) get neighbouring tiles -- each XCD sweeps its own eighth of the batch -- so the halo a tile shares
 // with its neighbour is an L2 hit; placement affects speed only.  Channel-end tiles (slower, see below) are simply tiles
 // that take longer; the dispatcher balances them.
-template <typename T, int N>
-__global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kernel(const Job1D job, const Taps taps)
+template <typename T, int N, typename CV>
+__device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename CV::Args &taps)
 {
     typedef K1D<T, N> K;
     typedef typename K::VT VT;
@@ -330,8 +330,7 @@ __global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kerne
 
     // ---- the convolution: lane owns outputs [lane*R, lane*R + R) of the tile ----
     T acc[R];
-    if constexpr (sizeof(T) == 8) Conv<T, N>::run(slab + 16 * (lane * (VPL + 1)), taps, acc, (job.flags & JOB_ODD_TAPS) ? 0x80000000u : 0u);
-    else Conv<T, N>::run(slab + 16 * (lane * (VPL + 1)), taps, acc);
+    CV::run(slab + 16 * (lane * (VPL + 1)), taps, acc, job.flags);
     if (job.flags & JOB_SCALE) {
         const T s = (T)job.dt_inv;
 #pragma unroll
@@ -376,6 +375,23 @@ __global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kerne
         }
     }
     SG_STAMP(4);
+}
+
+// the plain sliding dot product: every output is 2N+1 multiply-adds (Conv<T, N> above)
+template <typename T, int N>
+struct DirectConv {
+    typedef Taps Args;
+    static __device__ __forceinline__ void run(const char *win, const Taps &taps, T (&acc)[K1D<T, N>::R], unsigned flags)
+    {
+        if constexpr (sizeof(T) == 8) Conv<T, N>::run(win, taps, acc, (flags & JOB_ODD_TAPS) ? 0x80000000u : 0u);
+        else Conv<T, N>::run(win, taps, acc);
+    }
+};
+
+template <typename T, int N>
+__global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kernel(const Job1D job, const Taps taps)
+{
+    sg1d_tile_body<T, N, DirectConv<T, N>>(job, taps);
 }
 
 // ---------------------------------------------------------------------------------------------

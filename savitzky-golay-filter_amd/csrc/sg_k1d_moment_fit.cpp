@@ -1,0 +1,125 @@
+// sg_k1d_moment_fit.cpp -- host side of the half_window = 32 fast path (sg_k1d_moment.hpp): recover the polynomial behind a
+// filter's 65 fp32 centre taps and re-express its 32-tap pieces in the Legendre basis of a 32-sample block.  Double
+// precision throughout; the results are rounded to fp32 once, when the table is written.
+//
+// The taps are w[k] = p(k) + rounding, p of degree <= poly_order (reference compute_weight, src/savgolFilter.c:336-356).
+// Nothing here trusts that: the degree is found by fitting (3, 5, then 7 terms) and the fit must reproduce every tap to
+// 3e-7 of the largest one -- the size of the fp32 rounding already in the reference's table -- or the caller keeps the
+// plain kernel.  Hand-edited tables therefore still run, just not on this path.
+#include <cmath>
+#include <cstring>
+
+#include "sg_k1d_host.hpp"
+
+namespace {
+
+constexpr int N = 32, WS = 65, BLOCK = 32, MAXT = sg::MOMENT_MAX_TERMS;
+
+void legendre(double z, int terms, double *P)          // P[s] = P_s(z), s < terms
+{
+    P[0] = 1.0;
+    if (terms > 1) P[1] = z;
+    for (int s = 2; s < terms; ++s) P[s] = ((2 * s - 1) * z * P[s - 1] - (s - 1) * P[s - 2]) / s;
+}
+
+// solve G x = b (G symmetric positive definite, terms x terms) by Gaussian elimination with partial pivoting
+bool solve(int terms, const double (*G)[MAXT], const double *b, double *x)
+{
+    double a[MAXT][MAXT + 1];
+    for (int i = 0; i < terms; ++i) { for (int j = 0; j < terms; ++j) a[i][j] = G[i][j]; a[i][terms] = b[i]; }
+    for (int c = 0; c < terms; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < terms; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (std::fabs(a[piv][c]) < 1e-300) return false;
+        if (piv != c) for (int j = 0; j <= terms; ++j) { const double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+        for (int r = c + 1; r < terms; ++r) {
+            const double f = a[r][c] / a[c][c];
+            for (int j = c; j <= terms; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = terms - 1; i >= 0; --i) {
+        double s = a[i][terms];
+        for (int j = i + 1; j < terms; ++j) s -= a[i][j] * x[j];
+        x[i] = s / a[i][i];
+    }
+    return true;
+}
+
+// least-squares coefficients of y[0..count) on P_s(z_i), s < terms
+bool fit(int terms, int count, const double *z, const double *y, double *coef)
+{
+    double G[MAXT][MAXT] = {}, b[MAXT] = {}, P[MAXT];
+    for (int i = 0; i < count; ++i) {
+        legendre(z[i], terms, P);
+        for (int s = 0; s < terms; ++s) { b[s] += P[s] * y[i]; for (int t = 0; t < terms; ++t) G[s][t] += P[s] * P[t]; }
+    }
+    return solve(terms, G, b, coef);
+}
+
+}  // namespace
+
+extern "C" int sg1d_moment_prepare(const float *w, float *table)
+{
+    double zk[WS], wk[WS], wmax = 0.0;
+    for (int k = 0; k < WS; ++k) {
+        zk[k] = (double)(k - N) / N; wk[k] = (double)w[k];
+        if (!std::isfinite(wk[k])) return 0;
+        if (std::fabs(wk[k]) > wmax) wmax = std::fabs(wk[k]);
+    }
+    if (wmax == 0.0) return 0;
+    int terms = 0;
+    double coef[MAXT] = {};
+    for (int t : {3, 5, 7}) {
+        double c[MAXT] = {}, P[MAXT];
+        if (!fit(t, WS, zk, wk, c)) continue;
+        double worst = 0.0;
+        for (int k = 0; k < WS; ++k) {
+            legendre(zk[k], t, P);
+            double v = 0.0;
+            for (int s = 0; s < t; ++s) v += c[s] * P[s];
+            worst = std::fmax(worst, std::fabs(v - wk[k]));
+        }
+        if (worst <= 3e-7 * wmax) { terms = t; memcpy(coef, c, sizeof(coef)); break; }
+    }
+    if (!terms) return 0;
+    auto p = [&](double k) {                       // the polynomial behind the taps, at a real tap index
+        double P[MAXT], v = 0.0;
+        legendre((k - N) / N, terms, P);
+        for (int s = 0; s < terms; ++s) v += coef[s] * P[s];
+        return v;
+    };
+
+    memset(table, 0, sizeof(float) * sg::MOMENT_TABLE_FLOATS);
+    for (int k = 0; k < WS; ++k) table[sg::MOMENT_OFF_W + k] = w[k];
+    // block basis phi_s(t) = P_s((t - 15.5) / 16), t = 0..31; the kernel reads t < 16 and mirrors the rest
+    double zt[BLOCK];
+    for (int t = 0; t < BLOCK; ++t) zt[t] = (t - 15.5) / 16.0;
+    for (int t = 0; t < 16; ++t) {
+        double P[MAXT];
+        legendre(zt[t], terms, P);
+        for (int s = 1; s < terms; ++s) table[sg::MOMENT_OFF_PHI + (s - 1) * 16 + t] = (float)P[s];
+    }
+    // Output r of a lane reads its own block X[32 + t] with tap w[t - r + 32]: q_r(t) = p(t - r + 32), a polynomial of degree
+    // < terms in t, so its coefficients in the block basis are exact (the least-squares system has a zero residual).  The
+    // moments the kernel forms use the fp32-ROUNDED phi, so the coefficients are solved against those same rounded values:
+    // sum_s c_s(r) * phi32_s(t) then equals q_r(t) in the least-squares sense on the 32 block samples.
+    for (int r = 0; r < 32; ++r) {
+        double G[MAXT][MAXT] = {}, b[MAXT] = {}, c[MAXT] = {};
+        for (int t = 0; t < BLOCK; ++t) {
+            double P[MAXT], Pr[MAXT];
+            legendre(zt[t], terms, P);
+            const int tm = t < 16 ? t : 31 - t;
+            Pr[0] = 1.0;
+            for (int s = 1; s < terms; ++s) {
+                const double v = (double)table[sg::MOMENT_OFF_PHI + (s - 1) * 16 + tm];
+                Pr[s] = (t < 16 || !(s & 1)) ? v : -v;
+            }
+            (void)P;
+            const double q = p((double)(t - r + N));
+            for (int s = 0; s < terms; ++s) { b[s] += Pr[s] * q; for (int u = 0; u < terms; ++u) G[s][u] += Pr[s] * Pr[u]; }
+        }
+        if (!solve(terms, G, b, c)) return 0;
+        for (int s = 0; s < terms; ++s) table[sg::MOMENT_OFF_C + s * 32 + (r >> 1) * 2 + (r & 1)] = (float)c[s];
+    }
+    return terms;
+}

@@ -56,24 +56,27 @@ static uint64_t fnv1a(const void *p, size_t n, uint64_t h)
     return h;
 }
 
+// Entries are never freed while the process lives: callers keep the returned pointer past the call -- a stream bank for its
+// whole life, a captured hipGraph for as long as it is replayed, a launch that is still queued -- so evicting (round 1 dropped
+// the oldest half at 256 entries) handed out memory that later kernels still read.  A table is at most 9 KB and there is one
+// per distinct filter content, so the cache of a process that builds ten thousand different filters is < 100 MB.  A hit
+// compares the content, not just the 64-bit key.
 const float *ctx_table(DeviceCtx *ctx, const void *host, size_t bytes, uint64_t salt)
 {
     const uint64_t key = fnv1a(host, bytes, 0xcbf29ce484222325ull ^ salt);
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     for (const TableEntry &t : ctx->tables)
-        if (t.key == key && t.bytes == bytes) return t.dev;
-    if (ctx->tables.size() >= 256) {               // bounded: drop the oldest half
-        if (!hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize")) return nullptr;
-        for (size_t i = 0; i < 128; ++i) (void)hipFree(ctx->tables[i].dev);
-        ctx->tables.erase(ctx->tables.begin(), ctx->tables.begin() + 128);
-    }
+        if (t.key == key && t.bytes == bytes && memcmp(t.host.data(), host, bytes) == 0) return t.dev;
     float *dev = nullptr;
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&dev), bytes), "hipMalloc(weight table)")) return nullptr;
     if (!hip_ok(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(weight table)")) {
         (void)hipFree(dev);
         return nullptr;
     }
-    ctx->tables.push_back(TableEntry{key, bytes, dev});
+    TableEntry e;
+    e.key = key; e.bytes = bytes; e.dev = dev;
+    e.host.assign(static_cast<const unsigned char *>(host), static_cast<const unsigned char *>(host) + bytes);
+    ctx->tables.push_back(std::move(e));
     return dev;
 }
 

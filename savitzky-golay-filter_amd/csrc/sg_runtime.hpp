@@ -13,10 +13,11 @@
 
 namespace sg {
 
-struct TableEntry {            // one uploaded float table (edge rows, 2-D kernels, separable factors)
+struct TableEntry {            // one uploaded float table (edge rows, 2-D kernels, separable factors); lives as long as the process
     uint64_t key;
     size_t   bytes;
     float   *dev;
+    std::vector<unsigned char> host;    // the content, compared on a key hit
 };
 
 struct DeviceCtx {
