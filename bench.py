@@ -3,18 +3,22 @@
 4096 channels x 2^20 fp32 samples per GPU, half_window=32, poly_order=4, all four boundary modes),
 with the HBM-roofline fraction of the dominant kernel and the reference's CPU path timed beside it.
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python bench.py --workload stream | image        (secondary: BASELINE configs 3 / 4 on one GPU)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W]          N > 1: this process starts the N ranks itself
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (the driver's form)
+    python bench.py --workload batch1d_f64 | stream | image [--rowband]      the other BASELINE configs as the main line
 
 A step = one pass of savgol_apply_batch_f32 over the whole resident batch in EACH of the four boundary
 modes (4 launches of the centre kernel + the tiny polynomial edge kernel).  Inputs are generated in HBM
 before the timed region.  Channels are independent: with N GPUs every rank owns its own 4096 channels
-(weak scaling, no data-path collective); rank 0 prints one JSON line.
+(weak scaling, no data-path collective); rank 0 prints one JSON line.  At N = 1 that line also carries, under
+"extra", BASELINE configs 1, 3, 4 and the per-GPU slice of config 5, each with its own roofline and CPU baseline
+(--no-extra skips them).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,24 +33,33 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 N, M, D = 32, 4, 0
 
 
-def cpu_baseline(length, deriv=D, budget_s=12.0):
-    """The reference's own savgol_apply (oracle/_ref, gcc -O2, 1 thread -- the reference has no threading)
-    on a bounded sample of the same workload: as many 2^20-sample channels of config 2 as fit in ~12 s."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU legs: the reference's own code (oracle/_ref/libsavgol_ref.so, gcc -O2) on the host cores of this box
+# ---------------------------------------------------------------------------------------------------------------
+def _ref():
+    """(ctypes lib of the compiled reference, make_golden helpers) or (None, None) when it did not travel."""
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsavgol_ref.so")):
+        from tests.golden import make_golden as mg
+        return mg.load(), mg
+    return None, None
+
+
+def cpu_baseline(length, n=N, m=M, deriv=D, budget_s=12.0, all_cores=True):
+    """The reference's savgol_apply (1 thread -- the reference has no threading) on a bounded sample of the same
+    workload: as many `length`-sample channels as fit in ~budget_s."""
     import ctypes as C
     from oracle import sgo
     x = sgo.synth_f32(0, 1, length)[0]
     y = np.empty_like(x)
-    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libsavgol_ref.so")
-    if os.path.exists(ref_lib):
-        from tests.golden import make_golden as mg
-        L = mg.load()
-        cfg = mg.Cfg(N, M, deriv, 1.0, 0)
+    L, mg = _ref()
+    if L is not None:
+        cfg = mg.Cfg(n, m, deriv, 1.0, 0)
         f = L.savgol_create(C.byref(cfg))
         run = lambda: L.savgol_apply(f, mg.fptr(x), mg.fptr(y), length)
         kind = "reference"
     else:
-        f = sgo.Filter(N, M, deriv)
-        run = lambda: f.apply(x)
+        flt = sgo.Filter(n, m, deriv)
+        run = lambda: flt.apply(x)
         kind = "port"
     run()
     n_done, t0 = 0, time.perf_counter()
@@ -56,11 +69,11 @@ def cpu_baseline(length, deriv=D, budget_s=12.0):
         if el > budget_s:
             break
     out = {"value": round(n_done * length / el / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
-           "sample": f"{n_done} channels x {length} fp32 samples (the reference is fp32 only; n={N}, m={M}, d={deriv}, POLYNOMIAL), "
+           "sample": f"{n_done} channels x {length} fp32 samples (the reference is fp32 only; n={n}, m={m}, d={deriv}, POLYNOMIAL), "
                      f"savgol_apply back to back for {el:.1f} s, 1 thread"}
     # the same call from one thread per host core, each on its own channel (the reference has no threading
     # of its own; savgol_apply is re-entrant on a shared const filter and ctypes drops the GIL around it)
-    if kind == "reference":
+    if kind == "reference" and all_cores:
         import threading
         cores = os.cpu_count() or 1
         bufs = [(x.copy(), np.empty_like(x)) for _ in range(cores)]
@@ -83,33 +96,22 @@ def cpu_baseline(length, deriv=D, budget_s=12.0):
     return out
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# secondary workloads (python bench.py --workload stream | image): BASELINE configs 3 and 4, single GPU
-# ---------------------------------------------------------------------------------------------------------------
 def cpu_reference(kind):
-    """The reference's own code (oracle/_ref/libsavgol_ref.so, gcc -O2, 1 thread) on a bounded sample of the same
-    workload, timed on this host; falls back to the oracle port if the compiled reference did not travel."""
+    """CPU leg of the stream / image workloads."""
     import ctypes as C
     from oracle import sgo
-    ref = os.path.join(ROOT, "oracle", "_ref", "libsavgol_ref.so")
-    have_ref = os.path.exists(ref)
-    if have_ref:
-        from tests.golden import make_golden as mg
-        L = mg.load()
+    L, mg = _ref()
     if kind == "stream":
-        exe = os.path.join(os.path.dirname(ref), "cpu_stream_bench")
+        exe = os.path.join(ROOT, "oracle", "_ref", "cpu_stream_bench")
         if os.path.exists(exe):
-            import subprocess
             n_push = 20_000_000
             v = float(subprocess.run([exe, "16", "2", "1", "0.001", str(n_push)], capture_output=True, text=True, check=True).stdout)
-            return {"kind": "reference", "cores": 1, "unit": "Msamples/s", "value": v,
+            return {"kind": "reference", "cores": 1, "unit": "Msamples/s", "value": v, "ns_per_sample": round(1e3 / v, 2),
                     "sample": f"the reference's savgol_stream_push in a C loop, 1 stream, {n_push} samples, best of 5 (oracle/cpu_stream_bench.c)"}
-        n_push = 2_000_000
-        x = sgo.synth_f32(0, 1, n_push)[0]
-        f = sgo.Filter(16, 2, 1, 1e-3)
-        o = sgo.Stream(f)
+        x = sgo.synth_f32(0, 1, 200000)[0]
+        o = sgo.Stream(sgo.Filter(16, 2, 1, 1e-3))
         t0 = time.perf_counter()
-        for v in x[:200000]:
+        for v in x:
             o.push(v)
         el = time.perf_counter() - t0
         return {"kind": "port", "cores": 1, "unit": "Msamples/s", "value": round(200000 / el / 1e6, 3),
@@ -119,7 +121,7 @@ def cpu_reference(kind):
     out = np.zeros_like(img)
     res = {}
     for name, b in (("VALID", 0), ("CONSTANT", 1), ("REFLECT", 2)):
-        if have_ref:
+        if L is not None:
             cfg = mg.Cfg2(7, 7, 3, 0, 0, 1.0, 1.0)
             f = L.savgol2d_create(C.byref(cfg))
             t0 = time.perf_counter()
@@ -129,7 +131,7 @@ def cpu_reference(kind):
             f = sgo.Filter2D(7, 7, 3)
             t0 = time.perf_counter(); f.apply(img, size, b); el = time.perf_counter() - t0
         res[name] = round(size * size / el / 1e6, 2)
-    return {"kind": "reference" if have_ref else "port", "cores": 1, "unit": "Mpix/s", "value": res,
+    return {"kind": "reference" if L is not None else "port", "cores": 1, "unit": "Mpix/s", "value": res,
             "sample": f"savgol2d_apply on one {size}x{size} fp32 frame, n=7, order 3, per boundary mode"}
 
 
@@ -137,6 +139,86 @@ def ev():
     return torch.cuda.Event(enable_timing=True)
 
 
+def timed(fn, reps=5, warm=1):
+    """median HIP-event time of fn() in ms (torch's current stream is the stream every launch goes to)"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = ev(), ev()
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def roofline(alg_bytes, ms, **more):
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), **more}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 1: 1 channel x 1e6 samples, n=5, m=3, d=0, POLYNOMIAL -- the reference's own CPU-runnable case, and the
+# reference's demo loop (test/iterative/test_savgol_main.c:136-155: 360 points, n=6, m=3, 10 000 iterations)
+# ---------------------------------------------------------------------------------------------------------------
+def bench_config1(sg, no_cpu):
+    L1 = 1_000_000
+    x = torch.empty((1, L1), dtype=torch.float32, device="cuda")
+    sg.synth(x)
+    y = torch.empty_like(x)
+    f = sg.Filter(5, 3, 0, 1.0, 0)
+    ms = timed(lambda: f.apply_batch(x, y, 1, L1), reps=20, warm=3)
+    xh = x.cpu().numpy()[0]
+    f.apply(xh); t0 = time.perf_counter(); reps = 5
+    for _ in range(reps):
+        yh = f.apply(xh)
+    host_ms = (time.perf_counter() - t0) / reps * 1e3
+    out = {"workload": "BASELINE config 1: 1 channel x 1e6 samples, half_window=5, poly_order=3, derivative=0, POLYNOMIAL (fp32: the "
+                       "reference's API is fp32)",
+           "device_resident": {"ms": round(ms, 4), "Msamples_per_s": round(L1 / ms / 1e3, 1),
+                               "roofline": roofline(8.0 * L1, ms, kernel="sg1d_center_kernel<float,5>",
+                                                    note="one 4 MB signal = 489 tiles on a 1024-SIMD chip: launch/latency bound, not a roofline case")},
+           "host_pointer_savgol_apply": {"ms": round(host_ms, 3), "Msamples_per_s": round(L1 / host_ms / 1e3, 1),
+                                         "note": "drop-in call on pageable host buffers: H2D + reference-order kernel + D2H, PCIe inclusive; bit-identical to the reference"}}
+    if not no_cpu:
+        out["cpu_baseline"] = cpu_baseline(L1, 5, 3, 0, budget_s=3.0, all_cores=False)
+        from oracle import sgo
+        ref = sgo.Filter(5, 3, 0, 1.0, 0).apply(xh)
+        assert np.array_equal(yh.view(np.uint32), ref.view(np.uint32)), "config 1: host-pointer savgol_apply lost bit-identity"
+        ref64 = sgo.Filter(5, 3, 0, 1.0, 0).apply_f64(xh.astype(np.float64)[None])[0]
+        out["parity_normwise_vs_fp64_oracle"] = float(np.max(np.abs(y.cpu().numpy()[0] - ref64)) / np.max(np.abs(ref64)))
+        assert out["parity_normwise_vs_fp64_oracle"] < 1e-6
+        # the reference's demo loop, on its CPU path and through our host-pointer call
+        Lr, mg = _ref()
+        if Lr is not None:
+            import ctypes as C
+            d = np.load(os.path.join(ROOT, "tests", "golden", "demo360.npz"))
+            sig = np.ascontiguousarray(d["dataset"].astype(np.float32))
+            o = np.empty_like(sig)
+            cfg = mg.Cfg(6, 3, 0, 1.0, 0)
+            fr = Lr.savgol_create(C.byref(cfg))
+            iters = 10000
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                Lr.savgol_apply(fr, mg.fptr(sig), mg.fptr(o), 360)
+            el = time.perf_counter() - t0
+            fd = sg.Filter(6, 3, 0, 1.0, 0)
+            fd.apply(sig); it2 = 300
+            t0 = time.perf_counter()
+            for _ in range(it2):
+                fd.apply(sig)
+            el2 = time.perf_counter() - t0
+            out["reference_demo_360pt"] = {"cpu_reference_Msamples_per_s": round(360 * iters / el / 1e6, 2),
+                                           "gpu_host_pointer_Msamples_per_s": round(360 * it2 / el2 / 1e6, 4),
+                                           "note": "test_savgol_main.c:136-155 (360 points, n=6, m=3, called back to back through ctypes); a 1.4 KB "
+                                                   "signal per call is pure launch + PCIe latency on a GPU: the CPU wins this case by design"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 3: 65 536 streams, n=16, m=2, d=1, dt=1e-3
+# ---------------------------------------------------------------------------------------------------------------
 def bench_stream(sg, a):
     S, T, n = a.streams, a.ticks, 16
     x = torch.empty((T, S), dtype=torch.float32, device="cuda")
@@ -162,67 +244,154 @@ def bench_stream(sg, a):
         bank.push(x[t % T], o1)
     e1.record(); torch.cuda.synchronize()
     tick_us = e0.elapsed_time(e1)
-    # (c) block push: T ticks in one launch, ring in LDS
+    # (c) block push: T ticks in one launch
     bank2 = sg.StreamBank(S, n, 2, 1, 1e-3)
-    bank2.push_block(x, T, out); torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        e0, e1 = ev(), ev()
-        e0.record(); bank2.push_block(x, T, out); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    ms = float(np.median(ts))
+    ms = timed(lambda: bank2.push_block(x, T, out), reps=5, warm=1)
     samples = S * T
-    print(json.dumps({
+    res = {
         "workload": f"BASELINE config 3: {S} streams, n=16, m=2, d=1, dt=1e-3",
         "per_tick_launch": {"wall_latency_us_p50": round(float(lat[len(lat) // 2]), 2), "wall_latency_us_p99": round(float(lat[int(len(lat) * 0.99)]), 2),
                             "device_us_per_tick_back_to_back": round(tick_us, 3), "ns_per_sample": round(tick_us * 1e3 / S, 4),
                             "Msamples_per_s": round(S / tick_us, 1)},
         "block_push": {"ticks_per_launch": T, "ms": round(ms, 3), "ns_per_sample": round(ms * 1e6 / samples, 5),
                        "Msamples_per_s": round(samples / ms / 1e3, 1),
-                       "roofline": {"bound": "hbm", "achieved": round(8.0 * samples / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(8.0 * samples / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sample": 8}},
-        **({} if a.no_cpu else {"cpu_baseline": cpu_reference("stream")}),
-    }))
+                       "roofline": roofline(8.0 * samples, ms, kernel="sg_bank_roll_kernel<16>", algorithmic_bytes_per_sample=8)},
+    }
+    # (d) the single-stream drop-in call: one sample per savgol_stream_push (launch + sync per sample)
+    s1 = sg.Stream(n, 2, 1, 1e-3)
+    xs = x[:, 0].cpu().numpy()
+    for v in xs[:64]:
+        s1.push(float(v))
+    t0 = time.perf_counter()
+    for v in xs[64:64 + 500]:
+        s1.push(float(v))
+    res["single_stream_push"] = {"us_per_sample": round((time.perf_counter() - t0) / 500 * 1e6, 2),
+                                 "note": "savgol_stream_push on one SavgolStream: a kernel launch and a synchronise per sample; the reference's CPU "
+                                         "push costs ~50 ns (cpu_baseline below) -- one stream at a time is the CPU's case, the bank API is the GPU's"}
+    if not a.no_cpu:
+        res["cpu_baseline"] = cpu_reference("stream")
+    return res
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 4: 512 images x 4096 x 4096 fp32, n=7, order 3
+# ---------------------------------------------------------------------------------------------------------------
 def bench_image(sg, a):
-    N, size, n = a.images, a.size, 7
-    x = torch.empty((N * size, size), dtype=torch.float32, device="cuda")
+    Nimg, size, n = a.images, a.size, 7
+    x = torch.empty((Nimg * size, size), dtype=torch.float32, device="cuda")
     sg.synth(x)
     y = torch.empty_like(x)
     f = sg.Filter2D(n, n, 3)
     res = {}
     for name, b in (("VALID", 0), ("CONSTANT", 1), ("REFLECT", 2)):
-        f.apply_batch(x, y, size, size, N, boundary=b, method=a.method); torch.cuda.synchronize()
-        ts = []
-        for _ in range(3):
-            e0, e1 = ev(), ev()
-            e0.record(); f.apply_batch(x, y, size, size, N, boundary=b, method=a.method); e1.record(); torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        ms = float(np.median(ts))
-        pix = N * size * size
+        ms = timed(lambda: f.apply_batch(x, y, size, size, Nimg, boundary=b, method=a.method), reps=3, warm=1)
+        pix = Nimg * size * size
         res[name] = {"ms": round(ms, 3), "Mpix_per_s": round(pix / ms / 1e3, 1),
-                     "roofline": {"bound": "hbm", "achieved": round(8.0 * pix / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(8.0 * pix / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_pixel": 8}}
-    print(json.dumps({"workload": f"BASELINE config 4{'' if N == 512 and size == 4096 else ' (subset)'}: {N} images x {size}x{size} fp32, n=7, order 3, method {a.method}", "modes": res,
-                      **({} if a.no_cpu else {"cpu_baseline": cpu_reference("image")})}))
+                     "roofline": roofline(8.0 * pix, ms, algorithmic_bytes_per_pixel=8)}
+    out = {"workload": f"BASELINE config 4{'' if Nimg == 512 and size == 4096 else ' (subset)'}: {Nimg} images x {size}x{size} fp32, n=7, order 3, "
+                       f"method {a.method} ({'dense, bit-identical' if a.method == 1 else 'exact low-rank row+column passes'})",
+           "modes": res}
+    if not a.no_cpu:
+        out["cpu_baseline"] = cpu_reference("image")
+    del x, y
+    torch.cuda.empty_cache()
+    return out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5, per-GPU slice: 4096 channels x 2^22 fp64 (137 GB), n=32, m=4, d=2, POLYNOMIAL, in 1024-channel chunks
+# ---------------------------------------------------------------------------------------------------------------
+def config5_buffers(sg, channels, chunk, length, rank, dev):
+    """Input slice resident in HBM (generated there, chunk by chunk); output for the whole slice when it fits beside it,
+    else one chunk-sized output buffer that every chunk overwrites."""
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(dev)
+    row = length * 8
+    margin = 6 << 30
+    resident = min(channels, max(chunk, int((free - margin - chunk * row) // row) // chunk * chunk))
+    x = torch.empty((resident, length), dtype=torch.float64, device=dev)
+    for c0 in range(0, resident, chunk):
+        sg.synth(x[c0:c0 + chunk], channel0=rank * channels + c0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    full_out = free - margin >= resident * row
+    y = torch.empty((resident if full_out else chunk, length), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    return x, y, resident, full_out
 
-def pmc_traffic(ch, length):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of the same command
-    (FETCH_SIZE x2 for gfx950 + WRITE_SIZE, separate passes; see profiles/*_pmc_summary.json).  bench.py cannot
-    collect counters itself; the newest committed summary for the same workload is reported, else null."""
+
+def bench_config5_slice(sg, a, rank=0, dev=None, steps=2):
+    dev = dev or torch.device("cuda", torch.cuda.current_device())
+    channels, chunk, length = a.c5_channels, a.c5_chunk, 1 << 22
+    x, y, resident, full_out = config5_buffers(sg, channels, chunk, length, rank, dev)
+    f = sg.Filter(N, M, 2, 1.0, 0)
+    per_launch = []
+
+    def one_pass():
+        for c0 in range(0, resident, chunk):
+            e0, e1 = ev(), ev()
+            e0.record()
+            f.apply_batch(x[c0:c0 + chunk], y[c0:c0 + chunk] if full_out else y, chunk, length, dtype="f64")
+            e1.record(); per_launch.append((e0, e1))
+    one_pass(); torch.cuda.synchronize(); per_launch.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = float(np.mean([p.elapsed_time(q) for p, q in per_launch]))
+    out = {"workload": f"BASELINE config 5, one GPU's slice: {resident} of {channels} channels x {length} fp64 samples resident in HBM "
+                       f"({resident * length * 8 / 1e9:.1f} GB in), half_window=32, poly_order=4 (BASELINE names no order; d=2 needs >= 2), "
+                       f"derivative=2, POLYNOMIAL, processed in {chunk}-channel chunks; "
+                       + ("output slice resident too" if full_out else "every chunk writes the same chunk-sized output buffer (the slice's output does not fit beside its input)"),
+           "Msamples_per_s": round(resident * length * steps / el / 1e6, 1), "ms_per_pass": round(el / steps * 1e3, 3),
+           "roofline": roofline(16.0 * chunk * length, ms, kernel="sg1d_center_kernel<double,32>", launches_timed=len(per_launch))}
+    if not a.no_cpu:
+        from oracle import sgo
+        c0 = resident - chunk
+        sample = [0, chunk - 1]
+        got = (y[c0:c0 + chunk] if full_out else y)[sample].cpu().numpy()
+        ref = sgo.Filter(N, M, 2, 1.0, 0).apply_f64(x[c0:c0 + chunk][sample].cpu().numpy())
+        err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+        assert err < 1e-12, f"config 5 parity lost: {err}"
+        out["parity_normwise_vs_fp64_oracle"] = err
+        out["cpu_baseline"] = {"note": "the reference has no fp64 path (SURVEY.md fact 1); its fp32 savgol_apply at this shape is the headline's cpu_baseline "
+                                       "(same 65-tap loop, n=32)"}
+    del x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def kernel_source_sha():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_summary import kernel_source_sha as sha
+    return sha()
+
+
+def pmc_traffic(alg_bytes):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x2
+    for gfx950 + WRITE_SIZE, separate passes: profiles/*_pmc_summary.json, written by tools/pmc_summary.py).  bench.py cannot
+    collect counters itself, so it reports a committed summary ONLY when that summary was taken on the kernel sources
+    this run is built from (sha256 of csrc/sg_k1d*.h* + sg_api_1d.cpp recorded in the summary) -- otherwise null."""
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_1d_f32_n32_pmc_summary.json"))):
+    try:
+        cur = kernel_source_sha()
+    except Exception:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_1d_f32_n32_pmc_summary.json")), reverse=True):
         try:
             d = json.load(open(path))
-            if d.get("algorithmic_bytes_per_launch") == 8.0 * ch * length:
-                best = d["hbm_traffic_bytes_per_launch"]
         except Exception:
-            pass
-    return best
+            continue
+        if d.get("kernel_source_sha") == cur and d.get("algorithmic_bytes_per_launch") == alg_bytes and "hbm_traffic_bytes_per_launch" in d:
+            return d["hbm_traffic_bytes_per_launch"], {"file": os.path.relpath(path, ROOT), "kernel_source_sha": cur}
+    return None, {"kernel_source_sha": cur, "note": "no committed PMC summary matches these kernel sources"}
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def main():
@@ -232,70 +401,61 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
     ap.add_argument("--length", type=int, default=1 << 20)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs and the oracle spot checks")
+    ap.add_argument("--no-extra", action="store_true", help="headline only: skip the configs 1/3/4/5 'extra' section")
     ap.add_argument("--workload", choices=["batch1d", "batch1d_f64", "stream", "image"], default="batch1d",
-                    help="batch1d = the headline (BASELINE config 2); batch1d_f64 = config 5's per-GPU shape (fp64, n=32, d=2, "
-                         "2^22-sample channels, POLYNOMIAL; 1024 channels per GPU by default); stream / image = configs 3 / 4, "
-                         "single GPU, extra JSON")
+                    help="batch1d = the headline (BASELINE config 2); batch1d_f64 = config 5's per-GPU slice (4096 channels x 2^22 fp64, "
+                         "n=32, d=2, POLYNOMIAL, 1024-channel chunks); stream / image = configs 3 / 4")
     ap.add_argument("--streams", type=int, default=65536)
     ap.add_argument("--ticks", type=int, default=4096)
     ap.add_argument("--images", type=int, default=512, help="2-D: frames per pass (BASELINE config 4 has 512 = 34 GB in + 34 GB out)")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--method", type=int, default=2, help="2-D: 1 = dense (bit-exact), 2 = separable")
+    ap.add_argument("--rowband", action="store_true", help="--workload image: split every frame into one row band per GPU and trade the "
+                                                           "ny-row halos with the neighbours (RCCL point to point) instead of sharding whole frames")
+    ap.add_argument("--c5-channels", type=int, default=4096, help="config 5: channels per GPU (32768 / 8)")
+    ap.add_argument("--c5-chunk", type=int, default=1024)
     args = ap.parse_args()
-    args.no_cpu = args.no_cpu
-    if args.workload in ("stream", "image"):
-        sg = load_package()
-        (bench_stream if args.workload == "stream" else bench_image)(sg, args)
-        return
 
+    # ---- N ranks: start them from here, BEFORE anything in this process touches the GPU (never re-exec after that) ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` or give torchrun the same N")
+
     dist = None
-    # test hooks (tests/test_gpu_bench_contract.py): run the N>1 plumbing on a 1-GPU box with every rank on one device
+    # test hooks (tests/): run the N>1 plumbing with every rank on one device / without a device at all
     backend = os.environ.get("SAVGOL_BENCH_BACKEND", "nccl")
+    dry = os.environ.get("SAVGOL_BENCH_DRYRUN") == "1"
     if "SAVGOL_BENCH_DEVICE" in os.environ:
         local = int(os.environ["SAVGOL_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        if backend == "nccl":
+        if backend == "nccl" and not dry:
+            torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo")
+    if dry:
+        # no GPU: only the launch / barrier / max-over-ranks plumbing (tests/test_bench_selflaunch.py)
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        if dist is not None:
+            dist.barrier(); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (no GPU work)", "n_gpus": world, "max_over_ranks": t.item()}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-
     sg = load_package()
     assert sg.lib().savgol_hip_set_device(local) == 0, sg.last_error()
-
-    f64 = args.workload == "batch1d_f64"
-    if f64:                                               # config 5 shape unless overridden on the command line
-        if args.channels == 4096: args.channels = 1024
-        if args.length == 1 << 20: args.length = 1 << 22
-    ch, length = args.channels, args.length
-    deriv = 2 if f64 else D
-    modes = [0] if f64 else [0, 1, 2, 3]
-    esize = 8 if f64 else 4
-    x = torch.empty((ch, length), dtype=torch.float64 if f64 else torch.float32, device=dev)
-    y = torch.empty_like(x)
-    sg.synth(x, channel0=rank * ch)                       # generated in HBM, never crosses PCIe
-    filters = [sg.Filter(N, M, deriv, 1.0, mode) for mode in modes]
-    torch.cuda.synchronize()
-
-    def step(events=None):
-        for f in filters:
-            if events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            f.apply_batch(x, y, ch, length, dtype="f64" if f64 else "f32")
-            if events is not None:
-                e1.record(); events.append((e0, e1))
-
-    for _ in range(args.warmup):
-        step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -303,86 +463,246 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    events = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(events)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    def timed_region(step):
+        """W untimed steps, then K steps between barriers; returns max-over-ranks seconds"""
+        for _ in range(args.warmup):
+            step(None)
+        events = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(events)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el, events
+
+    common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "data": "synthetic"}
+
+    # =========================================== stream (config 3) ===========================================
+    if args.workload == "stream":
+        lo, hi = sg.shard_range(args.streams * world, world, rank)          # weak scaling: every GPU its own 65 536 streams
+        S, T = hi - lo, args.ticks
+        x = torch.empty((T, S), dtype=torch.float32, device=dev); sg.synth(x, channel0=lo)
+        y = torch.empty_like(x)
+        bank = sg.StreamBank(S, 16, 2, 1, 1e-3)
+
+        def step(events):
+            e0, e1 = ev(), ev()
+            e0.record(); bank.push_block(x, T, y); e1.record()
+            if events is not None:
+                events.append((e0, e1))
+        el, events = timed_region(step)
+        if rank == 0:
+            ms = float(np.mean([p.elapsed_time(q) for p, q in events]))
+            out = {"metric": "Msamples/s filtered (streaming, 65536 streams per GPU, hw=16, poly=2, derivative=1, block push)",
+                   "value": round(S * T * args.steps * world / el / 1e6, 1), "unit": "Msamples/s", **common,
+                   "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": "f32",
+                   "config": {"workload": f"BASELINE config 3: {S} streams per GPU x {T} ticks per step, n=16, m=2, d=1, dt=1e-3", "sharding": "streams, no collective"},
+                   "roofline": roofline(8.0 * S * T, ms, kernel="sg_bank_roll_kernel<16>", launches_timed=len(events))}
+            if world == 1:
+                out["latency"] = bench_stream(sg, args)
+                if "cpu_baseline" in out["latency"]:
+                    out["cpu_baseline"] = out["latency"]["cpu_baseline"]
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # =========================================== image (config 4) ===========================================
+    if args.workload == "image":
+        size, n = args.size, 7
+        f2 = sg.Filter2D(n, n, 3)
+        if args.rowband:
+            import importlib
+            rowband = importlib.import_module("savgol_amd.rowband")
+            Nimg = min(args.images, 128)
+            band = rowband.RowBand(size * world, n, rank, world)          # weak scaling: a (size*world)-row frame, `size` rows per GPU
+            rows = band.hi - band.lo
+            local_rows = torch.empty((Nimg * rows, size), dtype=torch.float32, device=dev)
+            sg.synth(local_rows, channel0=band.lo)
+            local_band = local_rows.view(Nimg, rows, size)
+
+            def apply_fn(frames):
+                k, r, c = frames.shape
+                o = torch.empty_like(frames)
+                f2.apply_batch(frames, o, r, c, k, boundary=1, method=args.method)
+                return o
+
+            def step(events):
+                e0, e1 = ev(), ev()
+                e0.record(); band.apply_overlapped(local_band, apply_fn); e1.record()
+                if events is not None:
+                    events.append((e0, e1))
+            el, events = timed_region(step)
+            pix_rank = Nimg * rows * size
+            cfg = {"workload": f"BASELINE config 4 shape, row-band split: {Nimg} frames of {size * world} x {size} fp32, one {rows}-row band per GPU, "
+                               f"n=7, order 3, CONSTANT; per step: {n}-row halos to both neighbours (RCCL point to point), band filtered meanwhile, edge strips redone",
+                   "sharding": "row bands, nearest-neighbour halo exchange"}
+        else:
+            Nimg = args.images
+            x = torch.empty((Nimg * size, size), dtype=torch.float32, device=dev); sg.synth(x, channel0=rank * Nimg * size)
+            y = torch.empty_like(x)
+
+            def step(events):
+                for b in (0, 1, 2):
+                    e0, e1 = ev(), ev()
+                    e0.record(); f2.apply_batch(x, y, size, size, Nimg, boundary=b, method=args.method); e1.record()
+                    if events is not None:
+                        events.append((e0, e1))
+            el, events = timed_region(step)
+            pix_rank = 3 * Nimg * size * size
+            cfg = {"workload": f"BASELINE config 4: {Nimg} images x {size}x{size} fp32 per GPU, n=7, order 3, one pass per boundary mode "
+                               f"(VALID, CONSTANT, REFLECT) per step, method {args.method}", "sharding": "images, no collective"}
+        if rank == 0:
+            ms = float(np.mean([p.elapsed_time(q) for p, q in events]))
+            per_launch_pix = pix_rank if args.rowband else pix_rank // 3
+            out = {"metric": "Mpix/s filtered (2-D, hw=7, order 3)", "value": round(pix_rank * args.steps * world / el / 1e6, 1), "unit": "Mpix/s", **common,
+                   "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": "f32", "config": cfg,
+                   "roofline": roofline(8.0 * per_launch_pix, ms, kernel="sg2d_rolling_kernel<7,2>" if args.method == 2 else "sg2d_dense_roll_kernel<7>",
+                                        launches_timed=len(events))}
+            if world == 1 and not args.no_cpu:
+                out["cpu_baseline"] = cpu_reference("image")
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # =========================================== config 5 as the main line ===========================================
+    if args.workload == "batch1d_f64":
+        channels, chunk, length = args.c5_channels, args.c5_chunk, 1 << 22
+        x, y, resident, full_out = config5_buffers(sg, channels, chunk, length, rank, dev)
+        f = sg.Filter(N, M, 2, 1.0, 0)
+
+        def step(events):
+            for c0 in range(0, resident, chunk):
+                e0, e1 = ev(), ev()
+                e0.record()
+                f.apply_batch(x[c0:c0 + chunk], y[c0:c0 + chunk] if full_out else y, chunk, length, dtype="f64")
+                e1.record()
+                if events is not None:
+                    events.append((e0, e1))
+        el, events = timed_region(step)
+        if rank == 0:
+            ms = float(np.mean([p.elapsed_time(q) for p, q in events]))
+            out = {"metric": "Msamples/s filtered (1D batch fp64, hw=32, poly=4, derivative=2) + % HBM roofline",
+                   "value": round(resident * length * args.steps * world / el / 1e6, 1), "unit": "Msamples/s", **common,
+                   "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": "f64",
+                   "config": {"workload": f"BASELINE config 5: {resident} channels x {length} fp64 samples per GPU ({channels} = 32768/8 asked for; "
+                                          f"{resident * length * 8 / 1e9:.1f} GB resident input), n=32, m=4, d=2, POLYNOMIAL, {chunk}-channel chunks per launch, "
+                                          + ("output slice resident" if full_out else "one chunk-sized output buffer reused"),
+                              "channels_per_gpu": resident, "length": length, "sharding": "channels, no collective"},
+                   "roofline": roofline(16.0 * chunk * length, ms, kernel="sg1d_center_kernel<double,32>", launches_timed=len(events))}
+            if world == 1 and not args.no_cpu:
+                from oracle import sgo
+                sample = [0, chunk - 1]
+                c0 = resident - chunk
+                got = (y[c0:c0 + chunk] if full_out else y)[sample].cpu().numpy()
+                ref = sgo.Filter(N, M, 2, 1.0, 0).apply_f64(x[c0:c0 + chunk][sample].cpu().numpy())
+                err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+                assert err < 1e-12, f"parity lost: normwise error {err}"
+                out["parity_normwise_vs_fp64_oracle"] = err
+                out["cpu_baseline"] = cpu_baseline(1 << 20, N, M, 2, budget_s=8.0, all_cores=False)
+                out["cpu_baseline"]["sample"] += " (fp32: the reference has no fp64 path)"
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # =========================================== the headline: config 2 ===========================================
+    ch, length = args.channels, args.length
+    modes = [0, 1, 2, 3]
+    x = torch.empty((ch, length), dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    sg.synth(x, channel0=rank * ch)                       # generated in HBM, never crosses PCIe
+    filters = [sg.Filter(N, M, D, 1.0, mode) for mode in modes]
+    torch.cuda.synchronize()
+
+    def step(events):
+        for f in filters:
+            e0, e1 = ev(), ev()
+            e0.record(); f.apply_batch(x, y, ch, length); e1.record()
+            if events is not None:
+                events.append((e0, e1))
+    elapsed, events = timed_region(step)
 
     if rank == 0:
         launches_ms = [a.elapsed_time(b) for a, b in events]
         avg_ms = float(np.mean(launches_ms))
-        alg_bytes = 2.0 * esize * ch * length               # sizeof(T) read + sizeof(T) written per sample
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        alg_bytes = 8.0 * ch * length                        # 4 B read + 4 B written per sample
         samples = float(len(modes)) * ch * length * args.steps * world
+        import ctypes as C
+        tab = (C.c_float * 400)()
+        terms = sg.lib().savgol_hip_moment_table(filters[0].ptr, tab)
+        kernel = f"sg1d_center_moment_kernel<{terms}>" if terms > 0 else f"sg1d_center_kernel<float,{N}>"
+        traffic, traffic_src = pmc_traffic(alg_bytes)
         out = {
-            "metric": "Msamples/s filtered (1D batch, hw=32, poly=4) + % HBM roofline" if not f64 else
-                      "Msamples/s filtered (1D batch fp64, hw=32, poly=4, derivative=2) + % HBM roofline",
-            "value": round(samples / elapsed / 1e6, 1),
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64" if f64 else "f32",
-            "data": "synthetic",
-            "config": {"workload": (f"BASELINE config 2: {ch} channels x {length} fp32 samples per GPU, half_window={N}, "
-                                    f"poly_order={M}, derivative={D}, one pass per boundary mode "
-                                    "(POLYNOMIAL, REFLECT, PERIODIC, CONSTANT) per step") if not f64 else
-                                   (f"BASELINE config 5 shape: {ch} channels x {length} fp64 samples per GPU (the full config is 4096 per "
-                                    f"GPU, processed in such chunks), half_window={N}, poly_order={M}, derivative=2, POLYNOMIAL"),
+            "metric": "Msamples/s filtered (1D batch, hw=32, poly=4) + % HBM roofline",
+            "value": round(samples / elapsed / 1e6, 1), "unit": "Msamples/s", **common,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "dtype": "f32",
+            "config": {"workload": f"BASELINE config 2: {ch} channels x {length} fp32 samples per GPU, half_window={N}, "
+                                   f"poly_order={M}, derivative={D}, one pass per boundary mode "
+                                   "(POLYNOMIAL, REFLECT, PERIODIC, CONSTANT) per step",
                        "channels_per_gpu": ch, "length": length, "sharding": "channels, no collective"},
-            "roofline": {"bound": "hbm", "kernel": f"sg1d_center_kernel<{'double' if f64 else 'float'},{N}>",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if f64 else pmc_traffic(ch, length),
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
-                         "launches_timed": len(launches_ms)},
+            "roofline": {**roofline(alg_bytes, avg_ms, kernel=kernel, launches_timed=len(launches_ms)), "traffic": traffic,
+                         "traffic_source": traffic_src},
         }
         if world == 1 and not args.no_cpu:
-            # CPU leg (rank 0, N=1 only): the reference timed on this host + a parity spot check of what was just
-            # timed (last mode run = CONSTANT) against the CPU oracle -- the only place bench.py touches oracle/
-            out["cpu_baseline"] = cpu_baseline(length, deriv)
+            # CPU leg (rank 0, N=1 only): the reference timed on this host + parity spot checks of what was just timed
+            # (last mode run = CONSTANT) against the CPU oracle -- the only place bench.py touches oracle/
+            out["cpu_baseline"] = cpu_baseline(length)
             from oracle import sgo
             sample = [0, ch // 2, ch - 1]
-            ref = sgo.Filter(N, M, deriv, 1.0, modes[-1]).apply_f64(x[sample].cpu().numpy().astype(np.float64))
+            ref = sgo.Filter(N, M, D, 1.0, modes[-1]).apply_f64(x[sample].cpu().numpy().astype(np.float64))
             checked = float(np.max(np.abs(y[sample].cpu().numpy() - ref)) / np.max(np.abs(ref)))
-            assert checked < (1e-12 if f64 else 1e-6), f"parity lost: normwise error {checked}"
+            assert checked < 1e-6, f"parity lost: normwise error {checked}"
             out["parity_normwise_vs_fp64_oracle"] = checked
-        if world == 1 and not f64:
-            # secondary figure, outside the timed region: the same four passes with the reference's own summation
-            # order (SAVGOL_HIP_OPT_REFERENCE_SUMMATION -> outputs bit-identical to the reference library's)
+            # a derivative filter through the same kernel (documented bar for d >= 1: 2e-6, include/savgol_hip.h)
+            fd = sg.Filter(N, M, 1, 1.0, 0)
+            fd.apply_batch(x, y, ch, length); torch.cuda.synchronize()
+            refd = sgo.Filter(N, M, 1, 1.0, 0).apply_f64(x[sample].cpu().numpy().astype(np.float64))
+            out["parity_normwise_vs_fp64_oracle_d1"] = float(np.max(np.abs(y[sample].cpu().numpy() - refd)) / np.max(np.abs(refd)))
+            assert out["parity_normwise_vs_fp64_oracle_d1"] < 2e-6
+        if world == 1:
+            # secondary figures, outside the timed region
             L = sg.lib()
-            if L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 1) == 0:
+            sec = {}
+            for name, opt in (("plain_65_tap_sum", sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION), ("bit_identical_mode", sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION)):
+                if L.savgol_hip_set_option(opt, 1) != 0:
+                    continue
                 try:
-                    for flt in filters:
-                        flt.apply_batch(x, y, ch, length)
-                    torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for flt in filters:
-                        flt.apply_batch(x, y, ch, length)
-                    e1.record(); torch.cuda.synchronize()
-                    ms = e0.elapsed_time(e1) / len(filters)
-                    out["bit_identical_mode"] = {"Msamples_per_s": round(ch * length / ms / 1e3, 1), "avg_launch_ms": round(ms, 4),
-                                                 "roofline_frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                 "note": "reference summation order (four chains, separate multiply and add): "
-                                                         "outputs equal the reference library's bit for bit"}
-                    if not args.no_cpu:
+                    ms = timed(lambda: [flt.apply_batch(x, y, ch, length) for flt in filters], reps=3, warm=1) / len(filters)
+                    sec[name] = {"Msamples_per_s": round(ch * length / ms / 1e3, 1), "avg_launch_ms": round(ms, 4),
+                                 "roofline_frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                    if name == "bit_identical_mode" and not args.no_cpu:
                         from oracle import sgo
                         sample = [0, ch - 1]
-                        ref32 = sgo.Filter(N, M, deriv, 1.0, modes[-1]).apply(x[sample].cpu().numpy())
+                        ref32 = sgo.Filter(N, M, D, 1.0, modes[-1]).apply(x[sample].cpu().numpy())
                         assert np.array_equal(y[sample].cpu().numpy().view(np.uint32), ref32.view(np.uint32)), "bit-identical mode lost"
                 finally:
-                    L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 0)
+                    L.savgol_hip_set_option(opt, 0)
+            if "plain_65_tap_sum" in sec:
+                sec["plain_65_tap_sum"]["note"] = "SAVGOL_HIP_OPT_PLAIN_SUMMATION: sg1d_center_kernel<float,32>, all 65 taps one by one (the default replaces 32 of them by block moments)"
+            if "bit_identical_mode" in sec:
+                sec["bit_identical_mode"]["note"] = ("reference summation order (four chains, separate multiply and add): outputs equal the reference "
+                                                     "library's bit for bit")
+            out.update(sec)
+        if world == 1 and not args.no_extra:
+            del x, y
+            torch.cuda.empty_cache()
+            extra = {}
+            for name, fn in (("config1", lambda: bench_config1(sg, args.no_cpu)), ("config3", lambda: bench_stream(sg, args)),
+                             ("config4", lambda: bench_image(sg, args)), ("config5_slice", lambda: bench_config5_slice(sg, args))):
+                try:
+                    extra[name] = fn()
+                except Exception as e:                               # an extra must never take the headline down
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

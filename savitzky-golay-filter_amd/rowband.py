@@ -9,6 +9,8 @@ stack -- so on MI355X it rides one xGMI link per neighbour pair (RCCL, `backend=
 all-reduce.
 
     band = RowBand(rows, ny, rank, world)            # which rows this rank owns
+    out  = band.apply_overlapped(local, apply_fn)    # halo exchange in flight while the band itself is filtered
+  or, in two steps (one extra copy of the band, nothing overlapped):
     ext  = band.exchange(local)                      # local [images, own_rows, cols] -> + halo rows from neighbours
     out  = band.apply(ext, apply_fn)                 # apply_fn(frames[images, R, cols]) -> same shape; returns own rows
 
@@ -64,3 +66,51 @@ class RowBand:
         """Filter the extended band and return this rank's own rows [images, hi-lo, cols]."""
         out = apply_fn(ext)
         return out[:, self.top:self.top + (self.hi - self.lo)]
+
+    # ---- the same result with the exchange hidden behind the interior ----
+    def start_exchange(self, local):
+        """Post the halo sends/receives (non-blocking) and return a handle for finish_exchange()."""
+        images, own, cols = local.shape
+        assert own == self.hi - self.lo
+        ops, bufs = [], {}
+        if self.top:
+            send_up = local[:, :self.ny].contiguous()
+            bufs["up"] = torch.empty_like(send_up)
+            ops += [dist.P2POp(dist.isend, send_up, self.rank - 1), dist.P2POp(dist.irecv, bufs["up"], self.rank - 1)]
+            bufs["_keep_up"] = send_up
+        if self.bottom:
+            send_dn = local[:, own - self.ny:].contiguous()
+            bufs["dn"] = torch.empty_like(send_dn)
+            ops += [dist.P2POp(dist.isend, send_dn, self.rank + 1), dist.P2POp(dist.irecv, bufs["dn"], self.rank + 1)]
+            bufs["_keep_dn"] = send_dn
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        return reqs, bufs
+
+    @staticmethod
+    def finish_exchange(handle):
+        reqs, bufs = handle
+        for r in reqs:
+            r.wait()
+        return bufs.get("up"), bufs.get("dn")
+
+    def apply_overlapped(self, local, apply_fn):
+        """Filter this rank's band with the halo exchange in flight.
+
+        1. the `ny` boundary rows go out / come in (point to point, non-blocking);
+        2. meanwhile the whole local band is filtered as if it were a frame: every output row except the `ny` next to an
+           artificial edge is already final (a row r needs input rows r-ny..r+ny, all local);
+        3. when the halos have landed, each artificial edge is redone on a 3*ny-row strip (halo + the band's first / last
+           2*ny rows): its middle `ny` output rows see only real data and replace the tainted ones.
+        No extended copy of the band is made; the strips are 3*ny/own of the work (0.5 % for 4096-row bands, ny = 7)."""
+        images, own, cols = local.shape
+        ny = self.ny
+        handle = self.start_exchange(local)
+        out = apply_fn(local)
+        up, dn = self.finish_exchange(handle)
+        if up is not None:
+            strip = torch.cat([up, local[:, :2 * ny]], dim=1)
+            out[:, :ny] = apply_fn(strip)[:, ny:2 * ny]
+        if dn is not None:
+            strip = torch.cat([local[:, own - 2 * ny:], dn], dim=1)
+            out[:, own - ny:] = apply_fn(strip)[:, ny:2 * ny]
+        return out

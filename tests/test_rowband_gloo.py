@@ -55,6 +55,9 @@ def _worker(rank, world, port, images, rows, cols, n, out_dir):
     for b in range(3):
         own = band.apply(ext, _oracle_apply(sgo, n, b))
         np.save(os.path.join(out_dir, f"b{b}_r{rank}.npy"), own.numpy())
+        # the overlapped form (exchange in flight while the band is filtered, edge strips redone afterwards)
+        own2 = band.apply_overlapped(local, _oracle_apply(sgo, n, b))
+        np.save(os.path.join(out_dir, f"o{b}_r{rank}.npy"), own2.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,6 +72,8 @@ def test_row_band_halo_exchange_matches_whole_frame(tmp_path, sgo, world):
         got = np.concatenate([np.load(tmp_path / f"b{b}_r{r}.npy") for r in range(world)], axis=1)
         assert got.shape == whole.shape
         assert np.array_equal(got, whole), f"boundary {b}: max diff {np.max(np.abs(got - whole))}"
+        got2 = np.concatenate([np.load(tmp_path / f"o{b}_r{r}.npy") for r in range(world)], axis=1)
+        assert np.array_equal(got2, whole), f"overlapped, boundary {b}: max diff {np.max(np.abs(got2 - whole))}"
 
 
 def test_row_band_refuses_bands_thinner_than_the_window(sg):
