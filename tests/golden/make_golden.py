@@ -316,7 +316,28 @@ def gen_embedded(L, out_m, out_d):
         L.savgol_destroy(f)
 
 
+EXPORT_CASES = [(5, 2, 0, None), (10, 3, 1, "deriv"), (32, 4, 0, "sg32"), (3, 2, 2, "Mixed_Case9"), (1, 0, 0, "one")]
+
+
+def gen_export():
+    """Headers written by the reference's own savgol_export tool (oracle/_ref/savgol_export, built unmodified by
+    `make -C oracle ref`) -- the reference's on-disk format for the weight tables.  The tool's "Generated by ... on <time>"
+    line is the only thing that changes from run to run; the time is replaced by @TIMESTAMP@ in the fixture."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "savgol_export")
+    for n, m, d, prefix in EXPORT_CASES:
+        cmd = [exe, "-n", str(n), "-m", str(m), "-d", str(d)] + (["-p", prefix] if prefix else [])
+        text = subprocess.run(cmd, capture_output=True, text=True, check=True).stdout
+        text = re.sub(r"(Generated by savgol_export on )\d{4}-\d\d-\d\d \d\d:\d\d:\d\d", r"\1@TIMESTAMP@", text)
+        assert "@TIMESTAMP@" in text
+        name = f"export_n{n}_m{m}_d{d}_{prefix or 'SAVGOL'}.txt"
+        open(os.path.join(HERE, name), "w").write(text)
+        print(f"{name}  {len(text)} bytes")
+
+
 def main():
+    if "--export-only" in sys.argv:
+        return gen_export()
     if not os.path.exists(LIB):
         sys.exit(f"{LIB} missing: run `make -C oracle ref` first")
     L = load()
@@ -327,6 +348,7 @@ def main():
         p = os.path.join(HERE, name + ".npz")
         np.savez_compressed(p, **d)
         print(f"{name:12s} {len(d):4d} arrays  {os.path.getsize(p)/1024:.1f} KiB")
+    gen_export()
 
 
 if __name__ == "__main__":
