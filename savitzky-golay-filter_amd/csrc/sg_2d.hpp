@@ -75,6 +75,18 @@ inline int sg2d_launch_rolling(int n, int terms, const Job2D &job, const float *
     return sg2d_launch_rolling_g2(n, terms, job, factors, scale, images, cu_count, st);
 }
 
+// two output frames (job.out, out1) from one walk over the input; both outputs have `terms` (<= 3) terms
+int sg2d_launch_rolling2_g0(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling2_g1(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling2_g2(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1, unsigned images, int cu_count, hipStream_t st);
+inline int sg2d_launch_rolling2(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1,
+                                unsigned images, int cu_count, hipStream_t st)
+{
+    if (sg2d_launch_rolling2_g0(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st) == 0) return 0;
+    if (sg2d_launch_rolling2_g1(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st) == 0) return 0;
+    return sg2d_launch_rolling2_g2(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
+}
+
 // sg_2d_dense.hip: the bit-exact dense kernel on packed math, square windows with half window <= DENSE_ROLL_MAX_N.
 // 0 = launched, 1 = not covered (the caller uses sg2d_direct_kernel of sg_2d.hip), -1 = error.  h_w = the kernel on the host.
 constexpr int DENSE_ROLL_MAX_N = 8;

@@ -45,11 +45,12 @@ struct Roll {
 };
 
 // taps 0..N of every vector (the mirrored half follows from the parity), Q already multiplied by the output scale
-template <int N, int NT>
+// NOUT output frames share one walk over the input (gradient: d/dx and d/dy); each has its own NT terms and parities
+template <int N, int NT, int NOUT>
 struct RollTaps {
-    f32x2 g[NT][Roll<N>::NP];
-    f32x2 q[NT][Roll<N>::NP];
-    f32x2 sy, sx;                                           // +1 / -1 (both halves equal)
+    f32x2 g[NOUT][NT][Roll<N>::NP];
+    f32x2 q[NOUT][NT][Roll<N>::NP];
+    f32x2 sy[NOUT], sx[NOUT];                               // +1 / -1 (both halves equal)
 };
 
 // a + s * b, s = {+-1, +-1} in an SGPR pair.  Deliberately NOT inline asm: the hazard recogniser counts no wait
@@ -78,8 +79,8 @@ __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
 // The two passes are skewed by one row: iteration m runs the vertical pass of row m and writes its results to one LDS
 // row, then reads row m-1's horizontal window from the other LDS row (written one iteration earlier, so the data
 // is there when the reads issue) and does row m-1's horizontal arithmetic and store.
-template <int N, int NT, bool VEC>
-__device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT> &taps, float *mine, const float *in, float *out,
+template <int N, int NT, int NOUT, bool VEC>
+__device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *mine, const float *in, float *const (&outs)[NOUT],
                                           int sx, int yb, int nout, int lane, int xlo, int xhi, int ylo, int yhi)
 {
     typedef Roll<N> R;
@@ -102,52 +103,58 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 
     f32x4 win[R::U];
 
-    // vertical pass of the output row whose first input row sits in slot u0 -> LDS row `par`
+    // vertical pass of the output row whose first input row sits in slot u0 -> LDS row `par` (one row per output and term)
     auto vertical = [&](auto u0c, int par) {
         constexpr int u0 = decltype(u0c)::value;
         // Instruction order matters: the assembler pads an inline-asm result that is consumed within the next two
         // instructions with s_nop, so the fold of tap k+1 is issued before the multiply-adds of tap k and the
         // accumulator chains (2 column pairs x NT terms) are interleaved.
-        f32x2 v[NT][2], f[2][N + 1];
-        auto fold = [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const f32x4 a = win[(u0 + k) % R::U], b = win[(u0 + 2 * N - k) % R::U];
-            if constexpr (k < N) {
-                f[0][k] = pk_fold(taps.sy, f32x2{b.x, b.y}, f32x2{a.x, a.y});
-                f[1][k] = pk_fold(taps.sy, f32x2{b.z, b.w}, f32x2{a.z, a.w});
-            } else {
-                f[0][N] = f32x2{a.x, a.y};
-                f[1][N] = f32x2{a.z, a.w};
-            }
-        };
-        fold(std::integral_constant<int, 0>{});
-        static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
-            constexpr int k = decltype(kc)::value;
-            if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
+        static_for<NOUT>([&](auto oc) -> bool {
+            constexpr int o = decltype(oc)::value;
+            f32x2 v[NT][2], f[2][N + 1];
+            auto fold = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const f32x4 a = win[(u0 + k) % R::U], b = win[(u0 + 2 * N - k) % R::U];
+                if constexpr (k < N) {
+                    f[0][k] = pk_fold(taps.sy[o], f32x2{b.x, b.y}, f32x2{a.x, a.y});
+                    f[1][k] = pk_fold(taps.sy[o], f32x2{b.z, b.w}, f32x2{a.z, a.w});
+                } else {
+                    f[0][N] = f32x2{a.x, a.y};
+                    f[1][N] = f32x2{a.z, a.w};
+                }
+            };
+            fold(std::integral_constant<int, 0>{});
+            static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if constexpr (k == 0) v[t][c] = pk_mul_sgpr<0>(taps.g[o][t][0], f[c][0]);
+                        else pk_fma_sgpr<(k & 1)>(v[t][c], taps.g[o][t][k >> 1], f[c][k]);
+                    }
+                return true;
+            });
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    if constexpr (k == 0) v[t][c] = pk_mul_sgpr<0>(taps.g[t][0], f[c][0]);
-                    else pk_fma_sgpr<(k & 1)>(v[t][c], taps.g[t][k >> 1], f[c][k]);
-                }
+                *reinterpret_cast<f32x4 *>(wr + ((par * NOUT + o) * NT + t) * R::BUFW) = f32x4{v[t][0].x, v[t][0].y, v[t][1].x, v[t][1].y};
             return true;
         });
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            *reinterpret_cast<f32x4 *>(wr + (par * NT + t) * R::BUFW) = f32x4{v[t][0].x, v[t][0].y, v[t][1].x, v[t][1].y};
     };
-    // horizontal pass, part 1: this lane's window of every term's strip row, from LDS row `par`
+    // horizontal pass, part 1: this lane's window of every term's strip row of output `o`, from LDS row `par`
     f32x4 hq[NT][R::NQ];
-    auto fetch = [&](int par) {
+    auto fetch = [&](auto oc, int par) {
+        constexpr int o = decltype(oc)::value;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < R::NQ; ++q) hq[t][q] = *reinterpret_cast<const f32x4 *>(rd + (par * NT + t) * R::BUFW + 4 * q);
+            for (int q = 0; q < R::NQ; ++q) hq[t][q] = *reinterpret_cast<const f32x4 *>(rd + ((par * NOUT + o) * NT + t) * R::BUFW + 4 * q);
     };
-    // part 2: the arithmetic on the fetched window and the store of frame row yo
-    auto horizontal = [&](int yo) {
-        f32x2 o[2];
+    // part 2: the arithmetic on the fetched window and the store of frame row yo of output `o`
+    auto horizontal = [&](auto oc, int yo) {
+        constexpr int o = decltype(oc)::value;
+        f32x2 r[2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x2 e[2 * R::NQ + 1];
@@ -166,8 +173,8 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             auto fold = [&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 if constexpr (k < N) {
-                    f[0][k] = pk_fold(taps.sx, pr[2 * N - k], pr[k]);
-                    f[1][k] = pk_fold(taps.sx, pr[2 + 2 * N - k], pr[2 + k]);
+                    f[0][k] = pk_fold(taps.sx[o], pr[2 * N - k], pr[k]);
+                    f[1][k] = pk_fold(taps.sx[o], pr[2 + 2 * N - k], pr[2 + k]);
                 } else {
                     f[0][N] = pr[N];
                     f[1][N] = pr[2 + N];
@@ -177,24 +184,27 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
                 constexpr int k = decltype(kc)::value;
                 if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
-                if (k == 0 && t == 0) { o[0] = pk_mul_sgpr<0>(taps.q[0][0], f[0][0]); o[1] = pk_mul_sgpr<0>(taps.q[0][0], f[1][0]); }
-                else { pk_fma_sgpr<(k & 1)>(o[0], taps.q[t][k >> 1], f[0][k]); pk_fma_sgpr<(k & 1)>(o[1], taps.q[t][k >> 1], f[1][k]); }
+                if (k == 0 && t == 0) { r[0] = pk_mul_sgpr<0>(taps.q[o][0][0], f[0][0]); r[1] = pk_mul_sgpr<0>(taps.q[o][0][0], f[1][0]); }
+                else { pk_fma_sgpr<(k & 1)>(r[0], taps.q[o][t][k >> 1], f[0][k]); pk_fma_sgpr<(k & 1)>(r[1], taps.q[o][t][k >> 1], f[1][k]); }
                 return true;
             });
         }
         if (yo >= ylo && yo < yhi) {                         // uniform
-            float *orow = out + (long long)yo * job.out_stride;
+            float *orow = outs[o] + (long long)yo * job.out_stride;
             if constexpr (VEC) {
                 if (out_lane)
-                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, f32x4{o[0].x, o[0].y, o[1].x, o[1].y}),
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, f32x4{r[0].x, r[0].y, r[1].x, r[1].y}),
                                                 reinterpret_cast<u32x4 *>(orow + c0));
             } else if (out_lane) {
-                if (c0 >= xlo && c0 < xhi) orow[c0] = o[0].x;
-                if (c0 + 1 >= xlo && c0 + 1 < xhi) orow[c0 + 1] = o[0].y;
-                if (c0 + 2 >= xlo && c0 + 2 < xhi) orow[c0 + 2] = o[1].x;
-                if (c0 + 3 >= xlo && c0 + 3 < xhi) orow[c0 + 3] = o[1].y;
+                if (c0 >= xlo && c0 < xhi) orow[c0] = r[0].x;
+                if (c0 + 1 >= xlo && c0 + 1 < xhi) orow[c0 + 1] = r[0].y;
+                if (c0 + 2 >= xlo && c0 + 2 < xhi) orow[c0 + 2] = r[1].x;
+                if (c0 + 3 >= xlo && c0 + 3 < xhi) orow[c0 + 3] = r[1].y;
             }
         }
+    };
+    auto finish_row = [&](int par, int yo) {                 // horizontal pass of every output, one after the other (hq is reused)
+        static_for<NOUT>([&](auto oc) -> bool { fetch(oc, par); horizontal(oc, yo); return true; });
     };
 
 #pragma unroll
@@ -209,27 +219,25 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             win[uu] = load_row(m + R::U - 1);                // slot of row m-1, which no later row needs
             vertical(std::integral_constant<int, (uu + 1) % R::U>{}, (uu + 1) & 1);
             wave_lds_sync();                                 // orders this row's LDS writes and the reads below for the compiler
-            fetch(uu & 1);
-            horizontal(yb + m - 1);
+            finish_row(uu & 1, yb + m - 1);
             done = m + 1;
             return true;
         });
     }
     wave_lds_sync();
-    fetch((done - 1) & 1);
-    horizontal(yb + done - 1);
+    finish_row((done - 1) & 1, yb + done - 1);
     wave_lds_sync();                                         // the next item's first write must stay behind these reads
 }
 
-template <int N, int NT>
-__global__ __launch_bounds__(256, (NT >= 3 && N >= 6) ? 3 : 4) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT> taps, unsigned strips, unsigned bands,
-                                                           int band_rows, unsigned total_items, int aligned)
+template <int N, int NT, int NOUT>
+__global__ __launch_bounds__(256, (NT >= 3 && N >= 6) ? 3 : 4) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1,
+                                                           unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
     typedef Roll<N> R;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *mine = lds + wv * (2 * NT * R::BUFW);             // two LDS rows per term, private to this wave
+    float *mine = lds + wv * (2 * NOUT * NT * R::BUFW);      // two LDS rows per output and term, private to this wave
 
     // persistent waves; blocks that share an XCD (blockIdx % 8) take neighbouring items (halo columns meet in L2)
     const unsigned nblk = gridDim.x;
@@ -246,12 +254,14 @@ __global__ __launch_bounds__(256, (NT >= 3 && N >= 6) ? 3 : 4) void sg2d_rolling
         const int sx = (int)strip * R::SW, yb = (int)band * band_rows;
         const int nout = job.rows - yb < band_rows ? job.rows - yb : band_rows;
         const float *in = job.in + (long long)img * job.in_pitch;
-        float *out = job.out + (long long)img * job.out_pitch;
+        float *outs[NOUT];
+        outs[0] = job.out + (long long)img * job.out_pitch;
+        if constexpr (NOUT > 1) outs[1] = out1 + (long long)img * job.out_pitch;
         // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
         if (aligned == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
-            roll_item<N, NT, true>(job, taps, mine, in, out, sx, yb, nout, lane, xlo, xhi, ylo, yhi);
+            roll_item<N, NT, NOUT, true>(job, taps, mine, in, outs, sx, yb, nout, lane, xlo, xhi, ylo, yhi);
         else
-            roll_item<N, NT, false>(job, taps, mine, in, out, sx, yb, nout, lane, xlo, xhi, ylo, yhi);
+            roll_item<N, NT, NOUT, false>(job, taps, mine, in, outs, sx, yb, nout, lane, xlo, xhi, ylo, yhi);
     }
 }
 
@@ -274,35 +284,45 @@ static bool vector_parity(const float *v, int n, float *sign)
     return false;
 }
 
-template <int N, int NT>
-static int launch_roll(const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
+// fill output o's taps from its factor block; false when a vector has no definite parity or the terms disagree
+template <int N, int NT, int NOUT>
+static bool fill_taps(RollTaps<N, NT, NOUT> &taps, int o, const float *factors, float scale)
 {
-    typedef Roll<N> R;
-    RollTaps<N, NT> taps;
-    memset(&taps, 0, sizeof(taps));
     float sy = 0.0f, sx = 0.0f;
     for (int t = 0; t < NT; ++t) {
         const float *q = factors + (size_t)t * 2 * (2 * N + 2), *g = q + (2 * N + 2);
         float s1, s2;
-        if (!vector_parity(g, N, &s1) || !vector_parity(q, N, &s2)) return 1;
-        if (t > 0 && (s1 != sy || s2 != sx)) return 1;
+        if (!vector_parity(g, N, &s1) || !vector_parity(q, N, &s2)) return false;
+        if (t > 0 && (s1 != sy || s2 != sx)) return false;
         sy = s1; sx = s2;
         for (int k = 0; k <= N; ++k) {
             const float gk = (k == N && sy < 0.0f) ? 0.0f : g[k];
             const float qk = (k == N && sx < 0.0f) ? 0.0f : (float)((double)q[k] * (double)scale);
-            if (k & 1) { taps.g[t][k >> 1].y = gk; taps.q[t][k >> 1].y = qk; }
-            else       { taps.g[t][k >> 1].x = gk; taps.q[t][k >> 1].x = qk; }
+            if (k & 1) { taps.g[o][t][k >> 1].y = gk; taps.q[o][t][k >> 1].y = qk; }
+            else       { taps.g[o][t][k >> 1].x = gk; taps.q[o][t][k >> 1].x = qk; }
         }
     }
-    taps.sy = f32x2{sy, sy};
-    taps.sx = f32x2{sx, sx};
+    taps.sy[o] = f32x2{sy, sy};
+    taps.sx[o] = f32x2{sx, sx};
+    return true;
+}
+
+template <int N, int NT, int NOUT>
+static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], const float (&scale)[NOUT], float *out1, unsigned images,
+                       int cu_count, hipStream_t st)
+{
+    typedef Roll<N> R;
+    RollTaps<N, NT, NOUT> taps;
+    memset(&taps, 0, sizeof(taps));
+    for (int o = 0; o < NOUT; ++o)
+        if (!fill_taps<N, NT, NOUT>(taps, o, factors[o], scale[o])) return 1;
 
     const unsigned strips = (unsigned)((job.cols + R::SW - 1) / R::SW);
     static int per_cu = 0;                                   // resident blocks per CU of this instantiation
-    const size_t lds = sizeof(float) * 4 * 2 * NT * R::BUFW;
+    const size_t lds = sizeof(float) * 4 * 2 * NOUT * NT * R::BUFW;
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT>, 256, lds) != hipSuccess || nb < 1) nb = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT>, 256, lds) != hipSuccess || nb < 1) nb = 2;
         per_cu = nb > 4 ? 4 : nb;
     }
     const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
@@ -314,18 +334,39 @@ static int launch_roll(const Job2D &job, const float *factors, float scale, unsi
     grid = (grid + 7u) & ~7u;
     int aligned = 0;
     if (job.in_stride % 4 == 0 && job.in_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.in) & 15u) == 0) aligned |= 1;
-    if (job.out_stride % 4 == 0 && job.out_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.out) & 15u) == 0) aligned |= 2;
-    hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT>), dim3(grid), dim3(256), lds, st, job, taps, strips, bands, band_rows, (unsigned)total,
-                       aligned);
+    if (job.out_stride % 4 == 0 && job.out_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.out) & 15u) == 0 &&
+        (NOUT == 1 || (reinterpret_cast<uintptr_t>(out1) & 15u) == 0)) aligned |= 2;
+    hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT>), dim3(grid), dim3(256), lds, st, job, taps, out1, strips, bands, band_rows,
+                       (unsigned)total, aligned);
     return 0;
 }
 
 template <int N, int NT>
 static int dispatch_roll(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
 {
-    if (n == N && terms == NT) return launch_roll<N, NT>(job, factors, scale, images, cu_count, st);
+    if (n == N && terms == NT) {
+        const float *const f1[1] = {factors};
+        const float s1[1] = {scale};
+        return launch_roll<N, NT, 1>(job, f1, s1, nullptr, images, cu_count, st);
+    }
     if constexpr (NT < SEP_MAX_TERMS) return dispatch_roll<N, NT + 1>(n, terms, job, factors, scale, images, cu_count, st);
     else if constexpr (N < SEP_ROLL_MAX_N) return dispatch_roll<N + 1, 1>(n, terms, job, factors, scale, images, cu_count, st);
+    else return 1;
+}
+
+// two output frames from one walk over the input, the same number of terms (<= 3) for both: the gradient
+constexpr int ROLL2_MAX_TERMS = 3;
+template <int N, int NT>
+static int dispatch_roll2(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1, unsigned images,
+                          int cu_count, hipStream_t st)
+{
+    if (n == N && terms == NT) {
+        const float *const ff[2] = {f0, f1};
+        const float ss[2] = {s0, s1};
+        return launch_roll<N, NT, 2>(job, ff, ss, out1, images, cu_count, st);
+    }
+    if constexpr (NT < ROLL2_MAX_TERMS) return dispatch_roll2<N, NT + 1>(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
+    else if constexpr (N < SEP_ROLL_MAX_N) return dispatch_roll2<N + 1, 1>(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
     else return 1;
 }
 
@@ -335,6 +376,14 @@ int SEP_ROLL_FN(int n, int terms, const Job2D &job, const float *factors, float 
 {
     if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > SEP_MAX_TERMS) return 1;
     return dispatch_roll<SEP_ROLL_MIN_N, 1>(n, terms, job, factors, scale, images, cu_count, st);
+}
+
+// the two-output form: job.out and out1 share stride and pitch; both outputs have `terms` terms
+int SEP_ROLL_FN2(int n, int terms, const Job2D &job, const float *factors0, float scale0, const float *factors1, float scale1, float *out1,
+                 unsigned images, int cu_count, hipStream_t st)
+{
+    if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > ROLL2_MAX_TERMS) return 1;
+    return dispatch_roll2<SEP_ROLL_MIN_N, 1>(n, terms, job, factors0, scale0, factors1, scale1, out1, images, cu_count, st);
 }
 
 }  // namespace sg
