@@ -10,9 +10,21 @@
  *
  * Each function names the reference routine whose arithmetic it performs.  All of them return
  * 0 on success and -1 on error unless stated otherwise; savgol_hip_last_error() has the text.
- * Launches are asynchronous on `stream`; nothing here allocates, frees or synchronises on the
- * hot path (weight tables are uploaded once per distinct filter and cached), so the batch calls
- * can be captured into a hipGraph.
+ * Launches are asynchronous on `stream`.  What "enqueue only" means, entry point by entry point:
+ *   - savgol_apply[_valid]_batch_f32/f64, savgol2d_apply_batch_f32, savgol2d_gradient/hessian/laplacian_batch_f32 (square and
+ *     rectangular windows), savgol_streambank_push/_push_full/_push_block/_flush/_flush_leading/_reset: launches only --
+ *     capturable into a hipGraph AFTER one warm-up call with the same filter: the FIRST call with a new filter content
+ *     uploads its tables (hipMalloc + a synchronous hipMemcpy, then cached for the life of the process; tables are never
+ *     freed or moved, so captured graphs and queued launches stay valid) and, for the derivative frames, solves the
+ *     least-squares problem on the host (cached per configuration);
+ *   - savgol_apply_strided_batch_f32: launches plus a stream-ordered hipMallocAsync/hipFreeAsync pair for its two dense
+ *     frames (no shared scratch, no lock, no synchronise);
+ *   - savgol_streambank_save/_load, savgol_hip_synchronize and every host-pointer drop-in call of savgolFilter.h /
+ *     savgol_stream.h / savgol2d.h: synchronous by nature (they return host data).
+ * Accuracy of the default fp32 device kernels against the double-accumulation oracle (normwise, max|err| / max|ref|):
+ * <= 1e-6 for smoothing filters (derivative 0), <= 2e-6 for derivative filters on the 1-D path (the reference's own fp32
+ * paths -- batch vs stream -- disagree by 1.3e-6 there), <= 4e-6 for 2-D derivative frames.  Bit-identical-to-the-reference
+ * results: SAVGOL_HIP_OPT_REFERENCE_SUMMATION (1-D), method 1 (2-D), and every host-pointer drop-in call.
  */
 #ifndef SAVGOL_HIP_H
 #define SAVGOL_HIP_H
@@ -70,7 +82,7 @@ long savgol_export_header(const SavgolFilter *filter, const char *prefix, const 
  * Arithmetic of savgol_apply (reference src/savgolFilter.c:743-804): centre taps on the
  * interior, filter->config.boundary on the first/last n samples (POLYNOMIAL rows incl. the
  * reference's reversed leading edge; REFLECT / PERIODIC / CONSTANT by index remap).
- * d_in and d_out must not overlap.  length >= 2n+1.
+ * d_in and d_out must not overlap (checked: -1).  length >= 2n+1.
  * f32: fp32 tables, fp32 FMA accumulation (within 1e-6 normwise of the fp64 oracle).
  * f64: the same fp32 tables promoted exactly to double, double accumulation, the reference's
  *      float 1/dt_scale promoted -- there is no fp64 path in the reference.

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "sg_2d.hpp"
 #include "sg_runtime.hpp"
@@ -303,31 +304,36 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
     DeviceCtx *ctx = ctx_get();
     if (!ctx) return -1;
 
-    if (nx != ny) {                                       // dense fallback: one filter per output (reference structure)
-        float *sum_out = specs[0].out;
-        for (int i = 0; i < nspec; ++i) {
+    if (nx != ny) {
+        // rectangular windows: the dense kernel, one launch per output frame; the Laplacian is ONE launch with the summed
+        // kernel sxx*Wxx + syy*Wyy (no temporary frame, no add pass, nothing but launches: capturable into a hipGraph)
+        Savgol2DFilter *fs[SEP_MAX_OUTPUTS] = {nullptr, nullptr, nullptr};
+        int rc = 0;
+        for (int i = 0; i < nspec && rc == 0; ++i) {
             cfg.deriv_x = (uint8_t)specs[i].dx; cfg.deriv_y = (uint8_t)specs[i].dy;
-            Savgol2DFilter *f = savgol2d_create(&cfg);
-            if (!f) return -1;
-            float *dst = specs[i].out;
-            std::unique_lock<std::recursive_mutex> lock(ctx->mu, std::defer_lock);
-            if (sum_into_one && i > 0) {                 // d2/dy2 into scratch, then out += scratch (reference :598-613)
-                lock.lock();
-                dst = static_cast<float *>(ctx_arena(ctx, sizeof(float) * images * out_pitch));
-                if (!dst) { savgol2d_destroy(f); return -1; }
-                if (!hip_ok(hipMemsetAsync(dst, 0, sizeof(float) * images * out_pitch, st), who)) { savgol2d_destroy(f); return -1; }
-            }
-            int rc = enqueue_2d(who, f, d_in, rows, cols, in_stride, (long long)in_pitch, dst, out_stride, (long long)out_pitch, images, boundary, 1, st);
-            savgol2d_destroy(f);
-            if (rc != 0) return rc;
-            if (sum_into_one && i > 0) {
-                for (size_t k = 0; k < images; ++k)
-                    hipLaunchKernelGGL(sg2d_add_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, st, sum_out + k * out_pitch,
-                                       dst + k * out_pitch, rows, cols, out_stride);
-                if (!hip_ok(hipStreamSynchronize(st), who)) return -1;        // scratch is released with the lock
-            }
+            fs[i] = savgol2d_create(&cfg);
+            if (!fs[i]) rc = -1;
         }
-        return hip_ok(hipGetLastError(), who) ? 0 : -1;
+        if (rc == 0 && sum_into_one) {
+            const int area = fs[0]->window_area;
+            std::vector<float> wsum((size_t)area);
+            for (int k = 0; k < area; ++k) {
+                double acc = 0.0;
+                for (int i = 0; i < nspec; ++i) acc += (double)fs[i]->scale * (double)fs[i]->weights[k];
+                wsum[(size_t)k] = (float)acc;
+            }
+            Savgol2DFilter summed = *fs[0];
+            summed.weights = wsum.data();
+            summed.scale = 1.0f;
+            rc = enqueue_2d(who, &summed, d_in, rows, cols, in_stride, (long long)in_pitch, specs[0].out, out_stride, (long long)out_pitch,
+                            images, boundary, 1, st);               // the table is copied into the device cache before this returns
+        } else if (rc == 0) {
+            for (int i = 0; i < nspec && rc == 0; ++i)
+                rc = enqueue_2d(who, fs[i], d_in, rows, cols, in_stride, (long long)in_pitch, specs[i].out, out_stride, (long long)out_pitch,
+                                images, boundary, 1, st);
+        }
+        for (int i = 0; i < nspec; ++i) savgol2d_destroy(fs[i]);
+        return rc;
     }
 
     const int n = nx, ws = 2 * n + 1;
@@ -508,8 +514,12 @@ int savgol2d_laplacian(int half_win_x, int half_win_y, int poly_order, const flo
         float *d_a = static_cast<float *>(sg::ctx_arena(ctx, 2 * n * sizeof(float)));
         if (!d_a) { free(temp); return -1; }
         float *d_b = d_a + n;
-        bool ok = sg::hip_ok(hipMemcpy(d_a, output, n * sizeof(float), hipMemcpyHostToDevice), "H2D copy") &&
-                  sg::hip_ok(hipMemcpy(d_b, temp, n * sizeof(float), hipMemcpyHostToDevice), "H2D copy");
+        // rows x cols only: the caller's frame may be a sub-view whose last row ends at `cols`, not at `stride` (the
+        // reference touches cols floats per row, :609-613)
+        bool ok = sg::hip_ok(hipMemcpy2D(d_a, sizeof(float) * stride, output, sizeof(float) * stride, sizeof(float) * cols, rows,
+                                         hipMemcpyHostToDevice), "H2D copy") &&
+                  sg::hip_ok(hipMemcpy2D(d_b, sizeof(float) * stride, temp, sizeof(float) * stride, sizeof(float) * cols, rows,
+                                         hipMemcpyHostToDevice), "H2D copy");
         if (ok) {
             hipLaunchKernelGGL(sg::sg2d_add_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, nullptr, d_a, d_b, rows, cols, stride);
             ok = sg::hip_ok(hipGetLastError(), "add kernel") &&

@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <utility>
@@ -327,9 +328,13 @@ static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], co
     }
     const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
     unsigned bands = choose_bands(job.rows, (unsigned long long)images * strips, nwaves, N, 0.3);   // warm-up rows are only loaded
+    static const char *env_bands = getenv("SAVGOL_HIP_ROLL_BANDS"), *env_one = getenv("SAVGOL_HIP_ROLL_ONEWAVE");     // tuning knobs
+    if (env_bands && atoi(env_bands) > 0 && atoi(env_bands) <= job.rows) bands = (unsigned)atoi(env_bands);
     const int band_rows = (int)((job.rows + (int)bands - 1) / (int)bands);
+    bands = (unsigned)((job.rows + band_rows - 1) / band_rows);
     const unsigned long long total = (unsigned long long)images * strips * bands;     // caller keeps this < 2^32
     unsigned grid = (unsigned)cu_count * (unsigned)per_cu;
+    if (env_one && atoi(env_one)) grid = (unsigned)((total + 3) / 4);
     if ((unsigned long long)grid * 4ull > total) grid = (unsigned)((total + 3) / 4);
     grid = (grid + 7u) & ~7u;
     int aligned = 0;

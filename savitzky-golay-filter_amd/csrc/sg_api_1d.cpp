@@ -2,6 +2,7 @@
 // the device-pointer batch entry points of savgol_hip.h.  All arithmetic on samples happens in the
 // HIP kernels (sg_k1d.hpp); this file validates, picks tile geometry and enqueues.
 #include <atomic>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -114,6 +115,11 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     const size_t out_len = (variant == VALID) ? length - 2 * (size_t)n : length;
     if (in_ld < length || out_ld < out_len) { sg_set_error("%s: row pitch smaller than the row", who); return -1; }
     if (channels == 0) return 0;
+    {   // tiles read their halo from the input while neighbouring tiles store: overlapping buffers would race
+        const uintptr_t a0 = (uintptr_t)d_in, a1 = a0 + ((channels - 1) * in_ld + length) * sizeof(T);
+        const uintptr_t b0 = (uintptr_t)d_out, b1 = b0 + ((channels - 1) * out_ld + out_len) * sizeof(T);
+        if (a0 < b1 && b0 < a1) { sg_set_error("%s: d_in and d_out overlap (the device batch calls are out of place)", who); return -1; }
+    }
 
     DeviceCtx *ctx = sg::ctx_get();
     if (!ctx) return -1;
@@ -302,24 +308,25 @@ int savgol_apply_strided_batch_f32(const SavgolFilter *filter, const void *d_in,
     if (channels == 0) return 0;
     DeviceCtx *ctx = sg::ctx_get();
     if (!ctx) return -1;
-    // gather the field into dense rows, filter, scatter back (the arena stays locked meanwhile)
-    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    // gather the field into dense rows, filter, scatter back.  The two dense frames are this call's own, allocated and freed in
+    // stream order (hipMallocAsync / hipFreeAsync): no shared arena, no lock, no synchronise -- the call only enqueues.
     const size_t ld = (count + 3) & ~(size_t)3;
-    float *dense = static_cast<float *>(sg::ctx_arena(ctx, 2 * channels * ld * sizeof(float)));
-    if (!dense) return -1;
-    float *result = dense + channels * ld;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    float *dense = nullptr;
+    if (!sg::hip_ok(hipMallocAsync(reinterpret_cast<void **>(&dense), 2 * channels * ld * sizeof(float), st), "hipMallocAsync(strided scratch)")) return -1;
+    float *result = dense + channels * ld;
+    int rc = 0;
     if (sg_launch_gather_f32(d_in, in_stride, in_offset, in_channel_pitch, dense, ld, channels, count, st) != 0) {
         sg_set_error("%s: gather launch failed", who);
-        return -1;
+        rc = -1;
     }
-    if (enqueue_batch<float>(who, filter, dense, result, channels, count, ld, ld, FULL_POLY_EDGES, st, g_reference_summation.load() != 0) != 0) return -1;
-    if (sg_launch_scatter_f32(result, ld, d_out, out_stride, out_offset, out_channel_pitch, channels, count, st) != 0) {
+    if (rc == 0 && enqueue_batch<float>(who, filter, dense, result, channels, count, ld, ld, FULL_POLY_EDGES, st, g_reference_summation.load() != 0) != 0) rc = -1;
+    if (rc == 0 && sg_launch_scatter_f32(result, ld, d_out, out_stride, out_offset, out_channel_pitch, channels, count, st) != 0) {
         sg_set_error("%s: scatter launch failed", who);
-        return -1;
+        rc = -1;
     }
-    // the arena may be reused by the next call: finish before releasing the lock
-    return sg::hip_ok(hipStreamSynchronize(st), who) ? 0 : -1;
+    if (!sg::hip_ok(hipFreeAsync(dense, st), "hipFreeAsync(strided scratch)")) rc = -1;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

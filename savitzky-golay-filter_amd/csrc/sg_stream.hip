@@ -486,6 +486,18 @@ struct SavgolStreamBank {
 
 namespace sg {
 static unsigned bank_blocks(const SavgolStreamBank *b) { return (unsigned)((b->streams + 255) / 256); }
+// A bank's ring and tables live on the device it was created on; launching from a thread whose current device is another
+// one would hand foreign pointers to that GPU.  Every entry point that touches the device checks.
+static bool bank_on_current_device(const SavgolStreamBank *b, const char *who)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != b->device) {
+        sg_set_error("%s: the bank lives on device %d but this thread's current device is %d (call savgol_hip_set_device(%d) first)", who,
+                     b->device, cur, b->device);
+        return false;
+    }
+    return true;
+}
 }
 
 extern "C" {
@@ -526,6 +538,7 @@ void savgol_streambank_destroy(SavgolStreamBank *bank)
 int savgol_streambank_reset(SavgolStreamBank *bank, void *stream)
 {
     if (!bank) { sg_set_error("savgol_streambank_reset: NULL bank"); return -1; }
+    if (!sg::bank_on_current_device(bank, "savgol_streambank_reset")) return -1;
     bank->wp = 0; bank->received = 0; bank->emitted = 0;
     const size_t bytes = sizeof(float) * (size_t)bank->filter->window_size * bank->streams;
     return sg::hip_ok(hipMemsetAsync(bank->d_ring, 0, bytes, static_cast<hipStream_t>(stream)), "hipMemsetAsync") ? 0 : -1;
@@ -534,6 +547,7 @@ int savgol_streambank_reset(SavgolStreamBank *bank, void *stream)
 int savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream)
 {
     if (!bank || !d_samples || !d_out) { sg_set_error("savgol_streambank_push: NULL pointer"); return -1; }
+    if (!sg::bank_on_current_device(bank, "savgol_streambank_push")) return -1;
     const int ws = bank->filter->window_size;
     const int emit = (bank->received + 1 >= (unsigned long long)ws) ? 1 : 0;
     if (emit) {
@@ -556,6 +570,7 @@ int savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float
 int savgol_streambank_push_full(SavgolStreamBank *bank, const float *d_samples, float *d_out, int max_rows, void *stream)
 {
     if (!bank || !d_samples || !d_out || max_rows <= 0) { sg_set_error("savgol_streambank_push_full: bad arguments"); return -1; }
+    if (!sg::bank_on_current_device(bank, "savgol_streambank_push_full")) return -1;
     const int ws = bank->filter->window_size, n = bank->filter->config.half_window;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool was_filling = bank->received < (unsigned long long)ws;
@@ -589,6 +604,7 @@ static int method_env()
 int savgol_streambank_push_block(SavgolStreamBank *bank, const float *d_samples, size_t ticks, float *d_out, void *stream)
 {
     if (!bank || !d_samples || !d_out) { sg_set_error("savgol_streambank_push_block: NULL pointer"); return -1; }
+    if (!sg::bank_on_current_device(bank, "savgol_streambank_push_block")) return -1;
     if (ticks == 0) return 0;
     const int ws = bank->filter->window_size;
     sg::StreamTaps taps;
@@ -642,12 +658,14 @@ static int bank_edge_rows(SavgolStreamBank *bank, float *d_out, int max_rows, vo
 int savgol_streambank_flush(SavgolStreamBank *bank, float *d_out, int max_rows, void *stream)
 {
     if (!bank || !d_out || max_rows <= 0) { sg_set_error("savgol_streambank_flush: bad arguments"); return -1; }
+    if (!sg::bank_on_current_device(bank, "savgol_streambank_flush")) return -1;
     return bank_edge_rows(bank, d_out, max_rows, stream, false, "savgol_streambank_flush launch");
 }
 
 int savgol_streambank_flush_leading(SavgolStreamBank *bank, float *d_out, int max_rows, void *stream)
 {
     if (!bank || !d_out || max_rows <= 0) { sg_set_error("savgol_streambank_flush_leading: bad arguments"); return 0; }
+    if (!sg::bank_on_current_device(bank, "savgol_streambank_flush_leading")) return 0;
     const int rc = bank_edge_rows(bank, d_out, max_rows, stream, true, "savgol_streambank_flush_leading launch");
     return rc < 0 ? 0 : rc;
 }
@@ -659,7 +677,8 @@ size_t savgol_streambank_samples_received(const SavgolStreamBank *bank) { return
 size_t savgol_streambank_samples_output(const SavgolStreamBank *bank) { return bank ? (size_t)bank->emitted : 0; }
 
 // checkpoint blob: {wp, received, emitted} header + the ring
-struct BankHeader { long long wp; unsigned long long received, emitted; unsigned long long streams; unsigned long long ws; };
+struct BankHeader { long long wp; unsigned long long received, emitted; unsigned long long streams; unsigned long long ws; unsigned long long magic; };
+static const unsigned long long kBankMagic = 0x5347424b30303032ull;      // "SGBK0002"
 
 size_t savgol_streambank_state_bytes(const SavgolStreamBank *bank)
 {
@@ -669,7 +688,8 @@ size_t savgol_streambank_state_bytes(const SavgolStreamBank *bank)
 int savgol_streambank_save(const SavgolStreamBank *bank, void *host_blob, void *stream)
 {
     if (!bank || !host_blob) { sg_set_error("savgol_streambank_save: NULL pointer"); return -1; }
-    BankHeader h = {bank->wp, bank->received, bank->emitted, bank->streams, (unsigned long long)bank->filter->window_size};
+    if (!sg::bank_on_current_device(bank, "savgol_streambank_save")) return -1;
+    BankHeader h = {bank->wp, bank->received, bank->emitted, bank->streams, (unsigned long long)bank->filter->window_size, kBankMagic};
     memcpy(host_blob, &h, sizeof(h));
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!sg::hip_ok(hipMemcpyAsync(static_cast<char *>(host_blob) + sizeof(h), bank->d_ring,
@@ -681,10 +701,18 @@ int savgol_streambank_save(const SavgolStreamBank *bank, void *host_blob, void *
 int savgol_streambank_load(SavgolStreamBank *bank, const void *host_blob, void *stream)
 {
     if (!bank || !host_blob) { sg_set_error("savgol_streambank_load: NULL pointer"); return -1; }
+    if (!sg::bank_on_current_device(bank, "savgol_streambank_load")) return -1;
     BankHeader h;
     memcpy(&h, host_blob, sizeof(h));
+    if (h.magic != kBankMagic) { sg_set_error("savgol_streambank_load: not a stream-bank blob (bad magic)"); return -1; }
     if (h.streams != bank->streams || h.ws != (unsigned long long)bank->filter->window_size) {
         sg_set_error("savgol_streambank_load: blob is for %llu streams / window %llu", h.streams, h.ws);
+        return -1;
+    }
+    // the write position indexes the ring in every later kernel: it must be inside it and consistent with the counters
+    if (h.wp < 0 || (unsigned long long)h.wp >= h.ws || (unsigned long long)h.wp != h.received % h.ws || h.emitted > h.received) {
+        sg_set_error("savgol_streambank_load: corrupt blob (write position %lld, %llu received, %llu emitted, window %llu)", h.wp, h.received,
+                     h.emitted, h.ws);
         return -1;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -456,3 +456,52 @@ def test_reference_summation_batch_mode_is_bit_identical(sg, sgo, torch_gpu, n):
             assert same_bits(g[:, :length - 2 * n], want) and np.all(g[:, length - 2 * n:] == -9.0), (n, "valid")
     finally:
         assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 0) == 0
+
+
+def test_overlapping_device_buffers_are_refused(sg, torch_gpu):
+    """The device batch calls are out of place (tiles read halos while their neighbours store); savgol_hip.h says so and
+    the call checks instead of racing silently."""
+    torch = torch_gpu
+    x = torch.randn((4, 5000), device="cuda")
+    f = sg.Filter(8, 3)
+    with pytest.raises(RuntimeError, match="overlap"):
+        f.apply_batch(x, x, 4, 5000)
+    with pytest.raises(RuntimeError, match="overlap"):
+        f.apply_batch(x, x[1:], 3, 5000)                 # shifted by one row: still overlapping
+    y = torch.empty_like(x)
+    f.apply_batch(x, y, 4, 5000)                         # disjoint: fine
+
+
+def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu):
+    """half_window 32: the default kernel (block moments, csrc/sg_k1d_moment.hpp) and the plain 65-tap kernel
+    (SAVGOL_HIP_OPT_PLAIN_SUMMATION) are both within 1e-6 of the fp64 oracle and within 1e-6 of each other, for every boundary
+    mode, VALID, derivative filters (2e-6) and a hand-edited table (which must silently take the plain kernel)."""
+    torch = torch_gpu
+    L = sg.lib()
+    x = torch.empty((6, 70001), dtype=torch.float32, device="cuda")
+    sg.synth(x)
+    xh = x.cpu().numpy().astype(np.float64)
+    for (m, d, mode, tol) in [(4, 0, 0, 1e-6), (4, 0, 1, 1e-6), (4, 0, 2, 1e-6), (4, 0, 3, 1e-6), (2, 0, 1, 1e-6), (6, 0, 1, 1e-6),
+                              (4, 1, 3, 2e-6), (4, 2, 0, 2e-5), (3, 1, 2, 2e-6)]:
+        f = sg.Filter(32, m, d, 1.0, mode)
+        ref = sgo.Filter(32, m, d, 1.0, mode).apply_f64(xh)
+        a = f.apply_tensor(x).cpu().numpy()
+        assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 1) == 0
+        try:
+            b = f.apply_tensor(x).cpu().numpy()
+        finally:
+            L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 0)
+        assert not np.array_equal(a, b), "the option did not switch kernels"
+        assert normwise(a, ref) < tol and normwise(b, ref) < tol, (m, d, mode, normwise(a, ref), normwise(b, ref))
+        v = f.apply_tensor(x, valid=True).cpu().numpy()
+        assert normwise(v, ref[:, 32:-32]) < tol
+    # a table that is not a polynomial: same result with and without the option (both run the plain kernel)
+    f = sg.Filter(32, 4, 0, 1.0, 1)
+    f.ptr.contents.center_weights[20] += 3e-4
+    a = f.apply_tensor(x).cpu().numpy()
+    L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 1)
+    try:
+        b = f.apply_tensor(x).cpu().numpy()
+    finally:
+        L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 0)
+    assert np.array_equal(a, b)

@@ -129,7 +129,7 @@ def test_2d_batch_and_derivative_calls_are_graph_capturable(sg, torch_gpu):
     torch = torch_gpu
     images, rows, cols = 3, 200, 520
     x = torch.randn((images, rows, cols), device="cuda")
-    outs = [torch.zeros_like(x) for _ in range(7)]
+    outs = [torch.zeros_like(x) for _ in range(9)]
     f = sg.Filter2D(7, 7, 3)
     L = sg.lib()
     pitch = rows * cols
@@ -142,6 +142,11 @@ def test_2d_batch_and_derivative_calls_are_graph_capturable(sg, torch_gpu):
                                              cols, pitch, images, 1.0, 1.0, 1, h) == 0
         assert L.savgol2d_hessian_batch_f32(7, 7, 3, x.data_ptr(), rows, cols, cols, pitch, outs[4].data_ptr(), outs[5].data_ptr(),
                                             outs[6].data_ptr(), cols, pitch, images, 1.0, 1.0, 1, h) == 0
+        # rectangular windows (nx != ny): round 1 synchronised and used a shared scratch frame here
+        assert L.savgol2d_laplacian_batch_f32(4, 6, 3, x.data_ptr(), rows, cols, cols, pitch, outs[7].data_ptr(), cols, pitch, images,
+                                              1.0, 1.0, 1, h) == 0
+        assert L.savgol2d_laplacian_batch_f32(7, 7, 3, x.data_ptr(), rows, cols, cols, pitch, outs[8].data_ptr(), cols, pitch, images,
+                                              1.0, 1.0, 2, h) == 0
 
     enqueue(None)                                              # warm-up: uploads weight / factor tables
     torch.cuda.synchronize()

@@ -278,3 +278,30 @@ def test_randomized_stream_bank_sequences(sg, sgo, torch_gpu):
             a, b2 = np.array(want[s], np.float32), np.array(got[s], np.float32)
             assert a.shape == b2.shape and same_bits(a, b2), (it, n, m, d, dt, S, T, s)
         assert tuple(bank.counters) == tuple(oracles[pick[0]].counters[:2])
+
+
+def test_corrupt_checkpoint_and_foreign_device_are_refused(sg, torch_gpu):
+    """ADVICE r01: a blob whose write position lies outside the ring (or disagrees with the counters) must not be loaded;
+    a blob without the magic is not a blob."""
+    import ctypes as C
+    torch = torch_gpu
+    bank = sg.StreamBank(64, 5, 3, 0, 1.0)
+    x = torch.randn((20, 64), device="cuda")
+    out = torch.zeros_like(x)
+    assert bank.push_block(x, 20, out) == 20 - 10
+    torch.cuda.synchronize()
+    blob = bank.save()
+    hdr = np.frombuffer(blob, dtype=np.int64, count=6).copy()          # wp, received, emitted, streams, ws, magic
+    assert hdr[0] == 20 % 11 and hdr[1] == 20 and hdr[4] == 11
+    L = sg.lib()
+
+    def load(h):
+        b = bytearray(blob)
+        b[:48] = h.tobytes()
+        return L.savgol_streambank_load(bank.ptr, bytes(b), None)
+    assert load(hdr) == 0
+    for idx, bad in ((0, 11), (0, -1), (0, 3), (2, 21), (5, 12345)):
+        h = hdr.copy(); h[idx] = bad
+        assert load(h) == -1, (idx, bad)
+    assert "blob" in sg.last_error()
+    assert load(hdr) == 0                                              # still usable afterwards
