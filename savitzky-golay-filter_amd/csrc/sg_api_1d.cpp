@@ -6,7 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "sg_k1d_host.hpp"
@@ -249,6 +252,116 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long host-pointer signals: upload, filter and download in chunks so that the two directions of the host link run at the
+// same time (round 1 ran H2D -> kernel -> D2H back to back: 6.9 Gsamples/s at 2^26 samples, half of a full-duplex link).
+//   main thread : for every chunk  H2D(samples up to the chunk's right halo) -> reference-order kernel on [a_k, b_k) -> event
+//   helper      : for every chunk  wait(event) -> D2H of [a_k, b_k) into the caller's buffer
+// then the first / last 32 outputs (every boundary mode's edge handling) by the per-thread reference-order kernel.  Chunks
+// are sub-rows handed to the same kernels the unchunked call uses (pointer + 32-sample halo; what lies beyond a sub-row only
+// reaches outputs that are not stored), so the result is the reference's, bit for bit, as before.
+// ------------------------------------------------------------------------------------------------
+constexpr size_t PIPE_MIN_LENGTH = (size_t)1 << 23;       // below this the plain path is as fast
+constexpr size_t PIPE_CHUNK = (size_t)1 << 22;            // 16 MB of samples per chunk
+constexpr int    PIPE_HALO = 32;                          // >= any half window, multiple of 4
+
+struct PipeStreams { hipStream_t up = nullptr, down = nullptr; };
+PipeStreams *pipe_streams(DeviceCtx *ctx)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, PipeStreams *>> all;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &e : all) if (e.first == ctx->ordinal) return e.second;
+    PipeStreams *p = new PipeStreams();
+    if (hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking) != hipSuccess) {
+        delete p;
+        return nullptr;
+    }
+    all.emplace_back(ctx->ordinal, p);
+    return p;
+}
+
+// variant FULL: output[j] for j in [0, L); VALID: output[j - n] for j in [n, L - n).  Caller holds ctx->mu.  0 on success.
+int host_apply_pipelined(const char *who, DeviceCtx *ctx, const SavgolFilter *f, const float *input, float *output, size_t L, Variant variant)
+{
+    if (!filter_sane(f, who)) return -1;
+    const int n = f->config.half_window, ws = f->window_size;
+    PipeStreams *ps = pipe_streams(ctx);
+    if (!ps) { sg_set_error("%s: could not create copy streams", who); return -1; }
+    const size_t ld = (L + 3) & ~(size_t)3;
+    float *d_in = static_cast<float *>(sg::ctx_arena(ctx, 2 * ld * sizeof(float)));
+    if (!d_in) return -1;
+    float *d_out = d_in + ld;
+    float packed[(SAVGOL_MAX_HALF_WINDOW + 1) * SAVGOL_MAX_WINDOW];
+    memcpy(packed, f->center_weights, sizeof(float) * ws);
+    for (int e = 0; e < n; ++e) memcpy(packed + (size_t)(1 + e) * ws, f->edge_weights[e], sizeof(float) * ws);
+    const float *d_table = sg::ctx_table(ctx, packed, sizeof(float) * (size_t)(n + 1) * ws, 0x1e00u + (unsigned)n);
+    if (!d_table) return -1;
+    const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
+    const int shift = (variant == VALID) ? n : 0;
+    const float dt_inv = dt_inverse(f);
+
+    const size_t lo = PIPE_HALO, hi = L - PIPE_HALO;                       // centre outputs [lo, hi) go through the chunks
+    const size_t nchunks = (hi - lo + PIPE_CHUNK - 1) / PIPE_CHUNK;
+    std::vector<hipEvent_t> done(nchunks, nullptr);
+    for (auto &e : done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { sg_set_error("%s: hipEventCreate failed", who); return -1; }
+
+    std::atomic<int> down_rc{0};
+    std::atomic<size_t> posted{0};                                         // chunks whose event has been recorded
+    std::atomic<bool> abort_flag{false};
+    const int device = ctx->ordinal;
+    std::thread helper([&] {
+        if (hipSetDevice(device) != hipSuccess) { down_rc = -1; return; }
+        for (size_t k = 0; k < nchunks; ++k) {
+            while (posted.load(std::memory_order_acquire) <= k) {
+                if (abort_flag.load()) return;
+                std::this_thread::yield();
+            }
+            const size_t a = lo + k * PIPE_CHUNK, b = std::min(a + PIPE_CHUNK, hi);
+            if (hipStreamWaitEvent(ps->down, done[k], 0) != hipSuccess ||
+                hipMemcpyAsync(output + (a - shift), d_out + (a - shift), (b - a) * sizeof(float), hipMemcpyDeviceToHost, ps->down) != hipSuccess ||
+                hipStreamSynchronize(ps->down) != hipSuccess) { down_rc = -1; return; }
+        }
+    });
+
+    int rc = 0;
+    size_t uploaded = 0;
+    for (size_t k = 0; k < nchunks && rc == 0; ++k) {
+        const size_t a = lo + k * PIPE_CHUNK, b = std::min(a + PIPE_CHUNK, hi);
+        const size_t need = (k + 1 == nchunks) ? L : std::min(L, b + PIPE_HALO);          // samples this chunk's windows reach
+        if (need > uploaded) {
+            if (!sg::hip_ok(hipMemcpyAsync(d_in + uploaded, input + uploaded, (need - uploaded) * sizeof(float), hipMemcpyHostToDevice, ps->up), "H2D copy")) { rc = -1; break; }
+            uploaded = need;
+        }
+        // the sub-row [a - 32, b + 32): its stored range [32, 32 + b - a) never sees what lies beyond it
+        if (sg1d_launch_refpk_f32(d_in + (a - PIPE_HALO), d_out + (a - PIPE_HALO) - shift, (long long)ld, (long long)ld,
+                                  (long long)((b - a) + 2 * PIPE_HALO), n, f->center_weights, dt_inv, (int)SAVGOL_BOUNDARY_CONSTANT,
+                                  PIPE_HALO, PIPE_HALO + (int)(b - a), 0, 1, ctx->cu_count, ps->up) != 0) { sg_set_error("%s: kernel launch failed", who); rc = -1; break; }
+        if (!sg::hip_ok(hipEventRecord(done[k], ps->up), "hipEventRecord")) { rc = -1; break; }
+        posted.store(k + 1, std::memory_order_release);
+    }
+    if (rc != 0) abort_flag = true;
+    // the 32 outputs at either end: boundary handling of every mode, reversed leading edge, VALID's narrower range
+    if (rc == 0) {
+        const int negate = (mode == SAVGOL_BOUNDARY_POLYNOMIAL && g_correct_leading_edge.load() && (f->config.derivative & 1)) ? 1 : 0;
+        const int e_lo0 = (variant == VALID) ? n : 0, e_hi1 = (variant == VALID) ? (int)L - n : (int)L;
+        if (sg1d_launch_reference_order_f32(d_in, d_out, (long long)ld, (long long)ld, (long long)L, n, d_table, dt_inv, mode, e_lo0, (int)lo, shift,
+                                            negate, 1, ps->up) != 0 ||
+            sg1d_launch_reference_order_f32(d_in, d_out, (long long)ld, (long long)ld, (long long)L, n, d_table, dt_inv, mode, (int)hi, e_hi1, shift, 0,
+                                            1, ps->up) != 0) { sg_set_error("%s: edge kernel launch failed", who); rc = -1; }
+        if (rc == 0 && !sg::hip_ok(hipStreamSynchronize(ps->up), who)) rc = -1;
+        if (rc == 0) {
+            const size_t lead = lo - (size_t)e_lo0, trail = (size_t)e_hi1 - hi;
+            if (!sg::hip_ok(hipMemcpy(output + (e_lo0 - shift), d_out + (e_lo0 - shift), lead * sizeof(float), hipMemcpyDeviceToHost), "D2H copy") ||
+                !sg::hip_ok(hipMemcpy(output + (hi - shift), d_out + (hi - shift), trail * sizeof(float), hipMemcpyDeviceToHost), "D2H copy")) rc = -1;
+        }
+    }
+    helper.join();
+    for (auto &e : done) (void)hipEventDestroy(e);
+    if (down_rc.load() != 0) { sg_set_error("%s: D2H copy failed", who); rc = -1; }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -347,6 +460,11 @@ int savgol_apply(const SavgolFilter *filter, const float *input, float *output, 
     DeviceCtx *ctx = sg::ctx_get();
     if (!ctx) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (length >= PIPE_MIN_LENGTH && length <= ((size_t)1 << 30)) {
+        if (host_apply_pipelined("savgol_apply", ctx, filter, input, output, length, FULL) == 0) return 0;
+        fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error());
+        return -1;
+    }
     const size_t ld = (length + 3) & ~(size_t)3;
     float *d_in = static_cast<float *>(sg::ctx_arena(ctx, 2 * ld * sizeof(float)));
     if (!d_in) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
@@ -366,6 +484,11 @@ size_t savgol_apply_valid(const SavgolFilter *filter, const float *input, size_t
     if (!ctx) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     const size_t out_len = input_length - 2 * (size_t)filter->config.half_window;
+    if (input_length >= PIPE_MIN_LENGTH && input_length <= ((size_t)1 << 30)) {
+        if (host_apply_pipelined("savgol_apply_valid", ctx, filter, input, output, input_length, VALID) == 0) return out_len;
+        fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error());
+        return 0;
+    }
     const size_t ld = (input_length + 3) & ~(size_t)3;
     float *d_in = static_cast<float *>(sg::ctx_arena(ctx, 2 * ld * sizeof(float)));
     if (!d_in) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }

@@ -505,3 +505,22 @@ def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu):
     finally:
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 0)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n,m,d,mode", [(32, 4, 0, 0), (5, 3, 1, 0), (16, 2, 0, 1), (7, 3, 2, 2), (32, 4, 0, 3)])
+def test_long_host_signals_are_pipelined_and_still_bit_identical(sg, sgo, torch_gpu, n, m, d, mode):
+    """Host-pointer calls on >= 2^23 samples upload / filter / download in chunks on two copy streams (sg_api_1d.cpp,
+    host_apply_pipelined).  The result must still be the reference's, bit for bit -- checked against the CPU oracle (pinned
+    bitwise to the compiled reference) on the whole signal, including chunk seams, both ends, VALID and in place."""
+    L = (1 << 23) + 12345
+    x = sgo.synth_f32(7, 1, L)[0]
+    f = sg.Filter(n, m, d, 0.5 if d else 1.0, mode)
+    o = sgo.Filter(n, m, d, 0.5 if d else 1.0, mode)
+    want = o.apply(x)
+    got = f.apply(x)
+    assert same_bits(got, want), int(np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))[0])
+    v = f.apply_valid(x)
+    assert same_bits(v, o.apply_valid(x))
+    buf = x.copy()
+    f.apply(buf, out=buf)                                # in place: the out-of-place answer (documented divergence)
+    assert same_bits(buf, want)
