@@ -219,8 +219,26 @@ def bench_config1(sg, no_cpu):
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE config 3: 65 536 streams, n=16, m=2, d=1, dt=1e-3
 # ---------------------------------------------------------------------------------------------------------------
+def pin_to_gpu_numa_node():
+    """Latency legs only: run on the CPUs of the socket the GPU hangs off (sysfs local_cpulist); a doorbell or a launch that
+    crosses the socket interconnect first costs microseconds.  Returns the number of CPUs in the mask (0 = left alone)."""
+    try:
+        p = torch.cuda.get_device_properties(torch.cuda.current_device())
+        bus = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        cpus = set()
+        for part in open(f"/sys/bus/pci/devices/{bus}/local_cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return len(cpus)
+    except Exception:
+        return 0
+
+
 def bench_stream(sg, a):
     S, T, n = a.streams, a.ticks, 16
+    pinned = pin_to_gpu_numa_node()
     x = torch.empty((T, S), dtype=torch.float32, device="cuda")
     sg.synth(x)
     out = torch.empty((T, S), dtype=torch.float32, device="cuda")
@@ -257,6 +275,27 @@ def bench_stream(sg, a):
                        "Msamples_per_s": round(samples / ms / 1e3, 1),
                        "roofline": roofline(8.0 * samples, ms, kernel="sg_bank_roll_kernel<16>", algorithmic_bytes_per_sample=8)},
     }
+    # (e) the resident tick service: a doorbell + a completion array per tick instead of a launch + synchronise
+    torch.cuda.synchronize()
+    try:
+        bank3 = sg.StreamBank(S, n, 2, 1, 1e-3)
+        bank3.service_start(2000)
+        for t in range(100):
+            bank3.service_tick(x[t % T], o1)
+        lat2 = []
+        for t in range(100, 100 + 4000):
+            t0 = time.perf_counter()
+            rc = bank3.service_tick(x[t % T], o1)
+            lat2.append((time.perf_counter() - t0) * 1e6)
+            assert rc == 1, sg.last_error()
+        bank3.service_stop()
+        lat2 = np.sort(np.array(lat2))
+        res["resident_service"] = {"wall_latency_us_p50": round(float(lat2[len(lat2) // 2]), 2), "wall_latency_us_p99": round(float(lat2[int(len(lat2) * 0.99)]), 2),
+                                   "note": "savgol_streambank_service_tick through the Python binding (ctypes adds ~2 us per call; examples/c_api_demo.c measures it "
+                                           "from C); outputs bit-identical to the per-tick kernel (tests/test_gpu_stream.py)"}
+    except Exception as e:
+        res["resident_service"] = {"error": f"{type(e).__name__}: {e}"}
+    res["cpus_pinned_to_gpu_numa_node"] = pinned
     # (d) the single-stream drop-in call: one sample per savgol_stream_push (launch + sync per sample)
     s1 = sg.Stream(n, 2, 1, 1e-3)
     xs = x[:, 0].cpu().numpy()

@@ -139,6 +139,19 @@ size_t savgol_streambank_latency(const SavgolStreamBank *bank);
 size_t savgol_streambank_streams(const SavgolStreamBank *bank);
 size_t savgol_streambank_samples_received(const SavgolStreamBank *bank);   /* per stream */
 size_t savgol_streambank_samples_output(const SavgolStreamBank *bank);     /* per stream */
+/* Resident tick service: ONE kernel stays on the device (one wave per 256 streams, accumulators in registers) and every tick
+ * is a doorbell write + a spin on a completion array instead of a launch + a synchronise (csrc/sg_stream_service.hip).
+ * service_tick is SYNCHRONOUS: it returns 1 when d_out[0..streams) holds this tick's centre outputs (complete in device
+ * memory), 0 while the windows are still filling (d_out untouched), -1 on error; results are bit-identical to
+ * savgol_streambank_push / the reference's savgol_stream_push.  Needs streams % 4 == 0, streams <= 262144, 16-byte aligned
+ * d_samples / d_out.  While the service runs, the other savgol_streambank_* calls on this bank return -1 (stop first; the
+ * ring, write position and counters carry over in both directions).  The kernel leaves by itself after idle_ms (0 = 1000)
+ * without a tick and is restarted by the next one; until then a DEVICE-wide synchronise waits for it -- synchronise
+ * streams, or stop the service.                                                                                     */
+int    savgol_streambank_service_start(SavgolStreamBank *bank, unsigned idle_ms);
+int    savgol_streambank_service_tick(SavgolStreamBank *bank, const float *d_samples, float *d_out);
+int    savgol_streambank_service_stop(SavgolStreamBank *bank);
+int    savgol_streambank_service_running(const SavgolStreamBank *bank);
 /* checkpoint / resume: the whole state as one blob (synchronous) */
 size_t savgol_streambank_state_bytes(const SavgolStreamBank *bank);
 int    savgol_streambank_save(const SavgolStreamBank *bank, void *host_blob, void *stream);

@@ -120,6 +120,10 @@ SIGNATURES = {
     "savgol_streambank_streams": (_sz, [_vp]),
     "savgol_streambank_samples_received": (_sz, [_vp]),
     "savgol_streambank_samples_output": (_sz, [_vp]),
+    "savgol_streambank_service_start": (C.c_int, [_vp, C.c_uint]),
+    "savgol_streambank_service_tick": (C.c_int, [_vp, _vp, _vp]),
+    "savgol_streambank_service_stop": (C.c_int, [_vp]),
+    "savgol_streambank_service_running": (C.c_int, [_vp]),
     "savgol_streambank_state_bytes": (_sz, [_vp]),
     "savgol_streambank_save": (C.c_int, [_vp, _vp, _vp]),
     "savgol_streambank_load": (C.c_int, [_vp, _vp, _vp]),
@@ -357,6 +361,17 @@ class StreamBank:
 
     def push_block(self, samples, ticks, out, stream=None):
         return lib().savgol_streambank_push_block(self.ptr, _addr(samples), ticks, _addr(out), _stream(stream))
+
+    def service_start(self, idle_ms=0):
+        if lib().savgol_streambank_service_start(self.ptr, idle_ms) != 0:
+            raise RuntimeError(last_error())
+
+    def service_tick(self, samples, out):
+        return lib().savgol_streambank_service_tick(self.ptr, _addr(samples), _addr(out))
+
+    def service_stop(self):
+        if lib().savgol_streambank_service_stop(self.ptr) != 0:
+            raise RuntimeError(last_error())
 
     def flush(self, out, max_rows, stream=None):
         return lib().savgol_streambank_flush(self.ptr, _addr(out), max_rows, _stream(stream))

@@ -473,23 +473,16 @@ size_t savgol_stream_samples_output(const SavgolStream *stream) { return stream 
 // =================================================================================================
 // stream bank (savgol_hip.h)
 // =================================================================================================
-struct SavgolStreamBank {
-    SavgolFilter *filter;
-    size_t        streams;
-    int           device;
-    float        *d_ring;            // [ws][streams]
-    const float  *d_table;           // [n+1][ws]
-    int           wp;
-    unsigned long long received, emitted;
-    float         dt_inv;
-};
-
 namespace sg {
 static unsigned bank_blocks(const SavgolStreamBank *b) { return (unsigned)((b->streams + 255) / 256); }
 // A bank's ring and tables live on the device it was created on; launching from a thread whose current device is another
 // one would hand foreign pointers to that GPU.  Every entry point that touches the device checks.
 static bool bank_on_current_device(const SavgolStreamBank *b, const char *who)
 {
+    if (b->service) {                                      // the resident kernel owns the accumulators; the ring it keeps current
+        sg_set_error("%s: the tick service is running on this bank -- savgol_streambank_service_stop() first", who);      // is only visible to other kernels after it has left
+        return false;
+    }
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != b->device) {
         sg_set_error("%s: the bank lives on device %d but this thread's current device is %d (call savgol_hip_set_device(%d) first)", who,
@@ -530,6 +523,7 @@ SavgolStreamBank *savgol_streambank_create(const SavgolConfig *config, size_t st
 void savgol_streambank_destroy(SavgolStreamBank *bank)
 {
     if (!bank) return;
+    if (bank->service) (void)savgol_streambank_service_stop(bank);
     if (bank->d_ring) (void)hipFree(bank->d_ring);
     savgol_destroy(bank->filter);
     free(bank);

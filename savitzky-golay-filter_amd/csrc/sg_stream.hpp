@@ -5,6 +5,22 @@
 
 #include <cstddef>
 
+#include "sg_internal.h"
+
+// the bank behind the opaque SavgolStreamBank of savgol_hip.h (sg_stream.hip owns it; sg_stream_service.hip adds the resident
+// tick service)
+struct SavgolStreamBank {
+    SavgolFilter *filter;
+    size_t        streams;
+    int           device;
+    float        *d_ring;            // [ws][streams]
+    const float  *d_table;           // [n+1][ws]
+    int           wp;
+    unsigned long long received, emitted;
+    float         dt_inv;
+    void         *service;           // sg::BankService while savgol_streambank_service_* is active, else NULL
+};
+
 namespace sg {
 
 constexpr int STREAM_ROLL_MAX_N = 32;   // the rolling block-push kernel covers every half window ...

@@ -305,3 +305,66 @@ def test_corrupt_checkpoint_and_foreign_device_are_refused(sg, torch_gpu):
         assert load(h) == -1, (idx, bad)
     assert "blob" in sg.last_error()
     assert load(hdr) == 0                                              # still usable afterwards
+
+
+@pytest.mark.parametrize("n,m,d,streams", [(16, 2, 1, 65536), (5, 3, 0, 1000), (32, 4, 2, 4096), (1, 0, 0, 260)])
+def test_resident_tick_service_is_bit_identical_and_hands_state_over(sg, torch_gpu, n, m, d, streams):
+    """savgol_streambank_service_*: a resident kernel answers doorbells instead of one launch + synchronise per tick
+    (csrc/sg_stream_service.hip).  Every tick's output must equal the per-tick kernel's (itself pinned bit for bit to the
+    reference's savgol_stream_push) for every stream, through the filling phase, across a stop -> stream-ordered calls -> start
+    hand-over, and across the kernel's own idle time-out."""
+    import time
+    torch = torch_gpu
+    ws = 2 * n + 1
+    T = ws + 40
+    x = torch.randn((T, streams), device="cuda")
+    ref_bank = sg.StreamBank(streams, n, m, d, 1e-3 if d else 1.0)
+    bank = sg.StreamBank(streams, n, m, d, 1e-3 if d else 1.0)
+    want = torch.full((T, streams), -7.0, device="cuda")
+    rcs = [ref_bank.push(x[t], want[t]) for t in range(T)]
+    torch.cuda.synchronize()
+    got = torch.full((T, streams), -7.0, device="cuda")
+    torch.cuda.synchronize()
+    bank.service_start(idle_ms=150)
+    L = sg.lib()
+    try:
+        cut1, cut2 = ws // 2, ws + 10
+        for t in range(cut1):                                  # still filling: no output, d_out untouched
+            assert bank.service_tick(x[t], got[t]) == rcs[t] == 0
+        assert bank.push(x[cut1], got[cut1]) == -1 and "service" in sg.last_error()      # other calls are refused meanwhile
+        bank.service_stop()
+        for t in range(cut1, cut1 + 3):                        # stream-ordered calls continue from the service's state ...
+            assert bank.push(x[t], got[t]) == rcs[t]
+        torch.cuda.synchronize()
+        bank.service_start(idle_ms=150)                        # ... and the service continues from theirs
+        for t in range(cut1 + 3, cut2):
+            assert bank.service_tick(x[t], got[t]) == rcs[t]
+        time.sleep(0.4)                                        # longer than idle_ms: the kernel has left by itself
+        for t in range(cut2, T):                               # the next tick restarts it transparently
+            assert bank.service_tick(x[t], got[t]) == rcs[t]
+    finally:
+        bank.service_stop()
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    assert bank.counters == ref_bank.counters
+    # and the trailing edge rows come out of the ring the service kept current
+    f1, f2 = torch.zeros((n, streams), device="cuda"), torch.zeros((n, streams), device="cuda")
+    assert bank.flush(f1, n) == ref_bank.flush(f2, n) == n
+    torch.cuda.synchronize()
+    assert torch.equal(f1.view(torch.int32), f2.view(torch.int32))
+
+
+def test_tick_service_argument_checks(sg, torch_gpu):
+    torch = torch_gpu
+    bank = sg.StreamBank(1002, 4, 2)                           # not a multiple of 4 streams
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        bank.service_start()
+    bank = sg.StreamBank(1000, 4, 2)
+    x = torch.zeros(1004, device="cuda")
+    assert bank.service_tick(x, x) == -1 and "service_start" in sg.last_error()
+    bank.service_start(idle_ms=100)
+    try:
+        assert bank.service_tick(x[1:], x) == -1 and "aligned" in sg.last_error()
+    finally:
+        bank.service_stop()
+    bank.service_stop()                                        # idempotent
