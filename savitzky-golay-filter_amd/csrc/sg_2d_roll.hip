@@ -1,4 +1,4 @@
-// sg_2d_roll.hip -- the 2-D fast path for half windows <= 8: rolling column windows in registers.
+// sg_2d_roll.hip -- the 2-D fast path for half windows <= 12: rolling column windows in registers.
 //
 // Same exact low-rank factorisation as sg_2d_sep.hip,  W(x,y) = sum_t G_t(y) Q_t(x)  (reference kernel:
 // src/savgol2d.c:188-265), applied vertical pass first:
@@ -230,8 +230,14 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     wave_lds_sync();                                         // the next item's first write must stay behind these reads
 }
 
+// terms per output the rolling kernel is built for: the taps live in SGPRs (2 * NT * NOUT * (N/2 + 1) pairs), which caps the
+// wide windows at 3 terms (1 when two outputs share the walk); everything else runs the tile kernel of sg_2d_sep.hip
+constexpr int roll_max_terms(int n, int nout) { return nout == 1 ? (n <= 8 ? SEP_MAX_TERMS : 3) : (n <= 8 ? 3 : 1); }
+// waves per SIMD the register allocation must allow: the row ring alone is (2N+2) x 4 VGPRs
+constexpr int roll_min_waves(int n, int nt) { return n >= 9 ? 2 : ((nt >= 3 && n >= 6) || (n == 7 && nt == 2) ? 3 : 4); }
+
 template <int N, int NT, int NOUT>
-__global__ __launch_bounds__(256, (NT >= 3 && N >= 6) ? 3 : 4) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1,
+__global__ __launch_bounds__(256, roll_min_waves(N, NT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
     typedef Roll<N> R;
@@ -354,13 +360,12 @@ static int dispatch_roll(int n, int terms, const Job2D &job, const float *factor
         const float s1[1] = {scale};
         return launch_roll<N, NT, 1>(job, f1, s1, nullptr, images, cu_count, st);
     }
-    if constexpr (NT < SEP_MAX_TERMS) return dispatch_roll<N, NT + 1>(n, terms, job, factors, scale, images, cu_count, st);
+    if constexpr (NT < roll_max_terms(N, 1)) return dispatch_roll<N, NT + 1>(n, terms, job, factors, scale, images, cu_count, st);
     else if constexpr (N < SEP_ROLL_MAX_N) return dispatch_roll<N + 1, 1>(n, terms, job, factors, scale, images, cu_count, st);
     else return 1;
 }
 
-// two output frames from one walk over the input, the same number of terms (<= 3) for both: the gradient
-constexpr int ROLL2_MAX_TERMS = 3;
+// two output frames from one walk over the input, the same number of terms for both: the gradient
 template <int N, int NT>
 static int dispatch_roll2(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1, unsigned images,
                           int cu_count, hipStream_t st)
@@ -370,7 +375,7 @@ static int dispatch_roll2(int n, int terms, const Job2D &job, const float *f0, f
         const float ss[2] = {s0, s1};
         return launch_roll<N, NT, 2>(job, ff, ss, out1, images, cu_count, st);
     }
-    if constexpr (NT < ROLL2_MAX_TERMS) return dispatch_roll2<N, NT + 1>(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
+    if constexpr (NT < roll_max_terms(N, 2)) return dispatch_roll2<N, NT + 1>(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
     else if constexpr (N < SEP_ROLL_MAX_N) return dispatch_roll2<N + 1, 1>(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
     else return 1;
 }
@@ -379,7 +384,7 @@ static int dispatch_roll2(int n, int terms, const Job2D &job, const float *f0, f
 // definite parity).  Built once per half-window group (Makefile), each under its own name SEP_ROLL_FN.
 int SEP_ROLL_FN(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
 {
-    if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > SEP_MAX_TERMS) return 1;
+    if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > roll_max_terms(n, 1)) return 1;
     return dispatch_roll<SEP_ROLL_MIN_N, 1>(n, terms, job, factors, scale, images, cu_count, st);
 }
 
@@ -387,7 +392,7 @@ int SEP_ROLL_FN(int n, int terms, const Job2D &job, const float *factors, float 
 int SEP_ROLL_FN2(int n, int terms, const Job2D &job, const float *factors0, float scale0, const float *factors1, float scale1, float *out1,
                  unsigned images, int cu_count, hipStream_t st)
 {
-    if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > ROLL2_MAX_TERMS) return 1;
+    if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > roll_max_terms(n, 2)) return 1;
     return dispatch_roll2<SEP_ROLL_MIN_N, 1>(n, terms, job, factors0, scale0, factors1, scale1, out1, images, cu_count, st);
 }
 
