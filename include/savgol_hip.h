@@ -51,7 +51,8 @@ const char *savgol_hip_version(void);
  * mathematically correct sign.  (The reference applies the trailing-edge rows to reversed data, which negates odd
  * derivatives on the leading edge -- src/savgolFilter.c:773-777)  Affects the 1-D batch / apply
  * entry points only; the streaming path keeps the reference behaviour.                                           */
-enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1, SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2, SAVGOL_HIP_OPT_PLAIN_SUMMATION = 3 };
+enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1, SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2, SAVGOL_HIP_OPT_PLAIN_SUMMATION = 3,
+       SAVGOL_HIP_OPT_BOUNDARY_AWARE = 4 };
 /* SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 1: the fp32 1-D batch / valid / strided DEVICE entry points sum each output in
  * the reference's own order (convolve_ilp, src/savgolFilter.c:547-580: four chains, separate multiply and add) and are
  * then bit-identical to the reference's savgol_apply; 1.5x (n=5) to 2.1x (n=32) slower than the default FMA kernel, which
@@ -60,7 +61,15 @@ enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1, SAVGOL_HIP_OPT_REFERENCE_SUMMATI
  * replaces the 32 taps that fall on a lane's own 32-sample block by block moments (the taps are a polynomial of degree
  * <= poly_order in the tap index; csrc/sg_k1d_moment.hpp): 43 instead of 65 multiply-adds per output at poly_order 4, the same
  * 1e-6 agreement with the fp64 oracle, different last bits.  Filters whose table is not such a polynomial (hand-edited
- * center_weights), poly_order > 6 and every other half window always use the plain sum.                                       */
+ * center_weights), poly_order > 6 and every other half window always use the plain sum.
+ * SAVGOL_HIP_OPT_BOUNDARY_AWARE = 1: the paths that IGNORE config.boundary in the reference honour it:
+ *   - savgol_apply_strided / savgol_apply_strided_batch_f32 (reference src/savgolFilter.c:877-934 always uses the polynomial
+ *     edge rows) apply the configured mode, like savgol_apply;
+ *   - savgol_stream_* and savgol_streambank_* (reference src/savgol_stream.c:43-74 likewise) emit REFLECT / CONSTANT edges in
+ *     push_full / flush / flush_leading: the first and last n outputs are the centre taps on the index-remapped window
+ *     (get_padded_sample, :442-482), so push_full... + flush equals savgol_apply in that mode.  PERIODIC needs samples from the
+ *     other end of the signal and keeps the polynomial rows.  Read when a stream or bank is created / a stream call is made;
+ *     set it before.  Default 0: the reference's behaviour.                                                                  */
 int         savgol_hip_set_option(int option, int value);
 /* Diagnostic (host only, no device needed): the constant table the half_window = 32 fp32 kernel reads -- SAVGOL_HIP_MOMENT_TABLE_FLOATS
  * floats: centre taps [0,66), block basis phi[s-1][t] at [80,176), own-block coefficients c[s][J][2] at [176,400); layout in

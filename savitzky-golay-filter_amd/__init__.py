@@ -26,6 +26,7 @@ SAVGOL2D_BOUNDARY_VALID, SAVGOL2D_BOUNDARY_CONSTANT, SAVGOL2D_BOUNDARY_REFLECT =
 SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1
 SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2
 SAVGOL_HIP_OPT_PLAIN_SUMMATION = 3
+SAVGOL_HIP_OPT_BOUNDARY_AWARE = 4
 
 
 class SavgolConfig(C.Structure):

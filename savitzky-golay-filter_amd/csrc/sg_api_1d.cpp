@@ -70,6 +70,7 @@ namespace {
 std::atomic<int> g_correct_leading_edge{0};
 std::atomic<int> g_reference_summation{0};      // SAVGOL_HIP_OPT_REFERENCE_SUMMATION: batch f32 calls in the reference's order
 std::atomic<int> g_plain_summation{0};          // SAVGOL_HIP_OPT_PLAIN_SUMMATION: no block moments at half_window 32
+std::atomic<int> g_boundary_aware{0};           // SAVGOL_HIP_OPT_BOUNDARY_AWARE: strided calls and streams honour config.boundary
 
 // half_window = 32 fast path: the polynomial fit of a filter's centre taps (sg_k1d_moment_fit.cpp), cached per table content
 struct MomentFit { float w[SAVGOL_MAX_WINDOW]; int terms; float table[sg::MOMENT_TABLE_FLOATS]; };
@@ -366,11 +367,14 @@ int host_apply_pipelined(const char *who, DeviceCtx *ctx, const SavgolFilter *f,
 
 extern "C" {
 
+int sg_option_boundary_aware(void) { return g_boundary_aware.load(); }
+
 int savgol_hip_set_option(int option, int value)
 {
     if (option == SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE) { g_correct_leading_edge.store(value != 0); return 0; }
     if (option == SAVGOL_HIP_OPT_REFERENCE_SUMMATION) { g_reference_summation.store(value != 0); return 0; }
     if (option == SAVGOL_HIP_OPT_PLAIN_SUMMATION) { g_plain_summation.store(value != 0); return 0; }
+    if (option == SAVGOL_HIP_OPT_BOUNDARY_AWARE) { g_boundary_aware.store(value != 0); return 0; }
     sg_set_error("savgol_hip_set_option: unknown option %d", option);
     return -1;
 }
@@ -433,7 +437,7 @@ int savgol_apply_strided_batch_f32(const SavgolFilter *filter, const void *d_in,
         sg_set_error("%s: gather launch failed", who);
         rc = -1;
     }
-    if (rc == 0 && enqueue_batch<float>(who, filter, dense, result, channels, count, ld, ld, FULL_POLY_EDGES, st, g_reference_summation.load() != 0) != 0) rc = -1;
+    if (rc == 0 && enqueue_batch<float>(who, filter, dense, result, channels, count, ld, ld, g_boundary_aware.load() ? FULL : FULL_POLY_EDGES, st, g_reference_summation.load() != 0) != 0) rc = -1;
     if (rc == 0 && sg_launch_scatter_f32(result, ld, d_out, out_stride, out_offset, out_channel_pitch, channels, count, st) != 0) {
         sg_set_error("%s: scatter launch failed", who);
         rc = -1;
@@ -517,7 +521,7 @@ int savgol_apply_strided(const SavgolFilter *filter, const void *input, size_t i
     const char *ib = static_cast<const char *>(input) + in_offset;
     for (size_t i = 0; i < count; ++i) memcpy(&stage[i], ib + i * in_stride, sizeof(float));
     bool ok = sg::hip_ok(hipMemcpy(d_in, stage, count * sizeof(float), hipMemcpyHostToDevice), "H2D copy");
-    ok = ok && enqueue_batch<float>("savgol_apply_strided", filter, d_in, d_out, 1, count, ld, ld, FULL_POLY_EDGES, nullptr, /*reference order*/ true) == 0;
+    ok = ok && enqueue_batch<float>("savgol_apply_strided", filter, d_in, d_out, 1, count, ld, ld, g_boundary_aware.load() ? FULL : FULL_POLY_EDGES, nullptr, /*reference order*/ true) == 0;
     ok = ok && sg::hip_ok(hipMemcpy(stage, d_out, count * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");
     if (!ok) { fprintf(stderr, "savgol_apply_strided: %s\n", savgol_hip_last_error()); return -1; }
     char *ob = static_cast<char *>(output) + out_offset;

@@ -22,6 +22,9 @@ int   sg2d_config_ok(const Savgol2DConfig *c);
 int   sg2d_weights_fill(const Savgol2DConfig *c, float *W, double *coef);
 float sg2d_scale(const Savgol2DConfig *c);
 
+/* ---- process-wide switches (sg_api_1d.cpp, savgol_hip_set_option) ---- */
+int   sg_option_boundary_aware(void);                    /* SAVGOL_HIP_OPT_BOUNDARY_AWARE */
+
 /* ---- error reporting (sg_runtime.cpp) ---- */
 void  sg_set_error(const char *fmt, ...);
 

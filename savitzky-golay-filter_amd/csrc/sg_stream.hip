@@ -271,14 +271,46 @@ __global__ __launch_bounds__(64) void sg_stream_rows_kernel(const float *__restr
     out[r] = __fmul_rn(acc, dt_inv);
 }
 
-// device table for a filter: row 0 = centre taps, row 1+e = edge row e, each ws floats
+// Device table for a filter, ws floats per row.  Reference behaviour (and PERIODIC always): row 0 = centre taps, row 1+e =
+// polynomial edge row e, used backwards on the first window and forwards on the last (src/savgol_stream.c:43-74).
+// With SAVGOL_HIP_OPT_BOUNDARY_AWARE and a REFLECT / CONSTANT filter the edge outputs are the centre taps on the index-remapped
+// window instead (get_padded_sample, src/savgolFilter.c:442-482); a remapped window is still a dot product with the 2n+1
+// samples in the ring, so the same kernels serve it from "effective" rows:
+//     leading  output i      : w'_i[j]  = sum of cw[k] over the taps k whose remapped index lands on sample j of the first window
+//     trailing output L-1-e  : w''_e[j] = the same on the last window
+// rows 1..n hold w'_i REVERSED (the kernels read leading rows backwards), rows n+1..2n hold w''_e.
+static bool boundary_aware_edges(const SavgolFilter *f)
+{
+    return sg_option_boundary_aware() && (f->config.boundary == SAVGOL_BOUNDARY_REFLECT || f->config.boundary == SAVGOL_BOUNDARY_CONSTANT);
+}
+static int trailing_row_base(const SavgolFilter *f) { return boundary_aware_edges(f) ? 1 + f->config.half_window : 1; }
+
 static const float *filter_table(DeviceCtx *ctx, const SavgolFilter *f)
 {
     const int n = f->config.half_window, ws = f->window_size;
-    float packed[(SAVGOL_MAX_HALF_WINDOW + 1) * SAVGOL_MAX_WINDOW];
+    float packed[(2 * SAVGOL_MAX_HALF_WINDOW + 1) * SAVGOL_MAX_WINDOW];
     memcpy(packed, f->center_weights, sizeof(float) * ws);
-    for (int e = 0; e < n; ++e) memcpy(packed + (size_t)(1 + e) * ws, f->edge_weights[e], sizeof(float) * ws);
-    return ctx_table(ctx, packed, sizeof(float) * (size_t)(n + 1) * ws, 0x57000000u + (unsigned)n);
+    if (!boundary_aware_edges(f)) {
+        for (int e = 0; e < n; ++e) memcpy(packed + (size_t)(1 + e) * ws, f->edge_weights[e], sizeof(float) * ws);
+        return ctx_table(ctx, packed, sizeof(float) * (size_t)(n + 1) * ws, 0x57000000u + (unsigned)n);
+    }
+    const bool reflect = f->config.boundary == SAVGOL_BOUNDARY_REFLECT;
+    for (int e = 0; e < n; ++e) {
+        double lead[SAVGOL_MAX_WINDOW] = {}, trail[SAVGOL_MAX_WINDOW] = {};
+        for (int k = 0; k < ws; ++k) {
+            int j = e - n + k;                                   // leading output e reads first-window sample e - n + k
+            if (j < 0) j = reflect ? -j - 1 : 0;
+            lead[j] += (double)f->center_weights[k];
+            j = ws - 1 - e - n + k;                              // trailing output L-1-e reads last-window sample ws-1-e-n+k
+            if (j >= ws) j = reflect ? 2 * ws - j - 1 : ws - 1;
+            trail[j] += (double)f->center_weights[k];
+        }
+        for (int j = 0; j < ws; ++j) {
+            packed[(size_t)(1 + e) * ws + j] = (float)lead[ws - 1 - j];
+            packed[(size_t)(1 + n + e) * ws + j] = (float)trail[j];
+        }
+    }
+    return ctx_table(ctx, packed, sizeof(float) * (size_t)(2 * n + 1) * ws, 0x58000000u + (unsigned)n * 4u + (unsigned)f->config.boundary);
 }
 
 static bool filter_ok(const SavgolFilter *f)
@@ -418,7 +450,7 @@ int savgol_stream_flush(SavgolStream *stream, float *output, int max_count)
     if (stream->samples_received < (size_t)f->window_size) return 0;
     sg::RowList rows; memset(&rows, 0, sizeof(rows));
     rows.count = max_count < n ? max_count : n;
-    for (int i = 0; i < rows.count; ++i) { rows.row[i] = 1 + (n - 1 - i); rows.backward[i] = 0; }   // :245-249
+    for (int i = 0; i < rows.count; ++i) { rows.row[i] = sg::trailing_row_base(f) + (n - 1 - i); rows.backward[i] = 0; }   // :245-249
     float tmp[SAVGOL_MAX_HALF_WINDOW + 1];
     if (sg::single_stream_rows(stream, rows, tmp) != 0) {
         fprintf(stderr, "savgol_stream_flush: %s\n", savgol_hip_last_error());
@@ -509,6 +541,7 @@ SavgolStreamBank *savgol_streambank_create(const SavgolConfig *config, size_t st
     b->device = ctx->ordinal;
     b->dt_inv = sg::dt_inverse(f);
     b->d_table = sg::filter_table(ctx, f);
+    b->trail_base = sg::trailing_row_base(f);             // the option is read once, here
     const size_t bytes = sizeof(float) * (size_t)f->window_size * streams;
     if (!b->d_table || !sg::hip_ok(hipMalloc(reinterpret_cast<void **>(&b->d_ring), bytes), "hipMalloc(stream bank)") ||
         !sg::hip_ok(hipMemset(b->d_ring, 0, bytes), "hipMemset(stream bank)")) {
@@ -638,7 +671,7 @@ static int bank_edge_rows(SavgolStreamBank *bank, float *d_out, int max_rows, vo
     sg::RowList rows; memset(&rows, 0, sizeof(rows));
     rows.count = max_rows < n ? max_rows : n;
     for (int i = 0; i < rows.count; ++i) {
-        rows.row[i] = leading ? 1 + i : 1 + (n - 1 - i);
+        rows.row[i] = leading ? 1 + i : bank->trail_base + (n - 1 - i);
         rows.backward[i] = leading ? 1 : 0;
     }
     hipLaunchKernelGGL(sg::sg_bank_rows_kernel, dim3(sg::bank_blocks(bank), rows.count), dim3(256), 0,

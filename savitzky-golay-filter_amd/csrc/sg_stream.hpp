@@ -14,7 +14,8 @@ struct SavgolStreamBank {
     size_t        streams;
     int           device;
     float        *d_ring;            // [ws][streams]
-    const float  *d_table;           // [n+1][ws]
+    const float  *d_table;           // [n+1][ws], or [2n+1][ws] with boundary-aware edges (filter_table, sg_stream.hip)
+    int           trail_base;        // first trailing-edge row of d_table
     int           wp;
     unsigned long long received, emitted;
     float         dt_inv;

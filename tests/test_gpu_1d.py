@@ -524,3 +524,35 @@ def test_long_host_signals_are_pipelined_and_still_bit_identical(sg, sgo, torch_
     buf = x.copy()
     f.apply(buf, out=buf)                                # in place: the out-of-place answer (documented divergence)
     assert same_bits(buf, want)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_opt_in_boundary_aware_strided_call(sg, sgo, torch_gpu, mode):
+    """savgol_apply_strided hard-codes the polynomial edge rows whatever config.boundary says (reference
+    src/savgolFilter.c:877-934).  With SAVGOL_HIP_OPT_BOUNDARY_AWARE it applies the configured mode, host and device entry
+    points alike; without it the reference's behaviour stays (test_savgol_apply_strided_* above)."""
+    torch = torch_gpu
+    L = sg.lib()
+    count, n, m = 700, 6, 3
+    rng = np.random.default_rng(5)
+    aos = rng.normal(0, 1, (count, 3)).astype(np.float32)
+    f = sg.Filter(n, m, 0, 1.0, mode)
+    want = sgo.Filter(n, m, 0, 1.0, mode).apply(np.ascontiguousarray(aos[:, 1]))
+    poly = sgo.Filter(n, m, 0, 1.0, 0).apply(np.ascontiguousarray(aos[:, 1]))
+    assert not np.array_equal(want, poly)
+    dst = np.full_like(aos, -9.0)
+    assert f.apply_strided(aos, 12, 4, dst, 12, 4, count) == 0
+    assert same_bits(dst[:, 1], poly)                          # default: the reference's behaviour
+    assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_BOUNDARY_AWARE, 1) == 0
+    try:
+        dst = np.full_like(aos, -9.0)
+        assert f.apply_strided(aos, 12, 4, dst, 12, 4, count) == 0
+        assert same_bits(dst[:, 1], want) and np.all(dst[:, 0] == -9.0) and np.all(dst[:, 2] == -9.0)
+        d_in = torch.from_numpy(aos).cuda()
+        d_out = torch.full_like(d_in, -9.0)
+        assert L.savgol_apply_strided_batch_f32(f.ptr, d_in.data_ptr(), 12, 4, 0, d_out.data_ptr(), 12, 4, 0, 1, count, None) == 0, sg.last_error()
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        assert normwise(got[:, 1], want) < 2e-6 and np.all(got[:, 0] == -9.0)
+    finally:
+        L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_BOUNDARY_AWARE, 0)

@@ -3,10 +3,12 @@
 The streaming kernels keep the reference's summation order and rounding (single fp32 accumulator, taps in
 order, separate multiply and add), so the bar here is BIT-EXACT against the reference's golden sequences
 and against the oracle's restatement of src/savgol_stream.c."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
-from tests._util import bits
+from tests._util import bits, normwise
 from tests.golden.make_golden import STREAM_CASES
 
 pytestmark = pytest.mark.gpu
@@ -368,3 +370,64 @@ def test_tick_service_argument_checks(sg, torch_gpu):
     finally:
         bank.service_stop()
     bank.service_stop()                                        # idempotent
+
+
+@pytest.mark.parametrize("mode", [1, 3, 2])                    # REFLECT, CONSTANT, PERIODIC
+@pytest.mark.parametrize("n,m,d", [(5, 3, 0), (16, 2, 1), (32, 4, 2)])
+def test_opt_in_boundary_aware_streams_match_the_batch_filter(sg, sgo, torch_gpu, mode, n, m, d):
+    """the reference's streaming path ignores config.boundary (src/savgol_stream.c:43-74 always uses the
+    polynomial rows).  With SAVGOL_HIP_OPT_BOUNDARY_AWARE, push_full... + flush of a REFLECT / CONSTANT stream equals
+    savgol_apply in that mode (centre outputs bit for bit, edge outputs to rounding: they are the same taps summed in another
+    order); PERIODIC cannot be streamed and keeps the polynomial rows.  Single stream and bank."""
+    torch = torch_gpu
+    L = sg.lib()
+    T = 3 * (2 * n + 1)
+    dt = 0.5 if d else 1.0
+    x = sgo.synth_f32(11, 4, T)
+    assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_BOUNDARY_AWARE, 1) == 0
+    try:
+        want_mode = mode if mode != 2 else 0                   # PERIODIC -> polynomial edges
+        ref = np.stack([sgo.Filter(n, m, d, dt, want_mode).apply(x[c]) for c in range(4)])
+        ref64 = np.stack([sgo.Filter(n, m, d, dt, want_mode).apply_f64(x[c:c + 1].astype(np.float64))[0] for c in range(4)])
+        # single stream (host API); the stream's filter carries the mode
+        cfg = sg.SavgolConfig(n, m, d, dt, mode)
+        f = L.savgol_create(C.byref(cfg))
+        st = sg.SavgolStream()
+        assert L.savgol_stream_init(C.byref(st), f) == 0
+        outs = []
+        buf = (C.c_float * 40)()
+        for t in range(T):
+            c = L.savgol_stream_push_full(C.byref(st), float(x[0, t]), buf, 40)
+            outs += list(buf[:c])
+        c = L.savgol_stream_flush(C.byref(st), buf, 40)
+        outs += list(buf[:c])
+        got = np.asarray(outs, np.float32)
+        assert got.shape == (T,)
+        if want_mode == 0:
+            assert normwise(got, ref[0]) < 2e-6                # stream vs batch: different summation order (reference: 1e-5)
+        else:
+            assert normwise(got, ref64[0]) < (1e-6 if d == 0 else 4e-6), normwise(got, ref64[0])
+            assert normwise(got[n:-n], ref[0][n:-n]) < 2e-6
+        L.savgol_destroy(f)
+        # bank
+        bank = sg.StreamBank.__new__(sg.StreamBank)
+        bank.ptr = L.savgol_streambank_create(C.byref(cfg), 4)
+        assert bank.ptr
+        xs = torch.from_numpy(np.ascontiguousarray(x.T)).cuda()          # [T][4]
+        rows_out = []
+        tmp = torch.zeros((n + 1, 4), device="cuda")
+        for t in range(T):
+            c = L.savgol_streambank_push_full(bank.ptr, xs[t].data_ptr(), tmp.data_ptr(), n + 1, None)
+            torch.cuda.synchronize()
+            rows_out += [tmp[i].cpu().numpy().copy() for i in range(c)]
+        c = L.savgol_streambank_flush(bank.ptr, tmp.data_ptr(), n, None)
+        torch.cuda.synchronize()
+        rows_out += [tmp[i].cpu().numpy().copy() for i in range(c)]
+        gotb = np.stack(rows_out).T                                      # [4][T]
+        assert gotb.shape == (4, T)
+        assert np.array_equal(gotb[0].view(np.uint32), got.view(np.uint32))      # bank == single stream, bit for bit
+        for c_ in range(4):
+            assert normwise(gotb[c_], ref64[c_]) < (2e-6 if d == 0 or want_mode else 4e-6) * (2 if d else 1)
+        L.savgol_streambank_destroy(bank.ptr); bank.ptr = None
+    finally:
+        L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_BOUNDARY_AWARE, 0)
