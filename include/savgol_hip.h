@@ -44,6 +44,11 @@ int         savgol_hip_device_count(void);          /* usable HIP devices (0 = n
 int         savgol_hip_set_device(int ordinal);     /* device used by THIS thread's calls  */
 int         savgol_hip_get_device(void);
 int         savgol_hip_synchronize(void *stream);
+/* Multi-GPU: the path shards by independent units (channels, streams, images) with no data-path collective, so the whole
+ * "context" is: one process (or thread) per GPU calls savgol_hip_set_device(local_rank) and filters its own contiguous slice.
+ * This returns that slice [*lo, *hi) of `total` units for `rank` of `world_size` (the first total % world_size ranks take
+ * one unit more); -1 on bad arguments.  bench.py and the Python mirror use the same arithmetic.                        */
+int         savgol_hip_shard_range(size_t total, int world_size, int rank, size_t *lo, size_t *hi);
 const char *savgol_hip_last_error(void);            /* thread-local, never NULL            */
 const char *savgol_hip_version(void);
 /* Process-wide switches; defaults reproduce the reference bit for bit in behaviour, quirks included.

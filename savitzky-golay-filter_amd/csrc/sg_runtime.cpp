@@ -150,4 +150,13 @@ int savgol_hip_synchronize(void *stream)
     return sg::hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize") ? 0 : -1;
 }
 
+int savgol_hip_shard_range(size_t total, int world_size, int rank, size_t *lo, size_t *hi)
+{
+    if (world_size < 1 || rank < 0 || rank >= world_size || !lo || !hi) { sg_set_error("savgol_hip_shard_range: bad arguments"); return -1; }
+    const size_t q = total / (size_t)world_size, r = total % (size_t)world_size, k = (size_t)rank;
+    *lo = k * q + (k < r ? k : r);
+    *hi = *lo + q + (k < r ? 1 : 0);
+    return 0;
+}
+
 }  // extern "C"

@@ -55,9 +55,15 @@ def test_two_rank_channel_sharding_matches_single_process(tmp_path, sgo, channel
 
 
 def test_shard_range_partitions_exactly(sg):
+    import ctypes as C
+    L = sg.lib()
     for total in (0, 1, 7, 8, 4096, 32768):
         for world in (1, 2, 3, 8):
             spans = [sg.shard_range(total, world, r) for r in range(world)]
+            for r in range(world):                             # the C-ABI twin (savgol_hip_shard_range) agrees
+                lo, hi = C.c_size_t(), C.c_size_t()
+                assert L.savgol_hip_shard_range(total, world, r, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == spans[r]
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
