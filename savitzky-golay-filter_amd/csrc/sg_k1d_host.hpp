@@ -20,7 +20,10 @@ struct alignas(8) Taps { union { float w[SAVGOL_MAX_WINDOW + 1]; double wd[(SAVG
 #ifndef SG_VPL_F32_WIDE
 #define SG_VPL_F32_WIDE 8          /* fp32, half_window >= 24; A/B builds override this */
 #endif
-constexpr int vectors_per_lane(size_t elem_size, int half_window) { return (elem_size == 4 && half_window >= 24) ? SG_VPL_F32_WIDE : 8; }
+#ifndef SG_VPL_NARROW
+#define SG_VPL_NARROW 8            /* every other kernel; A/B builds override this */
+#endif
+constexpr int vectors_per_lane(size_t elem_size, int half_window) { return (elem_size == 4 && half_window >= 24) ? SG_VPL_F32_WIDE : SG_VPL_NARROW; }
 
 struct Job1D {
     const void *in;

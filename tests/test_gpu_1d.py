@@ -481,10 +481,11 @@ def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu):
     x = torch.empty((6, 70001), dtype=torch.float32, device="cuda")
     sg.synth(x)
     xh = x.cpu().numpy().astype(np.float64)
-    for (m, d, mode, tol) in [(4, 0, 0, 1e-6), (4, 0, 1, 1e-6), (4, 0, 2, 1e-6), (4, 0, 3, 1e-6), (2, 0, 1, 1e-6), (6, 0, 1, 1e-6),
-                              (4, 1, 3, 2e-6), (4, 2, 0, 2e-5), (3, 1, 2, 2e-6)]:
-        f = sg.Filter(32, m, d, 1.0, mode)
-        ref = sgo.Filter(32, m, d, 1.0, mode).apply_f64(xh)
+    for (m, d, mode, tol, dt) in [(4, 0, 0, 1e-6, 1.0), (4, 0, 1, 1e-6, 1.0), (4, 0, 2, 1e-6, 1.0), (4, 0, 3, 1e-6, 1.0), (2, 0, 1, 1e-6, 1.0),
+                                  (6, 0, 1, 1e-6, 1.0), (4, 1, 3, 2e-6, 1.0), (4, 2, 0, 2e-5, 1.0), (3, 1, 2, 2e-6, 1.0),
+                                  (4, 1, 0, 2e-6, 0.25), (4, 2, 1, 2e-5, 1e-3)]:          # time_step != 1: the dt_inv multiply after the sum
+        f = sg.Filter(32, m, d, dt, mode)
+        ref = sgo.Filter(32, m, d, dt, mode).apply_f64(xh)
         a = f.apply_tensor(x).cpu().numpy()
         assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 1) == 0
         try:
