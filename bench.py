@@ -296,6 +296,22 @@ def bench_stream(sg, a):
     except Exception as e:
         res["resident_service"] = {"error": f"{type(e).__name__}: {e}"}
     res["cpus_pinned_to_gpu_numa_node"] = pinned
+    # the same two per-tick paths timed from plain C (examples/c_api_demo.c, built by `make` next to the library): no
+    # interpreter between the doorbell and the completion array
+    demo = os.path.join(ROOT, "savitzky-golay-filter_amd", "lib", "c_api_demo")
+    if os.path.exists(demo):
+        try:
+            import re
+            txt = subprocess.run([demo], capture_output=True, text=True, timeout=120).stdout
+            m1 = re.search(r"p50 ([0-9.]+) us\s+p99 ([0-9.]+) us\s+\(launch \+ sync", txt)
+            m2 = re.search(r"p50 ([0-9.]+) us\s+p99 ([0-9.]+) us\s+\(resident service", txt)
+            if m1 and m2 and "c_api_demo: OK" in txt:
+                res["from_c"] = {"launch_plus_synchronise_us": {"p50": float(m1.group(1)), "p99": float(m1.group(2))},
+                                 "resident_service_us": {"p50": float(m2.group(1)), "p99": float(m2.group(2))},
+                                 "note": "examples/c_api_demo.c: 2000 ticks each, thread pinned to the GPU's NUMA node; the service's outputs are compared bit "
+                                         "for bit with the per-tick kernel on a twin bank inside the program"}
+        except Exception as e:
+            res["from_c"] = {"error": f"{type(e).__name__}: {e}"}
     # (d) the single-stream drop-in call: one sample per savgol_stream_push (launch + sync per sample)
     s1 = sg.Stream(n, 2, 1, 1e-3)
     xs = x[:, 0].cpu().numpy()

@@ -76,10 +76,10 @@ enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1, SAVGOL_HIP_OPT_REFERENCE_SUMMATI
  *     other end of the signal and keeps the polynomial rows.  Read when a stream or bank is created / a stream call is made;
  *     set it before.  Default 0: the reference's behaviour.                                                                  */
 int         savgol_hip_set_option(int option, int value);
-/* Diagnostic (host only, no device needed): the constant table the half_window = 32 fp32 kernel reads -- SAVGOL_HIP_MOMENT_TABLE_FLOATS
+/* Diagnostic (host only, no device needed): the constant table the wide-window (24..32) fp32 kernel reads -- SAVGOL_HIP_MOMENT_TABLE_FLOATS
  * floats: centre taps [0,66), block basis phi[s-1][t] at [80,176), own-block coefficients c[s][J][2] at [176,400); layout in
  * csrc/sg_k1d_host.hpp.  Returns the number of block moments the kernel will use (3, 5 or 7), 0 when the filter runs the
- * plain 65-tap sum (other half windows, poly_order > 6, tables that are not a polynomial), -1 on NULL.                        */
+ * plain 2n+1-tap sum (half windows below 24, poly_order > 6, tables that are not a polynomial), -1 on NULL.                   */
 #define SAVGOL_HIP_MOMENT_TABLE_FLOATS 400
 int         savgol_hip_moment_table(const SavgolFilter *filter, float *table);
 

@@ -72,19 +72,22 @@ std::atomic<int> g_reference_summation{0};      // SAVGOL_HIP_OPT_REFERENCE_SUMM
 std::atomic<int> g_plain_summation{0};          // SAVGOL_HIP_OPT_PLAIN_SUMMATION: no block moments at half_window 32
 std::atomic<int> g_boundary_aware{0};           // SAVGOL_HIP_OPT_BOUNDARY_AWARE: strided calls and streams honour config.boundary
 
-// half_window = 32 fast path: the polynomial fit of a filter's centre taps (sg_k1d_moment_fit.cpp), cached per table content
-struct MomentFit { float w[SAVGOL_MAX_WINDOW]; int terms; float table[sg::MOMENT_TABLE_FLOATS]; };
+// wide-window fast path (half windows 24..32): the polynomial fit of a filter's centre taps (sg_k1d_moment_fit.cpp), cached per table content
+struct MomentFit { int n; float w[SAVGOL_MAX_WINDOW]; int terms; float table[sg::MOMENT_TABLE_FLOATS]; };
 std::mutex g_moment_mu;
 std::vector<MomentFit *> g_moment_fits;         // never shrinks: one entry (1.9 KB) per distinct n = 32 filter of the process
 
 const MomentFit *moment_fit(const SavgolFilter *f)
 {
     std::lock_guard<std::mutex> lock(g_moment_mu);
+    const int n = f->config.half_window;
     for (const MomentFit *m : g_moment_fits)
-        if (memcmp(m->w, f->center_weights, sizeof(float) * SAVGOL_MAX_WINDOW) == 0) return m;
+        if (m->n == n && memcmp(m->w, f->center_weights, sizeof(float) * (size_t)(2 * n + 1)) == 0) return m;
     MomentFit *m = new MomentFit();
-    memcpy(m->w, f->center_weights, sizeof(float) * SAVGOL_MAX_WINDOW);
-    m->terms = sg1d_moment_prepare(f->center_weights, m->table);
+    m->n = n;
+    memset(m->w, 0, sizeof(m->w));
+    memcpy(m->w, f->center_weights, sizeof(float) * (size_t)(2 * n + 1));
+    m->terms = sg1d_moment_prepare(n, f->center_weights, m->table);
     g_moment_fits.push_back(m);
     return m;
 }
@@ -217,13 +220,13 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         if (!d_edges) return -1;
     }
 
-    // half_window 32, fp32: block moments replace the 32 taps on each lane's own block when the table is a polynomial
+    // half windows 24..32, fp32: block moments replace the taps on the lanes' common block when the table is a polynomial
     const float *d_moment = nullptr;
     int moment_terms = 0;
-    if (sizeof(T) == 4 && n == SAVGOL_MAX_HALF_WINDOW && !g_plain_summation.load()) {
+    if (sizeof(T) == 4 && n >= sg::MOMENT_MIN_N && n <= sg::MOMENT_MAX_N && !g_plain_summation.load()) {
         const MomentFit *mf = moment_fit(f);
         if (mf->terms) {
-            d_moment = sg::ctx_table(ctx, mf->table, sizeof(mf->table), 0x1f00u);
+            d_moment = sg::ctx_table(ctx, mf->table, sizeof(mf->table), 0x1f00u + (unsigned)n);
             if (!d_moment) return -1;
             moment_terms = mf->terms;
         }
@@ -240,7 +243,10 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         unsigned blocks = (job.total_tiles + 3u) / 4u;
         blocks = (blocks + 7u) & ~7u;                                    // the XCD remap wants a multiple of 8
         if (d_moment) {
-            if (sg1d_launch_f32_moment(moment_terms, &job, d_moment, blocks, st) != 0) return -1;
+            const int rc = moment_terms == 3 ? sg1d_launch_f32_moment_t3(n, &job, d_moment, blocks, st)
+                         : moment_terms == 5 ? sg1d_launch_f32_moment_t5(n, &job, d_moment, blocks, st)
+                                             : sg1d_launch_f32_moment_t7(n, &job, d_moment, blocks, st);
+            if (rc != 0) return -1;
         } else if (sg::launch_center<T>(n, job, taps, blocks, st) != 0) return -1;
     }
     if (d_edges) {
@@ -382,8 +388,7 @@ int savgol_hip_set_option(int option, int value)
 int savgol_hip_moment_table(const SavgolFilter *filter, float *table)
 {
     if (!filter || !table) { sg_set_error("savgol_hip_moment_table: NULL pointer"); return -1; }
-    if (filter->config.half_window != SAVGOL_MAX_HALF_WINDOW) return 0;
-    return sg1d_moment_prepare(filter->center_weights, table);
+    return sg1d_moment_prepare(filter->config.half_window, filter->center_weights, table);
 }
 
 int savgol_apply_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out, size_t channels, size_t length,

@@ -53,13 +53,19 @@ inline void set_tiles_per_channel(Job1D &job, unsigned d)
     job.tpc_shift = l - 1;
 }
 
-// The half_window = 32 fp32 fast path (sg_k1d_moment.hpp): one device table per filter content, read through scalar loads.
-//   floats [0, 66)    centre taps w[0..64], w[65] = 0
-//   floats [80, 176)  phi[s-1][t] = P_s((t - 15.5) / 16), s = 1..6, t = 0..15   (Legendre; P_s(31 - t) = (-1)^s P_s(t))
-//   floats [176, 400) c[s][J] = (c_s(2J), c_s(2J+1)), s = 0..6, J = 0..15: the own block's share of output r is sum_s c_s(r) mu_s
+// The wide-window fp32 fast path (sg_k1d_moment.hpp, half windows 24..32): one device table per filter content, read through
+// scalar loads.  Geometry (host and kernel must agree): a lane's window is X[0 .. 32 + 2n + OFF), output r reads X[r + OFF + k];
+// the block every output's window contains is X[LO .. HI), both even.
+//   floats [0, 66)    centre taps w[0..2n], zero padded
+//   floats [80, 176)  phi[s-1][t] = P_s((t - (BK-1)/2) / (BK/2)), s = 1..6, t = 0..BK/2-1   (Legendre; P_s(BK-1-t) = (-1)^s P_s(t))
+//   floats [176, 400) c[s][J] = (c_s(2J), c_s(2J+1)), s = 0..6, J = 0..15: the block's share of output r is sum_s c_s(r) mu_s
+constexpr int MOMENT_MIN_N = 24, MOMENT_MAX_N = 32;
 constexpr int MOMENT_MAX_TERMS = 7;
 constexpr int MOMENT_OFF_W = 0, MOMENT_OFF_PHI = 80, MOMENT_OFF_C = 176;
 constexpr int MOMENT_TABLE_FLOATS = MOMENT_OFF_C + MOMENT_MAX_TERMS * 32;
+constexpr int moment_off(int n) { return (n + 3) / 4 * 4 - n; }                       // OFF of K1D<float, n>
+constexpr int moment_lo(int n) { return (31 + moment_off(n) + 1) / 2 * 2; }           // first sample of the common block (even)
+constexpr int moment_hi(int n) { return (moment_off(n) + 2 * n + 1) / 2 * 2; }        // one past its last sample (even)
 struct MomentArgs { const float *table; };
 
 enum : unsigned {
@@ -83,11 +89,14 @@ int sg1d_launch_f64_g1(int n, const sg::Job1D *job, const sg::Taps *taps, unsign
 int sg1d_launch_f64_g2(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
 int sg1d_launch_f64_g3(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
 
-// the n = 32 fp32 kernel with `terms` block moments (3, 5 or 7); returns 0 when enqueued
-int sg1d_launch_f32_moment(int terms, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
-// fits the polynomial behind the 65 centre taps and fills table[MOMENT_TABLE_FLOATS]; returns the number of moments the kernel
-// needs (3, 5, 7) or 0 when the taps are not a polynomial of degree <= 6 to fp32 rounding (sg_k1d_moment_fit.cpp)
-int sg1d_moment_prepare(const float *center_weights, float *table);
+// the fp32 kernel for half window n (24..32) with `terms` block moments (3, 5 or 7); one object per term count; returns 0 when enqueued
+int sg1d_launch_f32_moment_t3(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
+int sg1d_launch_f32_moment_t5(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
+int sg1d_launch_f32_moment_t7(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
+// fits the polynomial behind the 2n+1 centre taps and fills table[MOMENT_TABLE_FLOATS]; returns the number of moments the kernel
+// needs (3, 5, 7) or 0 when n is outside 24..32 or the taps are not a polynomial of degree <= 6 to fp32 rounding
+// (sg_k1d_moment_fit.cpp)
+int sg1d_moment_prepare(int n, const float *center_weights, float *table);
 
 int sg1d_launch_edges_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
                           const float *d_edges, float dt_inv, int apply_scale, size_t channels, void *st);

@@ -1,21 +1,38 @@
-// sg_k1d_moment.hip -- instantiates the half_window = 32 fp32 kernel that replaces the 32 taps falling on a lane's own block by
-// block moments (sg_k1d_moment.hpp) for 3, 5 and 7 moments (poly_order <= 2, <= 4, <= 6), and exports its launcher.
+// sg_k1d_moment.hip -- instantiates the wide-window fp32 kernel that replaces the taps falling on the lanes' common block by
+// block moments (sg_k1d_moment.hpp) for half windows 24..32 and ONE moment count per object (SG_MOMENT_TERMS = 3, 5 or 7:
+// poly_order <= 2, <= 4, <= 6; built three times by the Makefile so the objects compile in parallel), and exports its launcher.
 #include "sg_k1d_moment.hpp"
 
 #include <cstdio>
 #include <cstdlib>
 
-extern "C" int sg1d_launch_f32_moment(int terms, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream)
+#if !defined(SG_MOMENT_TERMS) || !defined(SG_MOMENT_FN)
+#error "compile with -DSG_MOMENT_TERMS=3|5|7 -DSG_MOMENT_FN=symbol"
+#endif
+
+namespace sg {
+
+template <int N>
+static int launch_moment(int n, const Job1D &job, const MomentArgs &args, unsigned grid, hipStream_t st)
 {
-    const hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n == N) {
+        hipLaunchKernelGGL((sg1d_center_moment_kernel<N, SG_MOMENT_TERMS>), dim3(grid), dim3(256), 0, st, job, args);
+        return 0;
+    }
+    if constexpr (N < MOMENT_MAX_N) return launch_moment<N + 1>(n, job, args, grid, st);
+    else return 1;
+}
+
+}  // namespace sg
+
+extern "C" int SG_MOMENT_FN(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream)
+{
     const sg::MomentArgs args{d_table};
     static const bool debug = getenv("SAVGOL_HIP_DEBUG") != nullptr;
-    if (debug) fprintf(stderr, "[savgol-hip] sg1d_center_moment_kernel<%d>: grid %u x 256\n", terms, grid);
-    switch (terms) {
-    case 3: hipLaunchKernelGGL((sg::sg1d_center_moment_kernel<3>), dim3(grid), dim3(256), 0, st, *job, args); break;
-    case 5: hipLaunchKernelGGL((sg::sg1d_center_moment_kernel<5>), dim3(grid), dim3(256), 0, st, *job, args); break;
-    case 7: hipLaunchKernelGGL((sg::sg1d_center_moment_kernel<7>), dim3(grid), dim3(256), 0, st, *job, args); break;
-    default: sg_set_error("no moment kernel with %d terms", terms); return -1;
+    if (debug) fprintf(stderr, "[savgol-hip] sg1d_center_moment_kernel<%d,%d>: grid %u x 256\n", n, SG_MOMENT_TERMS, grid);
+    if (sg::launch_moment<sg::MOMENT_MIN_N>(n, *job, args, grid, static_cast<hipStream_t>(stream)) != 0) {
+        sg_set_error("no moment kernel for half_window %d", n);
+        return -1;
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sg_set_error("1-D moment kernel launch failed: %s", hipGetErrorString(e)); return -1; }

@@ -1,5 +1,5 @@
-// sg_k1d_moment_fit.cpp -- host side of the half_window = 32 fast path (sg_k1d_moment.hpp): recover the polynomial behind a
-// filter's 65 fp32 centre taps and re-express its 32-tap pieces in the Legendre basis of a 32-sample block.  Double
+// sg_k1d_moment_fit.cpp -- host side of the wide-window fast path (sg_k1d_moment.hpp, half windows 24..32): recover the polynomial
+// behind a filter's 2n+1 fp32 centre taps and re-express the taps that fall on the lanes' common block in that block's Legendre basis.  Double
 // precision throughout; the results are rounded to fp32 once, when the table is written.
 //
 // The taps are w[k] = p(k) + rounding, p of degree <= poly_order (reference compute_weight, src/savgolFilter.c:336-356).
@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int N = 32, WS = 65, BLOCK = 32, MAXT = sg::MOMENT_MAX_TERMS;
+constexpr int MAXWS = 65, MAXBLOCK = 32, MAXT = sg::MOMENT_MAX_TERMS;
 
 void legendre(double z, int terms, double *P)          // P[s] = P_s(z), s < terms
 {
@@ -58,11 +58,13 @@ bool fit(int terms, int count, const double *z, const double *y, double *coef)
 
 }  // namespace
 
-extern "C" int sg1d_moment_prepare(const float *w, float *table)
+extern "C" int sg1d_moment_prepare(int n, const float *w, float *table)
 {
-    double zk[WS], wk[WS], wmax = 0.0;
+    if (n < sg::MOMENT_MIN_N || n > sg::MOMENT_MAX_N) return 0;
+    const int WS = 2 * n + 1, OFF = sg::moment_off(n), LO = sg::moment_lo(n), HI = sg::moment_hi(n), BLOCK = HI - LO;
+    double zk[MAXWS], wk[MAXWS], wmax = 0.0;
     for (int k = 0; k < WS; ++k) {
-        zk[k] = (double)(k - N) / N; wk[k] = (double)w[k];
+        zk[k] = (double)(k - n) / n; wk[k] = (double)w[k];
         if (!std::isfinite(wk[k])) return 0;
         if (std::fabs(wk[k]) > wmax) wmax = std::fabs(wk[k]);
     }
@@ -84,38 +86,35 @@ extern "C" int sg1d_moment_prepare(const float *w, float *table)
     if (!terms) return 0;
     auto p = [&](double k) {                       // the polynomial behind the taps, at a real tap index
         double P[MAXT], v = 0.0;
-        legendre((k - N) / N, terms, P);
+        legendre((k - n) / n, terms, P);
         for (int s = 0; s < terms; ++s) v += coef[s] * P[s];
         return v;
     };
 
     memset(table, 0, sizeof(float) * sg::MOMENT_TABLE_FLOATS);
     for (int k = 0; k < WS; ++k) table[sg::MOMENT_OFF_W + k] = w[k];
-    // block basis phi_s(t) = P_s((t - 15.5) / 16), t = 0..31; the kernel reads t < 16 and mirrors the rest
-    double zt[BLOCK];
-    for (int t = 0; t < BLOCK; ++t) zt[t] = (t - 15.5) / 16.0;
-    for (int t = 0; t < 16; ++t) {
+    // block basis phi_s(t) = P_s((t - (BLOCK-1)/2) / (BLOCK/2)), t = 0..BLOCK-1; the kernel reads t < BLOCK/2 and mirrors the rest
+    double zt[MAXBLOCK];
+    for (int t = 0; t < BLOCK; ++t) zt[t] = (t - 0.5 * (BLOCK - 1)) / (0.5 * BLOCK);
+    for (int t = 0; t < BLOCK / 2; ++t) {
         double P[MAXT];
         legendre(zt[t], terms, P);
         for (int s = 1; s < terms; ++s) table[sg::MOMENT_OFF_PHI + (s - 1) * 16 + t] = (float)P[s];
     }
-    // Output r of a lane reads its own block X[32 + t] with tap w[t - r + 32]: q_r(t) = p(t - r + 32), a polynomial of degree
+    // Output r of a lane reads block sample X[LO + t] with tap k = LO + t - r - OFF: q_r(t) = p(k), a polynomial of degree
     // < terms in t, so its coefficients in the block basis are exact (the least-squares system has a zero residual).  The
-    // moments the kernel forms use the fp32-ROUNDED phi, so the coefficients are solved against those same rounded values:
-    // sum_s c_s(r) * phi32_s(t) then equals q_r(t) in the least-squares sense on the 32 block samples.
+    // moments the kernel forms use the fp32-ROUNDED phi, so the coefficients are solved against those same rounded values.
     for (int r = 0; r < 32; ++r) {
         double G[MAXT][MAXT] = {}, b[MAXT] = {}, c[MAXT] = {};
         for (int t = 0; t < BLOCK; ++t) {
-            double P[MAXT], Pr[MAXT];
-            legendre(zt[t], terms, P);
-            const int tm = t < 16 ? t : 31 - t;
+            double Pr[MAXT];
+            const int tm = t < BLOCK / 2 ? t : BLOCK - 1 - t;
             Pr[0] = 1.0;
             for (int s = 1; s < terms; ++s) {
                 const double v = (double)table[sg::MOMENT_OFF_PHI + (s - 1) * 16 + tm];
-                Pr[s] = (t < 16 || !(s & 1)) ? v : -v;
+                Pr[s] = (t < BLOCK / 2 || !(s & 1)) ? v : -v;
             }
-            (void)P;
-            const double q = p((double)(t - r + N));
+            const double q = p((double)(LO + t - r - OFF));
             for (int s = 0; s < terms; ++s) { b[s] += Pr[s] * q; for (int u = 0; u < terms; ++u) G[s][u] += Pr[s] * Pr[u]; }
         }
         if (!solve(terms, G, b, c)) return 0;

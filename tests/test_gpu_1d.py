@@ -472,8 +472,9 @@ def test_overlapping_device_buffers_are_refused(sg, torch_gpu):
     f.apply_batch(x, y, 4, 5000)                         # disjoint: fine
 
 
-def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu):
-    """half_window 32: the default kernel (block moments, csrc/sg_k1d_moment.hpp) and the plain 65-tap kernel
+@pytest.mark.parametrize("n", [32, 31, 30, 29, 28, 27, 26, 25, 24])
+def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu, n):
+    """half windows 24..32: the default kernel (block moments, csrc/sg_k1d_moment.hpp) and the plain 2n+1-tap kernel
     (SAVGOL_HIP_OPT_PLAIN_SUMMATION) are both within 1e-6 of the fp64 oracle and within 1e-6 of each other, for every boundary
     mode, VALID, derivative filters (2e-6) and a hand-edited table (which must silently take the plain kernel)."""
     torch = torch_gpu
@@ -484,8 +485,8 @@ def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu):
     for (m, d, mode, tol, dt) in [(4, 0, 0, 1e-6, 1.0), (4, 0, 1, 1e-6, 1.0), (4, 0, 2, 1e-6, 1.0), (4, 0, 3, 1e-6, 1.0), (2, 0, 1, 1e-6, 1.0),
                                   (6, 0, 1, 1e-6, 1.0), (4, 1, 3, 2e-6, 1.0), (4, 2, 0, 2e-5, 1.0), (3, 1, 2, 2e-6, 1.0),
                                   (4, 1, 0, 2e-6, 0.25), (4, 2, 1, 2e-5, 1e-3)]:          # time_step != 1: the dt_inv multiply after the sum
-        f = sg.Filter(32, m, d, dt, mode)
-        ref = sgo.Filter(32, m, d, dt, mode).apply_f64(xh)
+        f = sg.Filter(n, m, d, dt, mode)
+        ref = sgo.Filter(n, m, d, dt, mode).apply_f64(xh)
         a = f.apply_tensor(x).cpu().numpy()
         assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 1) == 0
         try:
@@ -495,9 +496,9 @@ def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu):
         assert not np.array_equal(a, b), "the option did not switch kernels"
         assert normwise(a, ref) < tol and normwise(b, ref) < tol, (m, d, mode, normwise(a, ref), normwise(b, ref))
         v = f.apply_tensor(x, valid=True).cpu().numpy()
-        assert normwise(v, ref[:, 32:-32]) < tol
+        assert normwise(v, ref[:, n:-n]) < tol
     # a table that is not a polynomial: same result with and without the option (both run the plain kernel)
-    f = sg.Filter(32, 4, 0, 1.0, 1)
+    f = sg.Filter(n, 4, 0, 1.0, 1)
     f.ptr.contents.center_weights[20] += 3e-4
     a = f.apply_tensor(x).cpu().numpy()
     L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 1)

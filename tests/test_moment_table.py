@@ -1,4 +1,4 @@
-"""Host logic of the half_window = 32 fast path (csrc/sg_k1d_moment_fit.cpp), no GPU needed: the constant table the kernel
+"""Host logic of the wide-window (half windows 24..32) fast path (csrc/sg_k1d_moment_fit.cpp), no GPU needed: the constant table the kernel
 reads is rebuilt into outputs with the kernel's own arithmetic (fp32 FMA chains in the kernel's order, emulated in numpy)
 and compared with the fp64 oracle.  The reference loop this path replaces: savgol_apply centre loop,
 /root/reference/src/savgolFilter.c:763-766 with convolve_ilp :547-580."""
@@ -29,48 +29,60 @@ def table_for(sg, n, m, d):
     return terms, tab, w
 
 
-def emulate(tab, terms, x):
-    """outputs of every 32-sample lane block of x (x has 32 halo samples each side), kernel order: head taps, own-block
-    moments (even / odd chains), tail taps."""
+def geometry(n):
+    """csrc/sg_k1d_host.hpp: moment_off / moment_lo / moment_hi"""
+    off = (n + 3) // 4 * 4 - n
+    return off, (31 + off + 1) // 2 * 2, (off + 2 * n + 1) // 2 * 2
+
+
+def emulate(tab, terms, x, n):
+    """outputs of every 32-sample lane block of x (x has n halo samples each side), kernel order: head taps, block moments
+    (even / odd chains), tail taps.  A lane's window is X[0 .. 32 + 2n + OFF) with X[OFF] = the first sample output 0 reads."""
+    off, lo, hi = geometry(n)
+    bk = hi - lo
     w = tab[OFF_W:OFF_W + 66]
-    lanes = (len(x) - 64) // 32
-    X = np.stack([x[32 * l:32 * l + 96] for l in range(lanes)])          # [lanes, 96]
-    phi = np.ones((terms, 32), f32)
+    lanes = (len(x) - 2 * n) // 32
+    xp = np.concatenate([np.zeros(off, f32), x, np.zeros(8, f32)])      # X[i] = xp[32 l + i]
+    X = np.stack([xp[32 * l:32 * l + 32 + 2 * n + off + 4] for l in range(lanes)])
+    phi = np.ones((terms, bk), f32)
     for s in range(1, terms):
-        half = tab[OFF_PHI + (s - 1) * 16:OFF_PHI + s * 16]
-        phi[s, :16] = half
-        phi[s, 16:] = half[::-1] * (f32(-1) if s & 1 else f32(1))
+        half = tab[OFF_PHI + (s - 1) * 16:OFF_PHI + (s - 1) * 16 + bk // 2]
+        phi[s, :bk // 2] = half
+        phi[s, bk // 2:] = half[::-1] * (f32(-1) if s & 1 else f32(1))
     c = np.zeros((terms, 32), f32)
     for s in range(terms):
         c[s] = tab[OFF_C + s * 32:OFF_C + (s + 1) * 32]
     mu = np.zeros((terms, lanes), f32)
     for s in range(terms):
         ae, ao = np.zeros(lanes, f32), np.zeros(lanes, f32)
-        for i in range(16):
-            ae = fma(phi[s, 2 * i], X[:, 32 + 2 * i], ae)
-            ao = fma(phi[s, 2 * i + 1], X[:, 33 + 2 * i], ao)
+        for i in range(bk // 2):
+            ae = fma(phi[s, 2 * i], X[:, lo + 2 * i], ae)
+            ao = fma(phi[s, 2 * i + 1], X[:, lo + 2 * i + 1], ao)
         mu[s] = ae + ao
     out = np.zeros((lanes, 32), f32)
     for r in range(32):
         a = np.zeros(lanes, f32)
-        for i in range(r, 32):
-            a = fma(w[i - r], X[:, i], a)
+        for i in range(r + off, lo):
+            a = fma(w[i - r - off], X[:, i], a)
         for s in range(terms):
             a = fma(c[s, r], mu[s], a)
-        for i in range(64, r + 65):
-            a = fma(w[i - r], X[:, i], a)
+        for i in range(hi, r + off + 2 * n + 1):
+            a = fma(w[i - r - off], X[:, i], a)
         out[:, r] = a
     return out.reshape(-1)
 
 
+@pytest.mark.parametrize("n", [32, 31, 30, 29, 28, 27, 26, 25, 24])
 @pytest.mark.parametrize("m,d,terms_expected,tol", [(4, 0, 5, 1e-6), (2, 0, 3, 1e-6), (3, 0, 3, 1e-6), (6, 0, 7, 1e-6),
                                                     (4, 1, 5, 2e-6), (4, 2, 5, 4e-6), (5, 1, 7, 2e-6), (0, 0, 3, 1e-6)])
-def test_table_reproduces_the_filter(sg, m, d, terms_expected, tol):
-    terms, tab, w = table_for(sg, 32, m, d)
+def test_table_reproduces_the_filter(sg, n, m, d, terms_expected, tol):
+    terms, tab, w = table_for(sg, n, m, d)
     assert terms == terms_expected
-    assert np.array_equal(tab[OFF_W:OFF_W + 65], w) and tab[65] == 0
-    x = sgo.synth_f32(5, 1, 32 * 64 + 64)[0]
-    got = emulate(tab, terms, x)
+    assert np.array_equal(tab[OFF_W:OFF_W + 2 * n + 1], w) and not tab[2 * n + 1:66].any()
+    off, lo, hi = geometry(n)
+    assert lo % 2 == 0 and hi % 2 == 0 and lo >= 31 + off and hi <= off + 2 * n + 1 and 16 <= hi - lo <= 32     # inside every window
+    x = sgo.synth_f32(5, 1, 32 * 64 + 2 * n)[0]
+    got = emulate(tab, terms, x, n)
     ref = np.convolve(x.astype(f64), w[::-1].astype(f64), "valid")[:len(got)]
     err = np.max(np.abs(got - ref)) / np.max(np.abs(ref))
     assert err < tol, f"m={m} d={d}: normwise error {err:.3e}"
@@ -78,7 +90,7 @@ def test_table_reproduces_the_filter(sg, m, d, terms_expected, tol):
 
 def test_paths_that_keep_the_plain_sum(sg):
     assert table_for(sg, 32, 8, 0)[0] == 0            # poly_order > 6
-    assert table_for(sg, 16, 4, 0)[0] == 0            # other half windows
+    assert table_for(sg, 16, 4, 0)[0] == 0 and table_for(sg, 23, 4, 0)[0] == 0      # half windows below 24
     # a hand-edited table is not a polynomial: the fit must refuse it
     L = sg.lib()
     cfg = sg.SavgolConfig(32, 4, 0, 1.0, 0)
