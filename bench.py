@@ -427,7 +427,7 @@ def pmc_traffic(alg_bytes):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x2
     for gfx950 + WRITE_SIZE, separate passes: profiles/*_pmc_summary.json, written by tools/pmc_summary.py).  bench.py cannot
     collect counters itself, so it reports a committed summary ONLY when that summary was taken on the kernel sources
-    this run is built from (sha256 of csrc/sg_k1d*.h* + sg_api_1d.cpp recorded in the summary) -- otherwise null."""
+    this run is built from (sha256 of csrc/sg_k1d*, sg_pk.hpp and sg_api_1d.cpp, recorded in the summary) -- otherwise null."""
     import glob
     try:
         cur = kernel_source_sha()
@@ -693,7 +693,7 @@ def main():
         import ctypes as C
         tab = (C.c_float * 400)()
         terms = sg.lib().savgol_hip_moment_table(filters[0].ptr, tab)
-        kernel = f"sg1d_center_moment_kernel<{terms}>" if terms > 0 else f"sg1d_center_kernel<float,{N}>"
+        kernel = f"sg1d_center_moment_kernel<{N},{terms}>" if terms > 0 else f"sg1d_center_kernel<float,{N}>"
         traffic, traffic_src = pmc_traffic(alg_bytes)
         out = {
             "metric": "Msamples/s filtered (1D batch, hw=32, poly=4) + % HBM roofline",
