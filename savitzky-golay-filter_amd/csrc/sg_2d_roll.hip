@@ -39,7 +39,14 @@ struct Roll {
     static constexpr int SW = 4 * OUTL;                     // stored columns per strip
     static constexpr int NQ = 2 * HL + 1;                   // 16-byte quads a lane reads back per term
     static constexpr int D = 4 * HL - N;                    // window index of the first tap of output 0
-    static constexpr int P = 1;                             // rows loaded ahead of the arithmetic (odd: U must be even)
+    // rows loaded ahead of the arithmetic (odd: U must be even).  PMC on config 4 (n=7) showed the waves parked on s_waitcnt 47 %
+    // of their cycles with one row ahead; three rows ahead cost 8 VGPRs and buy 7 % at n=7, 3-8 % at n = 6, 10, 12, but lose
+    // at n = 4, 8, 9 where the extra registers cost occupancy or spill (A/B in one process, tools/ab_2d.py)
+#ifdef SG_ROLL_P
+    static constexpr int P = SG_ROLL_P;
+#else
+    static constexpr int P = (N == 6 || N == 7 || N >= 10) ? 3 : 1;
+#endif
     static constexpr int U = 2 * N + 1 + P;                 // ring slots = unroll factor of the row loop
     static constexpr int BUFW = 256 + 8 * HL;               // LDS floats per term row (strip + pad both sides)
     static constexpr int NP = N / 2 + 1;                    // SGPR pairs holding taps 0..N
