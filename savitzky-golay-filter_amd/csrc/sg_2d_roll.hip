@@ -200,9 +200,14 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
         if (yo >= ylo && yo < yhi) {                         // uniform
             float *orow = outs[o] + (long long)yo * job.out_stride;
             if constexpr (VEC) {
-                if (out_lane)
+                if (out_lane) {
+#ifdef SG_ROLL_PLAIN_STORE
+                    *reinterpret_cast<f32x4 *>(orow + c0) = f32x4{r[0].x, r[0].y, r[1].x, r[1].y};
+#else
                     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, f32x4{r[0].x, r[0].y, r[1].x, r[1].y}),
                                                 reinterpret_cast<u32x4 *>(orow + c0));
+#endif
+                }
             } else if (out_lane) {
                 if (c0 >= xlo && c0 < xhi) orow[c0] = r[0].x;
                 if (c0 + 1 >= xlo && c0 + 1 < xhi) orow[c0 + 1] = r[0].y;

@@ -18,7 +18,8 @@ static void run(const T *in, T *out, unsigned channels, unsigned length, unsigne
     memset(&job, 0, sizeof(job));
     job.in = in; job.out = out; job.in_ld = length; job.out_ld = length; job.length = length;
     const unsigned TW = 64 * sg::vectors_per_lane(sizeof(T), N) * (16 / sizeof(T));
-    job.tiles_per_channel = (length + TW - 1) / TW;
+    const unsigned tpc_ = (length + TW - 1) / TW;
+    sg::set_tiles_per_channel(job, tpc_);
     job.total_tiles = channels * job.tiles_per_channel;
     job.store_lo = 0; job.store_hi = length; job.out_shift = 0; job.dt_inv = 1.0f;
     job.flags = 1u | sg::JOB_VEC_IN | sg::JOB_VEC_OUT;
