@@ -26,6 +26,7 @@ static void run(const T *in, T *out, unsigned channels, unsigned length, unsigne
     sg::Taps taps;
     memset(&taps, 0, sizeof(taps));
     for (int k = 0; k < 2 * N + 1; ++k) taps.w[k] = 1.0f / (2 * N + 1);
+    grid = ((job.total_tiles + 3) / 4 + 7) & ~7u;             // round 2: one tile per wave, blocks in order (the argument is ignored)
     unsigned long long *d_st;
     CK(hipMalloc(&d_st, 64 * 8 * 8));
     CK(hipMemset(d_st, 0, 64 * 8 * 8));
@@ -40,7 +41,7 @@ static void run(const T *in, T *out, unsigned channels, unsigned length, unsigne
     std::vector<unsigned long long> st(64 * 8);
     CK(hipMemcpy(st.data(), d_st, 64 * 8 * 8, hipMemcpyDeviceToHost));
     printf("%s N=%d grid=%u: %.3f ms (stamped build)\n", sizeof(T) == 4 ? "f32" : "f64", N, grid, ms);
-    printf("  iter:  wait+stage   prefetch-issue   compute   store   | total (cycles)\n");
+    printf("  one tile of block 8 / wave 1:  load+stage   (sync)   compute   store   | total (cycles)\n");
     for (int it = 0; it < 12; ++it) {
         const unsigned long long *s = &st[it * 8];
         if (!s[4]) break;
