@@ -48,6 +48,13 @@ struct Roll {
     static constexpr int P = (N == 6 || N == 7 || N >= 10) ? 3 : 1;
 #endif
     static constexpr int U = 2 * N + 1 + P;                 // ring slots = unroll factor of the row loop
+    // branch-free row loop (buffer stores whose range check replaces the `if`, whole groups of U rows without an exit test):
+    // measured +4 % at n=7, +12-15 % at n = 10, 12, -3...-7 % at n <= 4 (tools/ab_2d.py), neutral or worse at n = 6, 8, 9: so at n = 7 and from n = 10 up
+#ifdef SG_ROLL_STRAIGHT
+    static constexpr bool STRAIGHT = SG_ROLL_STRAIGHT != 0;
+#else
+    static constexpr bool STRAIGHT = N == 7 || N >= 10;
+#endif
     static constexpr int BUFW = 256 + 8 * HL;               // LDS floats per term row (strip + pad both sides)
     static constexpr int NP = N / 2 + 1;                    // SGPR pairs holding taps 0..N
 };
@@ -106,6 +113,15 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
         else return f32x4{row[ix0], row[ix1], row[ix2], row[ix3]};
     };
     const bool out_lane = lane >= R::HL && lane < 64 - R::HL;
+    const int yend = yb + nout;                              // first frame row past this band
+    __amdgpu_buffer_rsrc_t rsrc[NOUT];                       // VEC stores go through a buffer descriptor per output frame (range-checked)
+    const __amdgpu_buffer_rsrc_t rsrc_none = __builtin_amdgcn_make_buffer_rsrc(outs[0], 0, 0, 0x00020000);     // zero records: drops every store
+    const unsigned col_off = out_lane ? (unsigned)(c0 * 4) : 0x80000000u;
+    if constexpr (VEC && R::STRAIGHT) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+            rsrc[o] = __builtin_amdgcn_make_buffer_rsrc(outs[o], 0, (int)((long long)job.rows * job.out_stride * 4), 0x00020000);
+    }
     float *const wr = mine + 4 * R::HL + 4 * lane;           // where this lane's vertical results go
     const float *const rd = mine + 4 * lane;                 // where its horizontal window starts
 
@@ -197,17 +213,23 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
                 return true;
             });
         }
-        if (yo >= ylo && yo < yhi) {                         // uniform
+        if constexpr (VEC && R::STRAIGHT) {
+            // ONE unconditional store instruction per row: a lane that must not store (strip halo, rows outside the band or the
+            // stored range) gets an offset beyond the buffer and the hardware range check drops it.  A store under an `if` is a
+            // branch, and behind a branch hipcc no longer knows how many memory operations are in flight: it then waits for
+            // vmcnt(1) where vmcnt(6) would do, which drains the row prefetch (PMC: waves parked 41 % of their cycles).
+            // The lane part of the offset (column bytes, or 2 GiB for a halo lane: beyond any frame the host lets through, with
+            // or without the row part added) is fixed for the item; the row part is wave-uniform: one v_add per row.  A row
+            // nobody stores selects the empty descriptor (scalar select).
+            const bool keep_row = yo >= ylo && yo < yhi && yo < yend;                     // uniform
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{r[0].x, r[0].y, r[1].x, r[1].y}), keep_row ? rsrc[o] : rsrc_none,
+                                                   (int)(col_off + (unsigned)(yo * job.out_stride * 4)), 0, 2 /* nt */);
+        } else if (yo >= ylo && yo < yhi && yo < yend) {     // uniform
             float *orow = outs[o] + (long long)yo * job.out_stride;
             if constexpr (VEC) {
-                if (out_lane) {
-#ifdef SG_ROLL_PLAIN_STORE
-                    *reinterpret_cast<f32x4 *>(orow + c0) = f32x4{r[0].x, r[0].y, r[1].x, r[1].y};
-#else
+                if (out_lane)
                     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, f32x4{r[0].x, r[0].y, r[1].x, r[1].y}),
                                                 reinterpret_cast<u32x4 *>(orow + c0));
-#endif
-                }
             } else if (out_lane) {
                 if (c0 >= xlo && c0 < xhi) orow[c0] = r[0].x;
                 if (c0 + 1 >= xlo && c0 + 1 < xhi) orow[c0 + 1] = r[0].y;
@@ -223,23 +245,25 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 #pragma unroll
     for (int r = 0; r < R::U; ++r) win[r] = load_row(r);         // rows 0..2N for the first output row, P more in flight
     vertical(std::integral_constant<int, 0>{}, 0);
-    int done = 1;                                            // rows whose vertical pass has run
-    for (int base = 1; base < nout; base += R::U) {
+    // Iteration m runs the vertical pass of row m and the horizontal pass + store of row m-1.  Whole groups of U iterations, no
+    // early exit: the iterations past the band (at most U-1, their loads clamped to real rows) compute rows nobody stores.  An
+    // exit test per row would be a branch per row, with the same cost to the wait counts as a branch around the store.
+    for (int base = 1; base <= nout; base += R::U) {
         static_for(std::make_integer_sequence<int, R::U>{}, [&](auto uuc) -> bool {
             constexpr int uu = decltype(uuc)::value;
             const int m = base + uu;                         // base = 1 mod U: row m starts in slot (uu+1) % U
-            if (m >= nout) return false;                     // uniform
+            if constexpr (!R::STRAIGHT) { if (m > nout) return false; }     // uniform; iteration m = nout still stores row nout-1
             win[uu] = load_row(m + R::U - 1);                // slot of row m-1, which no later row needs
             vertical(std::integral_constant<int, (uu + 1) % R::U>{}, (uu + 1) & 1);
             wave_lds_sync();                                 // orders this row's LDS writes and the reads below for the compiler
             finish_row(uu & 1, yb + m - 1);
-            done = m + 1;
+            // ... and those reads before the next iteration's writes into the same LDS row: without a branch between the
+            // iterations the compiler is free to hoist a lane's next write above reads of OTHER columns that it can prove
+            // distinct for that lane -- which are exactly the words its neighbours are about to read
+            wave_lds_sync();
             return true;
         });
     }
-    wave_lds_sync();
-    finish_row((done - 1) & 1, yb + done - 1);
-    wave_lds_sync();                                         // the next item's first write must stay behind these reads
 }
 
 // terms per output the rolling kernel is built for: the taps live in SGPRs (2 * NT * NOUT * (N/2 + 1) pairs), which caps the
@@ -358,7 +382,8 @@ static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], co
     int aligned = 0;
     if (job.in_stride % 4 == 0 && job.in_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.in) & 15u) == 0) aligned |= 1;
     if (job.out_stride % 4 == 0 && job.out_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.out) & 15u) == 0 &&
-        (NOUT == 1 || (reinterpret_cast<uintptr_t>(out1) & 15u) == 0)) aligned |= 2;
+        (NOUT == 1 || (reinterpret_cast<uintptr_t>(out1) & 15u) == 0) &&
+        (long long)job.rows * job.out_stride * 4 < 0x7fffff00ll) aligned |= 2;       // the store descriptor holds a 31-bit byte count
     hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT>), dim3(grid), dim3(256), lds, st, job, taps, out1, strips, bands, band_rows,
                        (unsigned)total, aligned);
     return 0;
