@@ -270,10 +270,11 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 // wide windows at 3 terms (1 when two outputs share the walk); everything else runs the tile kernel of sg_2d_sep.hip
 constexpr int roll_max_terms(int n, int nout) { return nout == 1 ? (n <= 8 ? SEP_MAX_TERMS : 3) : (n <= 8 ? 3 : 1); }
 // waves per SIMD the register allocation must allow: the row ring alone is (2N+2) x 4 VGPRs
-constexpr int roll_min_waves(int n, int nt) { return n >= 9 ? 2 : ((nt >= 3 && n >= 6) || (n == 7 && nt == 2) ? 3 : 4); }
+// (n = 7 with three rows in flight and the two-output form at n = 8 spill at 4 waves per SIMD: 300 / 108 bytes of scratch)
+constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt >= 3 && n >= 6) || n == 7 || (n == 8 && nout == 2) ? 3 : 4); }
 
 template <int N, int NT, int NOUT>
-__global__ __launch_bounds__(256, roll_min_waves(N, NT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1,
+__global__ __launch_bounds__(256, roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
     typedef Roll<N> R;
