@@ -42,15 +42,19 @@ struct Job1D {
 // runs the float-reciprocal sequence on the VECTOR unit, ~25 instructions per tile in a kernel that is VALU-issue bound).
 // For 0 <= t < 2^31 and 2^(l-1) < d <= 2^l:  floor(t / d) == (t * ceil(2^(31+l) / d)) >> (31 + l), and the multiplier
 // fits 32 bits; d == 1 is flagged with shift 32.
-inline void set_tiles_per_channel(Job1D &job, unsigned d)
+inline void division_magic(unsigned d, unsigned *magic, unsigned *shift)
 {
-    job.tiles_per_channel = d;
-    if (d <= 1) { job.tpc_magic = 0; job.tpc_shift = 32; return; }
+    if (d <= 1) { *magic = 0; *shift = 32; return; }
     unsigned l = 0;
     while ((1ull << l) < d) ++l;
     const unsigned long long p = 1ull << (31 + l);
-    job.tpc_magic = (unsigned)((p + d - 1) / d);
-    job.tpc_shift = l - 1;
+    *magic = (unsigned)((p + d - 1) / d);
+    *shift = l - 1;
+}
+inline void set_tiles_per_channel(Job1D &job, unsigned d)
+{
+    job.tiles_per_channel = d;
+    division_magic(d, &job.tpc_magic, &job.tpc_shift);
 }
 
 // The wide-window fp32 fast path (sg_k1d_moment.hpp, half windows 24..32): one device table per filter content, read through

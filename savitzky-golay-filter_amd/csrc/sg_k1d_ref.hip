@@ -84,6 +84,7 @@ struct RefJob {
     int          length, mode;
     int          store_lo, store_hi, out_shift;
     unsigned     tiles_per_channel, total_tiles;
+    unsigned     tpc_magic, tpc_shift;                       // tile / tiles_per_channel on the scalar unit (division_magic)
     float        dt_inv;
     int          vec_in, vec_out;                            // rows 16-byte aligned
 };
@@ -96,17 +97,20 @@ __global__ __launch_bounds__(256) void sg1d_refpk_kernel(const RefJob job, const
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *slab = smem + wave * K::SLAB;
-    const unsigned nblk = gridDim.x;
-    const unsigned blk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
-    const unsigned nwaves = nblk * 4u;
+    // one tile per wave, blocks dispatched in order, each XCD sweeping its own eighth of the batch (as sg1d_center_kernel, round 2)
+    const unsigned nb8 = gridDim.x >> 3;
+    unsigned blk = blockIdx.x;
+    if (blk < nb8 * 8u) blk = (blk & 7u) * nb8 + (blk >> 3);
+    const unsigned tile = blk * 4u + (unsigned)wave;
+    if (tile >= job.total_tiles) return;
     const int L = job.length;
 
     f32x2 W[N + 1];
 #pragma unroll
     for (int p = 0; p < N + 1; ++p) W[p] = f32x2{taps.w[2 * p], taps.w[2 * p + 1]};
 
-    for (unsigned tile = blk * 4u + (unsigned)wave; tile < job.total_tiles; tile += nwaves) {
-        const unsigned c = tile / job.tiles_per_channel;
+    {
+        const unsigned c = job.tpc_shift >= 32 ? tile : (__umulhi(tile, job.tpc_magic) >> job.tpc_shift);
         const int t0 = (int)(tile - c * job.tiles_per_channel) * K::TW;          // first output of the tile
         const float *x = job.in + (long long)c * job.in_ld;
         float *y = job.out + (long long)c * job.out_ld;
@@ -160,10 +164,9 @@ __global__ __launch_bounds__(256) void sg1d_refpk_kernel(const RefJob job, const
 template <int N>
 static int launch_refpk(const RefJob &job, const Taps &taps, int cu_count, hipStream_t st)
 {
-    unsigned blocks = (job.total_tiles + 3u) / 4u;
-    const unsigned resident = (unsigned)cu_count * 8u;       // ~60 VGPRs, 14 KB of LDS per block: 8 blocks per CU
-    if (blocks > resident) blocks = resident;
+    unsigned blocks = (job.total_tiles + 3u) / 4u;             // one tile per wave
     blocks = (blocks + 7u) & ~7u;
+    (void)cu_count;
     hipLaunchKernelGGL((sg1d_refpk_kernel<N>), dim3(blocks), dim3(256), 0, st, job, taps);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -193,6 +196,7 @@ extern "C" int sg1d_launch_refpk_f32(const float *in, float *out, long long in_l
     job.in_ld = in_ld; job.out_ld = out_ld; job.length = (int)length; job.mode = mode;
     job.store_lo = store_lo; job.store_hi = store_hi; job.out_shift = out_shift; job.dt_inv = dt_inv;
     job.tiles_per_channel = (unsigned)((length + 511) / 512);
+    division_magic(job.tiles_per_channel, &job.tpc_magic, &job.tpc_shift);
     job.vec_in = (in_ld % 4 == 0);
     job.vec_out = (out_ld % 4 == 0) && (out_shift % 4 == 0);
     const size_t max_ch = (size_t)0x7fffffffu / job.tiles_per_channel;
