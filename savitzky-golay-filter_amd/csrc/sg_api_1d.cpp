@@ -269,7 +269,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
 // reaches outputs that are not stored), so the result is the reference's, bit for bit, as before.
 // ------------------------------------------------------------------------------------------------
 constexpr size_t PIPE_MIN_LENGTH = (size_t)1 << 23;       // below this the plain path is as fast
-constexpr size_t PIPE_CHUNK = (size_t)1 << 22;            // 16 MB of samples per chunk
+constexpr size_t PIPE_CHUNK_DEFAULT = (size_t)1 << 22;    // 16 MB of samples per chunk (SAVGOL_HIP_PIPE_CHUNK_LOG2 overrides: tuning)
 constexpr int    PIPE_HALO = 32;                          // >= any half window, multiple of 4
 
 struct PipeStreams { hipStream_t up = nullptr, down = nullptr; };
@@ -308,6 +308,11 @@ int host_apply_pipelined(const char *who, DeviceCtx *ctx, const SavgolFilter *f,
     const int shift = (variant == VALID) ? n : 0;
     const float dt_inv = dt_inverse(f);
 
+    static const size_t PIPE_CHUNK = [] {
+        const char *e = getenv("SAVGOL_HIP_PIPE_CHUNK_LOG2");
+        const int l = e ? atoi(e) : 0;
+        return (l >= 16 && l <= 26) ? (size_t)1 << l : PIPE_CHUNK_DEFAULT;
+    }();
     const size_t lo = PIPE_HALO, hi = L - PIPE_HALO;                       // centre outputs [lo, hi) go through the chunks
     const size_t nchunks = (hi - lo + PIPE_CHUNK - 1) / PIPE_CHUNK;
     std::vector<hipEvent_t> done(nchunks, nullptr);
