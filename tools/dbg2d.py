@@ -1,3 +1,5 @@
+"""Diagnostic: where (rows / columns / frames) the 2-D rolling kernel (method 2) and the tile kernel (method 3) disagree -- found the
+missing LDS ordering fence of the branch-free row loop.  python tools/dbg2d.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from __graft_entry__ import load_package
