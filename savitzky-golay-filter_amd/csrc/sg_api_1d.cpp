@@ -474,7 +474,10 @@ int savgol_apply(const SavgolFilter *filter, const float *input, float *output, 
     DeviceCtx *ctx = sg::ctx_get();
     if (!ctx) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-    if (length >= PIPE_MIN_LENGTH && length <= ((size_t)1 << 30)) {
+    // pipelined unless the two host buffers overlap without being the same (in place is fine: a chunk is downloaded only
+    // after the samples it overwrites went up; a shifted overlap is not, so that case keeps the upload-everything-first path)
+    const bool partial_overlap = input != output && (uintptr_t)input < (uintptr_t)(output + length) && (uintptr_t)output < (uintptr_t)(input + length);
+    if (length >= PIPE_MIN_LENGTH && length <= ((size_t)1 << 30) && !partial_overlap) {
         if (host_apply_pipelined("savgol_apply", ctx, filter, input, output, length, FULL) == 0) return 0;
         fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error());
         return -1;
@@ -498,7 +501,9 @@ size_t savgol_apply_valid(const SavgolFilter *filter, const float *input, size_t
     if (!ctx) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     const size_t out_len = input_length - 2 * (size_t)filter->config.half_window;
-    if (input_length >= PIPE_MIN_LENGTH && input_length <= ((size_t)1 << 30)) {
+    // VALID writes output[j - n]: even output == input is a shifted overlap, so only disjoint buffers are pipelined
+    const bool overlap = (uintptr_t)input < (uintptr_t)(output + out_len) && (uintptr_t)output < (uintptr_t)(input + input_length);
+    if (input_length >= PIPE_MIN_LENGTH && input_length <= ((size_t)1 << 30) && !overlap) {
         if (host_apply_pipelined("savgol_apply_valid", ctx, filter, input, output, input_length, VALID) == 0) return out_len;
         fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error());
         return 0;

@@ -558,3 +558,19 @@ def test_opt_in_boundary_aware_strided_call(sg, sgo, torch_gpu, mode):
         assert normwise(got[:, 1], want) < 2e-6 and np.all(got[:, 0] == -9.0)
     finally:
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_BOUNDARY_AWARE, 0)
+
+
+def test_long_host_signals_with_shifted_overlap_keep_the_serial_path(sg, sgo, torch_gpu):
+    """Partially overlapping host buffers (output = input + k) cannot be pipelined -- a downloaded chunk would overwrite samples
+    that have not gone up yet -- and must give what uploading everything first gives (the out-of-place answer)."""
+    L = (1 << 23) + 100
+    base = np.concatenate([sgo.synth_f32(9, 1, L)[0], np.zeros(64, np.float32)])
+    want = sgo.Filter(5, 3).apply(base[:L].copy())
+    f = sg.Filter(5, 3)
+    buf = base.copy()
+    assert sg.lib().savgol_apply(f.ptr, buf[:L].ctypes.data_as(C.POINTER(C.c_float)), buf[16:16 + L].ctypes.data_as(C.POINTER(C.c_float)), L) == 0
+    assert same_bits(buf[16:16 + L], want)
+    wantv = sgo.Filter(5, 3).apply_valid(base[:L].copy())
+    buf = base.copy()
+    got = sg.lib().savgol_apply_valid(f.ptr, buf[:L].ctypes.data_as(C.POINTER(C.c_float)), L, buf[:L].ctypes.data_as(C.POINTER(C.c_float)))
+    assert got == L - 10 and same_bits(buf[:L - 10], wantv)
