@@ -29,6 +29,8 @@
 #include <type_traits>
 #include <utility>
 
+#include <csetjmp>
+#include <csignal>
 #include <immintrin.h>
 
 #include "sg_internal.h"
@@ -194,6 +196,36 @@ static bool launch_service(int n, const ServiceArgs &args, const float *cw, unsi
     else return false;
 }
 
+// Can the host really store into fine-grained device memory on this box?  isLargeBar says the BAR covers the memory, not that
+// the allocation is mapped for the CPU; a store into an unmapped one is a SIGSEGV / SIGBUS.  Probed ONCE per process under a
+// guard (handlers saved and restored around the single store), because the alternative is to crash the caller.
+static sigjmp_buf g_probe_jmp;
+static void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
+static bool host_can_write_device_memory(void *p)
+{
+    static int verdict = -1;                                 // -1 unknown, 0 no, 1 yes
+    if (verdict >= 0) return verdict == 1;
+    struct sigaction old_segv, old_bus, sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = probe_fault;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGSEGV, &sa, &old_segv);
+    sigaction(SIGBUS, &sa, &old_bus);
+    if (sigsetjmp(g_probe_jmp, 1) == 0) {
+        volatile unsigned long long *w = static_cast<volatile unsigned long long *>(p);
+        w[0] = 0x5347u;
+        _mm_sfence();
+        verdict = (w[0] == 0x5347u) ? 1 : 0;
+        w[0] = 0;
+        _mm_sfence();
+    } else {
+        verdict = 0;
+    }
+    sigaction(SIGSEGV, &old_segv, nullptr);
+    sigaction(SIGBUS, &old_bus, nullptr);
+    return verdict == 1;
+}
+
 static void service_free(BankService *s)
 {
     if (!s) return;
@@ -256,9 +288,11 @@ int savgol_streambank_service_start(SavgolStreamBank *bank, unsigned idle_ms)
     if (ok && prop.isLargeBar && !force_host) {
         void *p = nullptr;
         if (hipExtMallocWithFlags(&p, sizeof(sg::ServiceMailbox) * sg::SERVICE_BELLS, hipDeviceMallocFinegrained) == hipSuccess) {
-            s->bell_dev = static_cast<sg::ServiceMailbox *>(p);
-            s->bell_host = s->bell_dev;
-            s->bell_in_device = true;
+            if (sg::host_can_write_device_memory(p)) {
+                s->bell_dev = static_cast<sg::ServiceMailbox *>(p);
+                s->bell_host = s->bell_dev;
+                s->bell_in_device = true;
+            } else (void)hipFree(p);
         } else (void)hipGetLastError();
     }
     if (ok && !s->bell_dev) {
