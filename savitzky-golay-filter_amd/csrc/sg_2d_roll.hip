@@ -8,7 +8,7 @@
 // unrolled loop indexes with literals), so the vertical pass costs no LDS traffic and no halo rows; only
 // the r vertical results of the current row cross lanes, through a wave-private LDS row (no
 // __syncthreads anywhere: LDS operations of one wave execute in order).  The 2*HL outermost lanes of a
-// strip are halo (their columns are recomputed by the neighbouring strip): 240 of 256 columns are stored.
+// strip are halo (their columns are recomputed by the neighbouring strip): 224 to 240 of 256 columns are stored.
 //
 // Every term of one kernel has the same parity in y ((-1)^dy) and in x ((-1)^dx), so both passes fold
 //      sum_k w[k] s[k]  =  sum_{k<N} w[k] (s[k] +- s[2N-k])  +  w[N] s[N]
@@ -34,7 +34,17 @@ namespace sg {
 
 template <int N>
 struct Roll {
-    static constexpr int HL = (N + 3) / 4;                  // halo lanes on each side of a strip
+    // halo lanes on each side of a strip: ceil(N/4) are needed; more where that buys whole memory lines.  A strip stores
+    // 1024 - 32*HL bytes per row starting 16*HL bytes into its loaded KiB: with HL = 1 (3) the stores of neighbouring strips meet
+    // inside 64-byte halves of a line.  Copying frames with this walk and no arithmetic (tools/membench2d.hip) moves 4.72 TB/s
+    // with HL = 1, 5.15 with HL = 2 (stores on 64-byte boundaries) and 5.22 with HL = 4 (stores on 128-byte lines); the kernel
+    // itself gains 8-11 % at n <= 4 with HL = 2 and 7 % at n = 5, 6 with HL = 4; n = 7, 8 and the VALU-bound n >= 9 gain nothing
+    // (tools/ab_2d.py, same process)
+#ifdef SG_ROLL_HL_MIN
+    static constexpr int HL = (N + 3) / 4 > SG_ROLL_HL_MIN ? (N + 3) / 4 : SG_ROLL_HL_MIN;
+#else
+    static constexpr int HL = N <= 4 ? 2 : (N <= 6 ? 4 : (N + 3) / 4);
+#endif
     static constexpr int OUTL = 64 - 2 * HL;                // lanes whose columns are stored
     static constexpr int SW = 4 * OUTL;                     // stored columns per strip
     static constexpr int NQ = 2 * HL + 1;                   // 16-byte quads a lane reads back per term
@@ -273,8 +283,15 @@ constexpr int roll_max_terms(int n, int nout) { return nout == 1 ? (n <= 8 ? SEP
 // (n = 7 with three rows in flight and the two-output form at n = 8 spill at 4 waves per SIMD: 300 / 108 bytes of scratch)
 constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt >= 3 && n >= 6) || n == 7 || (n == 8 && nout == 2) ? 3 : 4); }
 
+// waves per block: the waves of a block walk neighbouring strips row for row, so a block's loads of one row step are one
+// contiguous run of the frame row
+#ifndef SG_ROLL_WPB
+#define SG_ROLL_WPB 4
+#endif
+constexpr int roll_wpb(int n) { (void)n; return SG_ROLL_WPB; }
+
 template <int N, int NT, int NOUT>
-__global__ __launch_bounds__(256, roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1,
+__global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
     typedef Roll<N> R;
@@ -286,13 +303,14 @@ __global__ __launch_bounds__(256, roll_min_waves(N, NT, NOUT)) void sg2d_rolling
     // persistent waves; blocks that share an XCD (blockIdx % 8) take neighbouring items (halo columns meet in L2)
     const unsigned nblk = gridDim.x;
     const unsigned blk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
-    const unsigned nwaves = nblk * 4u;
+    constexpr unsigned WPB = (unsigned)roll_wpb(N);
+    const unsigned nwaves = nblk * WPB;
 
     const bool valid = job.boundary == SAVGOL2D_BOUNDARY_VALID;
     const int xlo = valid ? N : 0, xhi = valid ? job.cols - N : job.cols;
     const int ylo = valid ? N : 0, yhi = valid ? job.rows - N : job.rows;
 
-    for (unsigned item = blk * 4u + (unsigned)wv; item < total_items; item += nwaves) {
+    for (unsigned item = blk * WPB + (unsigned)wv; item < total_items; item += nwaves) {
         const unsigned strip = item % strips, ib = item / strips;
         const unsigned band = ib % bands, img = ib / bands;
         const int sx = (int)strip * R::SW, yb = (int)band * band_rows;
@@ -363,13 +381,15 @@ static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], co
 
     const unsigned strips = (unsigned)((job.cols + R::SW - 1) / R::SW);
     static int per_cu = 0;                                   // resident blocks per CU of this instantiation
-    const size_t lds = sizeof(float) * 4 * 2 * NOUT * NT * R::BUFW;
+    constexpr unsigned WPB = (unsigned)roll_wpb(N);
+    const size_t lds = sizeof(float) * WPB * 2 * NOUT * NT * R::BUFW;
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT>, 256, lds) != hipSuccess || nb < 1) nb = 2;
-        per_cu = nb > 4 ? 4 : nb;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT>, 64 * WPB, lds) != hipSuccess || nb < 1)
+            nb = WPB <= 8 ? 2 : 1;
+        per_cu = nb > (int)(16 / WPB) ? (int)(16 / WPB) : nb;
     }
-    const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
+    const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * WPB;
     unsigned bands = choose_bands(job.rows, (unsigned long long)images * strips, nwaves, N, 0.3);   // warm-up rows are only loaded
     static const char *env_bands = getenv("SAVGOL_HIP_ROLL_BANDS"), *env_one = getenv("SAVGOL_HIP_ROLL_ONEWAVE");     // tuning knobs
     if (env_bands && atoi(env_bands) > 0 && atoi(env_bands) <= job.rows) bands = (unsigned)atoi(env_bands);
@@ -377,15 +397,15 @@ static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], co
     bands = (unsigned)((job.rows + band_rows - 1) / band_rows);
     const unsigned long long total = (unsigned long long)images * strips * bands;     // caller keeps this < 2^32
     unsigned grid = (unsigned)cu_count * (unsigned)per_cu;
-    if (env_one && atoi(env_one)) grid = (unsigned)((total + 3) / 4);
-    if ((unsigned long long)grid * 4ull > total) grid = (unsigned)((total + 3) / 4);
+    if (env_one && atoi(env_one)) grid = (unsigned)((total + WPB - 1) / WPB);
+    if ((unsigned long long)grid * WPB > total) grid = (unsigned)((total + WPB - 1) / WPB);
     grid = (grid + 7u) & ~7u;
     int aligned = 0;
     if (job.in_stride % 4 == 0 && job.in_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.in) & 15u) == 0) aligned |= 1;
     if (job.out_stride % 4 == 0 && job.out_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.out) & 15u) == 0 &&
         (NOUT == 1 || (reinterpret_cast<uintptr_t>(out1) & 15u) == 0) &&
         (long long)job.rows * job.out_stride * 4 < 0x7fffff00ll) aligned |= 2;       // the store descriptor holds a 31-bit byte count
-    hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT>), dim3(grid), dim3(256), lds, st, job, taps, out1, strips, bands, band_rows,
+    hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT>), dim3(grid), dim3(64 * WPB), lds, st, job, taps, out1, strips, bands, band_rows,
                        (unsigned)total, aligned);
     return 0;
 }

@@ -1,19 +1,19 @@
 """A/B two builds of libsavgol_hip.so on the 2-D batch path in one process (config 4 shape).  python tools/ab_2d.py libA.so libB.so [--n 7]"""
 import argparse, ctypes as C, sys
 import numpy as np, torch
-ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--n", type=int, default=7); ap.add_argument("--images", type=int, default=64)
+ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--n", type=int, default=7); ap.add_argument("--images", type=int, default=64); ap.add_argument("--cols", type=int, default=4096); ap.add_argument("--rows", type=int, default=4096); ap.add_argument("--boundary", type=int, default=1)
 a = ap.parse_args()
 class Cfg2(C.Structure):
     _fields_ = [("nx", C.c_uint8), ("ny", C.c_uint8), ("order", C.c_uint8), ("dx", C.c_uint8), ("dy", C.c_uint8), ("ddx", C.c_float), ("ddy", C.c_float)]
-size = 4096
-x = torch.randn((a.images, size, size), device="cuda"); y = torch.empty_like(x)
+cols, rows = a.cols, a.rows
+x = torch.randn((a.images, rows, cols), device="cuda"); y = torch.empty_like(x)
 runs = []
 for path in a.libs:
     L = C.CDLL(path)
     L.savgol2d_create.restype = C.c_void_p; L.savgol2d_create.argtypes = [C.POINTER(Cfg2)]
     L.savgol2d_apply_batch_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
     f = L.savgol2d_create(C.byref(Cfg2(a.n, a.n, 3, 0, 0, 1.0, 1.0)))
-    run = lambda L=L, f=f: L.savgol2d_apply_batch_f32(f, x.data_ptr(), size, size, size, size * size, y.data_ptr(), size, size * size, a.images, 1, 2, None)
+    run = lambda L=L, f=f: L.savgol2d_apply_batch_f32(f, x.data_ptr(), rows, cols, cols, rows * cols, y.data_ptr(), cols, rows * cols, a.images, a.boundary, 2, None)
     assert run() == 0
     runs.append((path, run, []))
 torch.cuda.synchronize()
@@ -22,4 +22,4 @@ for r in range(10):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); run(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
 for path, run, ts in runs:
-    print(f"{path:50s} n={a.n}: median {np.median(ts):.3f} ms  min {min(ts):.3f}")
+    print(f"{path:50s} n={a.n} {rows}x{cols}x{a.images}: median {np.median(ts):.3f} ms  min {min(ts):.3f}")
