@@ -50,20 +50,23 @@ struct Roll {
     static constexpr int NQ = 2 * HL + 1;                   // 16-byte quads a lane reads back per term
     static constexpr int D = 4 * HL - N;                    // window index of the first tap of output 0
     // rows loaded ahead of the arithmetic (odd: U must be even).  PMC on config 4 (n=7) showed the waves parked on s_waitcnt 47 %
-    // of their cycles with one row ahead; three rows ahead cost 8 VGPRs and buy 7 % at n=7, 3-8 % at n = 6, 10, 12, but lose
-    // at n = 4, 8, 9 where the extra registers cost occupancy or spill (A/B in one process, tools/ab_2d.py)
+    // of their cycles with one row ahead; three rows ahead cost 8 VGPRs and buy 5-10 % from n = 6 up (n = 8: 2.21 -> 2.00 ms per
+    // 64 frames, n = 9: 2.41 -> 2.29), nothing or a loss below (tools/ab_2d.py, all builds in one process)
 #ifdef SG_ROLL_P
     static constexpr int P = SG_ROLL_P;
 #else
-    static constexpr int P = (N == 6 || N == 7 || N >= 10) ? 3 : 1;
+    static constexpr int P = N >= 6 ? 3 : 1;
 #endif
     static constexpr int U = 2 * N + 1 + P;                 // ring slots = unroll factor of the row loop
-    // branch-free row loop (buffer stores whose range check replaces the `if`, whole groups of U rows without an exit test):
-    // measured +4 % at n=7, +12-15 % at n = 10, 12, -3...-7 % at n <= 4 (tools/ab_2d.py), neutral or worse at n = 6, 8, 9: so at n = 7 and from n = 10 up
+    // branch-free row loop (buffer stores whose range check replaces the `if`, whole groups of U rows without an exit test).
+    // It paid (+4 % at n=7, +12-15 % at n = 10, 12) while the LDS reads of a row were issued right before their use: the branches
+    // made hipcc wait for vmcnt(1) where vmcnt(6) was meant.  With the reads issued a pass early (see roll_item) the plain loop
+    // is as fast or faster at every half window (n=7: 1.96 vs 2.04 ms, n=12: 2.87 vs 3.04), so it is off; the macro keeps the
+    // variant buildable for the next compiler.
 #ifdef SG_ROLL_STRAIGHT
     static constexpr bool STRAIGHT = SG_ROLL_STRAIGHT != 0;
 #else
-    static constexpr bool STRAIGHT = N == 7 || N >= 10;
+    static constexpr bool STRAIGHT = false;
 #endif
     static constexpr int BUFW = 256 + 8 * HL;               // LDS floats per term row (strip + pad both sides)
     static constexpr int NP = N / 2 + 1;                    // SGPR pairs holding taps 0..N
@@ -84,6 +87,19 @@ struct RollTaps {
 __device__ __forceinline__ f32x2 pk_fold(const f32x2 s, const f32x2 b, const f32x2 a)
 {
     return __builtin_elementwise_fma(s, b, a);
+}
+// (q.y, q.z) of ONE 16-byte LDS read: the middle pair of a quad sits in an odd-aligned register pair, and the compiler copies it
+// out with two v_mov_b32 (it only uses v_pk_mov_b32 for a pair that straddles two reads).  One v_pk_mov_b32 does it: 10 VALU
+// instructions fewer per row at n = 7, rank 2 (135 -> 125).
+__device__ __forceinline__ f32x2 pk_middle(const f32x2 lo, const f32x2 hi)
+{
+#ifdef SG_ROLL_PLAIN_MIDDLE
+    return pk_straddle(lo, hi);
+#else
+    f32x2 r;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+#endif
 }
 // fix_index (sg_2d.hpp) without branches: the row index is wave-uniform, so this is a handful of SALU selects
 __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
@@ -176,53 +192,57 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             return true;
         });
     };
-    // horizontal pass, part 1: this lane's window of every term's strip row of output `o`, from LDS row `par`
-    f32x4 hq[NT][R::NQ];
-    auto fetch = [&](auto oc, int par) {
-        constexpr int o = decltype(oc)::value;
+    // horizontal pass in units of one (output, term): the unit's window comes out of LDS row `par` into one of two register
+    // buffers, so the reads of unit u+1 are in flight while unit u is computed -- and the reads of a row's FIRST unit are issued
+    // before the vertical pass of the next row (they depend on nothing in it), which hides the LDS round trip behind that
+    // pass's 14 + 16 NT independent multiply-adds.  (Issued after it, as the first version did, every row had the wave stall
+    // on lgkmcnt three to four times with nothing to do.)
+    constexpr int UNITS = NOUT * NT;
+    f32x4 hq[2][R::NQ];
+    auto fetch = [&](auto uc, int par) {
+        constexpr int u = decltype(uc)::value, o = u / NT, t = u % NT;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < R::NQ; ++q) hq[t][q] = *reinterpret_cast<const f32x4 *>(rd + ((par * NOUT + o) * NT + t) * R::BUFW + 4 * q);
+        for (int q = 0; q < R::NQ; ++q) hq[u & 1][q] = *reinterpret_cast<const f32x4 *>(rd + ((par * NOUT + o) * NT + t) * R::BUFW + 4 * q);
     };
-    // part 2: the arithmetic on the fetched window and the store of frame row yo of output `o`
-    auto horizontal = [&](auto oc, int yo) {
-        constexpr int o = decltype(oc)::value;
-        f32x2 r[2];
+    // one unit's arithmetic on its fetched window, accumulated into r (the first term of an output starts it)
+    auto hterm = [&](auto uc, f32x2 (&r)[2]) {
+        constexpr int u = decltype(uc)::value, o = u / NT, t = u % NT;
+        f32x2 e[2 * R::NQ + 1];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x2 e[2 * R::NQ + 1];
-#pragma unroll
-            for (int q = 0; q < R::NQ; ++q) {
-                e[2 * q] = f32x2{hq[t][q].x, hq[t][q].y};
-                e[2 * q + 1] = f32x2{hq[t][q].z, hq[t][q].w};
-            }
-            f32x2 pr[2 * N + 3];                             // pr[j] = window floats (D+j, D+j+1)
-#pragma unroll
-            for (int j = 0; j < 2 * N + 3; ++j) {
-                const int idx = R::D + j;
-                pr[j] = (idx & 1) ? pk_straddle(e[idx >> 1], e[(idx >> 1) + 1]) : e[idx >> 1];
-            }
-            f32x2 f[2][N + 1];
-            auto fold = [&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                if constexpr (k < N) {
-                    f[0][k] = pk_fold(taps.sx[o], pr[2 * N - k], pr[k]);
-                    f[1][k] = pk_fold(taps.sx[o], pr[2 + 2 * N - k], pr[2 + k]);
-                } else {
-                    f[0][N] = pr[N];
-                    f[1][N] = pr[2 + N];
-                }
-            };
-            fold(std::integral_constant<int, 0>{});
-            static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
-                constexpr int k = decltype(kc)::value;
-                if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
-                if (k == 0 && t == 0) { r[0] = pk_mul_sgpr<0>(taps.q[o][0][0], f[0][0]); r[1] = pk_mul_sgpr<0>(taps.q[o][0][0], f[1][0]); }
-                else { pk_fma_sgpr<(k & 1)>(r[0], taps.q[o][t][k >> 1], f[0][k]); pk_fma_sgpr<(k & 1)>(r[1], taps.q[o][t][k >> 1], f[1][k]); }
-                return true;
-            });
+        for (int q = 0; q < R::NQ; ++q) {
+            e[2 * q] = f32x2{hq[u & 1][q].x, hq[u & 1][q].y};
+            e[2 * q + 1] = f32x2{hq[u & 1][q].z, hq[u & 1][q].w};
         }
+        f32x2 pr[2 * N + 3];                                 // pr[j] = window floats (D+j, D+j+1)
+#pragma unroll
+        for (int j = 0; j < 2 * N + 3; ++j) {
+            const int idx = R::D + j;
+            // e[2q], e[2q+1] are the halves of one read
+            pr[j] = (idx & 1) ? (((idx >> 1) & 1) ? pk_straddle(e[idx >> 1], e[(idx >> 1) + 1]) : pk_middle(e[idx >> 1], e[(idx >> 1) + 1])) : e[idx >> 1];
+        }
+        f32x2 f[2][N + 1];
+        auto fold = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < N) {
+                f[0][k] = pk_fold(taps.sx[o], pr[2 * N - k], pr[k]);
+                f[1][k] = pk_fold(taps.sx[o], pr[2 + 2 * N - k], pr[2 + k]);
+            } else {
+                f[0][N] = pr[N];
+                f[1][N] = pr[2 + N];
+            }
+        };
+        fold(std::integral_constant<int, 0>{});
+        static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
+            if constexpr (k == 0 && t == 0) { r[0] = pk_mul_sgpr<0>(taps.q[o][0][0], f[0][0]); r[1] = pk_mul_sgpr<0>(taps.q[o][0][0], f[1][0]); }
+            else { pk_fma_sgpr<(k & 1)>(r[0], taps.q[o][t][k >> 1], f[0][k]); pk_fma_sgpr<(k & 1)>(r[1], taps.q[o][t][k >> 1], f[1][k]); }
+            return true;
+        });
+    };
+    // the store of frame row yo of output `o`
+    auto store_row = [&](auto oc, const f32x2 (&r)[2], int yo) {
+        constexpr int o = decltype(oc)::value;
         if constexpr (VEC && R::STRAIGHT) {
             // ONE unconditional store instruction per row: a lane that must not store (strip halo, rows outside the band or the
             // stored range) gets an offset beyond the buffer and the hardware range check drops it.  A store under an `if` is a
@@ -248,8 +268,24 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             }
         }
     };
-    auto finish_row = [&](int par, int yo) {                 // horizontal pass of every output, one after the other (hq is reused)
-        static_for<NOUT>([&](auto oc) -> bool { fetch(oc, par); horizontal(oc, yo); return true; });
+    // units 0 .. UNITS-1 of the row in LDS row `par` (unit 0 already fetched): fetch the next unit, compute this one
+    auto finish_row = [&](int par, int yo) {
+        f32x2 r[2];
+        static_for<UNITS>([&](auto uc) -> bool {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u + 1 < UNITS) fetch(std::integral_constant<int, u + 1>{}, par);
+            // the row's last reads are issued: order them before the next iteration's writes into the same LDS row.  Without a
+            // branch between the iterations the compiler is free to hoist a lane's next write above reads of OTHER columns that it
+            // can prove distinct for that lane -- which are exactly the words its neighbours are about to read
+            if constexpr (u + 1 == UNITS) wave_lds_sync();
+            // keep the reads ahead of this unit's arithmetic and that arithmetic ahead of the next unit's: left alone, the
+            // scheduler pulls the first consumers of a read (the pair shuffles) up to right behind it and waits there
+            __builtin_amdgcn_sched_barrier(0);
+            hterm(uc, r);
+            if constexpr (u % NT == NT - 1) store_row(std::integral_constant<int, u / NT>{}, r, yo);
+            __builtin_amdgcn_sched_barrier(0);
+            return true;
+        });
     };
 
 #pragma unroll
@@ -264,13 +300,12 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             const int m = base + uu;                         // base = 1 mod U: row m starts in slot (uu+1) % U
             if constexpr (!R::STRAIGHT) { if (m > nout) return false; }     // uniform; iteration m = nout still stores row nout-1
             win[uu] = load_row(m + R::U - 1);                // slot of row m-1, which no later row needs
+            wave_lds_sync();                                 // row m-1's vertical results (previous iteration) are written ...
+            fetch(std::integral_constant<int, 0>{}, uu & 1); // ... and its first window is on its way while row m's vertical pass runs
+            __builtin_amdgcn_sched_barrier(0);
             vertical(std::integral_constant<int, (uu + 1) % R::U>{}, (uu + 1) & 1);
-            wave_lds_sync();                                 // orders this row's LDS writes and the reads below for the compiler
+            __builtin_amdgcn_sched_barrier(0);
             finish_row(uu & 1, yb + m - 1);
-            // ... and those reads before the next iteration's writes into the same LDS row: without a branch between the
-            // iterations the compiler is free to hoist a lane's next write above reads of OTHER columns that it can prove
-            // distinct for that lane -- which are exactly the words its neighbours are about to read
-            wave_lds_sync();
             return true;
         });
     }
@@ -280,8 +315,13 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 // wide windows at 3 terms (1 when two outputs share the walk); everything else runs the tile kernel of sg_2d_sep.hip
 constexpr int roll_max_terms(int n, int nout) { return nout == 1 ? (n <= 8 ? SEP_MAX_TERMS : 3) : (n <= 8 ? 3 : 1); }
 // waves per SIMD the register allocation must allow: the row ring alone is (2N+2) x 4 VGPRs
-// (n = 7 with three rows in flight and the two-output form at n = 8 spill at 4 waves per SIMD: 300 / 108 bytes of scratch)
-constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt >= 3 && n >= 6) || n == 7 || (n == 8 && nout == 2) ? 3 : 4); }
+// (n = 7 and n = 8 with three rows in flight and the two-output form at n = 6, rank 2, spill at 4 waves per SIMD: 300 / 20-108 / 12
+// bytes of scratch; tools/roll_resources.py lists every instantiation)
+#ifdef SG_ROLL_MINWAVES
+constexpr int roll_min_waves(int, int, int) { return SG_ROLL_MINWAVES; }
+#else
+constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt >= 3 && n >= 6) || n == 7 || n == 8 || (n == 6 && nt == 2 && nout == 2) ? 3 : 4); }
+#endif
 
 // waves per block: the waves of a block walk neighbouring strips row for row, so a block's loads of one row step are one
 // contiguous run of the frame row
