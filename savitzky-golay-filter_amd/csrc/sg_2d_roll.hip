@@ -353,6 +353,9 @@ __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void
     for (unsigned item = blk * WPB + (unsigned)wv; item < total_items; item += nwaves) {
         const unsigned strip = item % strips, ib = item / strips;
         const unsigned band = ib % bands, img = ib / bands;
+#ifdef SG_ROLL_SKIP_EDGE_STRIPS                                   // timing experiment only (wrong frames): what do the frame-edge strips cost?
+        if (strip == 0 || strip + 1 == strips) continue;
+#endif
         const int sx = (int)strip * R::SW, yb = (int)band * band_rows;
         const int nout = job.rows - yb < band_rows ? job.rows - yb : band_rows;
         const float *in = job.in + (long long)img * job.in_pitch;

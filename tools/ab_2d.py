@@ -1,12 +1,12 @@
 """A/B two builds of libsavgol_hip.so on the 2-D batch path in one process (config 4 shape).  python tools/ab_2d.py libA.so libB.so [--n 7]"""
 import argparse, ctypes as C, sys
 import numpy as np, torch
-ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--n", type=int, default=7); ap.add_argument("--images", type=int, default=64); ap.add_argument("--cols", type=int, default=4096); ap.add_argument("--rows", type=int, default=4096); ap.add_argument("--boundary", type=int, default=1)
+ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--n", type=int, default=7); ap.add_argument("--images", type=int, default=64); ap.add_argument("--cols", type=int, default=4096); ap.add_argument("--rows", type=int, default=4096); ap.add_argument("--boundary", type=int, default=1); ap.add_argument("--zeros", action="store_true", help="all-zero frames (data-dependent power)")
 a = ap.parse_args()
 class Cfg2(C.Structure):
     _fields_ = [("nx", C.c_uint8), ("ny", C.c_uint8), ("order", C.c_uint8), ("dx", C.c_uint8), ("dy", C.c_uint8), ("ddx", C.c_float), ("ddy", C.c_float)]
 cols, rows = a.cols, a.rows
-x = torch.randn((a.images, rows, cols), device="cuda"); y = torch.empty_like(x)
+x = torch.zeros((a.images, rows, cols), device="cuda") if a.zeros else torch.randn((a.images, rows, cols), device="cuda"); y = torch.empty_like(x)
 runs = []
 for path in a.libs:
     L = C.CDLL(path)
