@@ -96,7 +96,9 @@ long savgol_export_header(const SavgolFilter *filter, const char *prefix, const 
  * Arithmetic of savgol_apply (reference src/savgolFilter.c:743-804): centre taps on the
  * interior, filter->config.boundary on the first/last n samples (POLYNOMIAL rows incl. the
  * reference's reversed leading edge; REFLECT / PERIODIC / CONSTANT by index remap).
- * d_in and d_out must not overlap (checked: -1).  length >= 2n+1.
+ * d_in and d_out must not overlap (checked: -1).  length >= 2n+1, and any size_t beyond that, like the
+ * reference's: a channel longer than 2^30 samples is enqueued as sub-rows of 2^29 outputs plus its two
+ * ends (same arithmetic per output; a little stream-ordered scratch for the ends).
  * f32: fp32 tables, fp32 FMA accumulation (within 1e-6 normwise of the fp64 oracle).
  * f64: the same fp32 tables promoted exactly to double, double accumulation, the reference's
  *      float 1/dt_scale promoted -- there is no fp64 path in the reference.

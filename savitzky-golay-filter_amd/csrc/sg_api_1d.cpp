@@ -92,7 +92,8 @@ const MomentFit *moment_fit(const SavgolFilter *f)
     return m;
 }
 
-enum Variant { FULL = 0, VALID = 1, FULL_POLY_EDGES = 2 /* strided: polynomial edges whatever the mode */ };
+enum Variant { FULL = 0, VALID = 1, FULL_POLY_EDGES = 2 /* strided: polynomial edges whatever the mode */,
+               INTERIOR = 3 /* out[g] for g in [n, L-n) only: the segments of a channel longer than one launch indexes */ };
 
 inline float dt_inverse(const SavgolFilter *f)      // reference :759
 {
@@ -110,6 +111,14 @@ bool filter_sane(const SavgolFilter *f, const char *who)
     return true;
 }
 
+// samples per channel one launch indexes (32-bit sample and tile indices inside the kernels); longer channels are cut into
+// sub-rows by enqueue_long below -- the reference's savgol_apply takes a size_t length
+constexpr size_t LAUNCH_MAX_LENGTH = (size_t)1 << 30;
+
+template <typename T>
+int enqueue_long(const char *who, const SavgolFilter *f, const T *d_in, T *d_out, size_t channels, size_t length,
+                 size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, bool reference_order);
+
 template <typename T>
 int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_out, size_t channels, size_t length,
                   size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, bool reference_order = false)
@@ -118,7 +127,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     if (!filter_sane(f, who)) return -1;
     const int n = f->config.half_window, ws = f->window_size;
     if (length < (size_t)ws) { sg_set_error("%s: data length (%zu) < window size (%d)", who, length, ws); return -1; }
-    if (length > (size_t)1 << 30) { sg_set_error("%s: data length %zu exceeds 2^30 samples per channel", who, length); return -1; }
+    if (length > LAUNCH_MAX_LENGTH) return enqueue_long<T>(who, f, d_in, d_out, channels, length, in_ld, out_ld, variant, st, reference_order);
     const size_t out_len = (variant == VALID) ? length - 2 * (size_t)n : length;
     if (in_ld < length || out_ld < out_len) { sg_set_error("%s: row pitch smaller than the row", who); return -1; }
     if (channels == 0) return 0;
@@ -140,17 +149,19 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
             const float *d_table = sg::ctx_table(ctx, packed, sizeof(float) * (size_t)(n + 1) * ws, 0x1e00u + (unsigned)n);
             if (!d_table) return -1;
             const int rmode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
-            const int lo = (variant == VALID) ? n : 0, hi = (variant == VALID) ? (int)length - n : (int)length;
+            const bool inner = variant == VALID || variant == INTERIOR;                 // no edge outputs at all
+            const int lo = inner ? n : 0, hi = inner ? (int)length - n : (int)length;
+            const int shift = (variant == VALID) ? n : 0;
             const int negate = (rmode == SAVGOL_BOUNDARY_POLYNOMIAL && g_correct_leading_edge.load() && (f->config.derivative & 1)) ? 1 : 0;
             const bool poly = rmode == SAVGOL_BOUNDARY_POLYNOMIAL;
             int rc;
             if (channels * length >= ((size_t)1 << 16) && length >= (size_t)4 * ws) {
                 // long batches: the packed kernel for everything the centre taps produce, the per-thread kernel for
                 // the 2n POLYNOMIAL edge samples of every channel
-                const int clo = (poly || variant == VALID) ? n : 0, chi = (poly || variant == VALID) ? (int)length - n : (int)length;
+                const int clo = (poly || inner) ? n : 0, chi = (poly || inner) ? (int)length - n : (int)length;
                 rc = sg1d_launch_refpk_f32(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, f->center_weights,
-                                           dt_inverse(f), rmode, clo, chi, lo, channels, ctx->cu_count, st);
-                if (rc == 0 && poly && variant != VALID) {
+                                           dt_inverse(f), rmode, clo, chi, shift, channels, ctx->cu_count, st);
+                if (rc == 0 && poly && !inner) {
                     rc = sg1d_launch_reference_order_f32(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_table,
                                                          dt_inverse(f), rmode, 0, n, 0, negate, channels, st);
                     if (rc == 0)
@@ -159,7 +170,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
                 }
             } else {
                 rc = sg1d_launch_reference_order_f32(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_table,
-                                                     dt_inverse(f), rmode, lo, hi, lo, negate, channels, st);
+                                                     dt_inverse(f), rmode, lo, hi, shift, negate, channels, st);
             }
             if (rc != 0) { sg_set_error("%s: kernel launch failed", who); return -1; }
             return 0;
@@ -180,7 +191,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     sg::set_tiles_per_channel(job, (unsigned)((length + TW - 1) / TW));
     job.dt_inv = dt_inverse(f);
     // which samples the centre kernel stores: the interior when edge rows / VALID take the rest
-    const bool interior_only = (variant == VALID) || poly;
+    const bool interior_only = (variant == VALID) || poly;              // INTERIOR runs as poly without the edge rows
     job.store_lo = interior_only ? (unsigned)n : 0u;
     job.store_hi = interior_only ? (unsigned)(length - n) : (unsigned)length;
     job.out_shift = (variant == VALID) ? (unsigned)n : 0u;
@@ -212,7 +223,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     }
 
     const float *d_edges = nullptr;
-    if (poly && variant != VALID) {
+    if (poly && variant != VALID && variant != INTERIOR) {
         // rows packed [n][ws]
         float packed[SAVGOL_MAX_HALF_WINDOW * SAVGOL_MAX_WINDOW];
         for (int e = 0; e < n; ++e) memcpy(packed + e * ws, f->edge_weights[e], sizeof(float) * ws);
@@ -257,6 +268,60 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         if (rc != 0) { sg_set_error("%s: edge kernel launch failed", who); return -1; }
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channels longer than LAUNCH_MAX_LENGTH samples (the reference's savgol_apply takes any size_t length, savgolFilter.c:743-766).
+// Outputs [n, L-n) do not depend on the boundary mode: they are enqueued as sub-rows [a-n, b+n) of at most 2^29 + 2n samples
+// through the same kernels (what lies beyond a sub-row only reaches outputs it does not store).  The 2n edge outputs of a
+// channel only see the 3n samples next to them -- or, PERIODIC, the other end of the channel -- so they are computed on two
+// 256-sample copies of the channel ends (one ring of both ends for PERIODIC) and copied into place: same arithmetic per
+// output as the unsplit call, in every summation mode.  Everything is enqueued on `st`; the scratch is stream-ordered.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+int enqueue_long(const char *who, const SavgolFilter *f, const T *d_in, T *d_out, size_t channels, size_t length,
+                 size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, bool reference_order)
+{
+    const size_t n = (size_t)f->config.half_window;
+    const size_t out_len = (variant == VALID) ? length - 2 * n : length;
+    if (in_ld < length || out_ld < out_len) { sg_set_error("%s: row pitch smaller than the row", who); return -1; }
+    if (channels == 0) return 0;
+    {
+        const uintptr_t a0 = (uintptr_t)d_in, a1 = a0 + ((channels - 1) * in_ld + length) * sizeof(T);
+        const uintptr_t b0 = (uintptr_t)d_out, b1 = b0 + ((channels - 1) * out_ld + out_len) * sizeof(T);
+        if (a0 < b1 && b0 < a1) { sg_set_error("%s: d_in and d_out overlap (the device batch calls are out of place)", who); return -1; }
+    }
+    constexpr size_t SEG = (size_t)1 << 29;                       // outputs per sub-row (a multiple of the vector width: sub-rows stay 16-byte aligned)
+    for (size_t a = n; a < length - n; a += SEG) {
+        const size_t b = (length - n - a < SEG) ? length - n : a + SEG;
+        // VALID stores out[g - n], INTERIOR out[g]: the same pointer offset serves both
+        if (enqueue_batch<T>(who, f, d_in + (a - n), d_out + (a - n), channels, (b - a) + 2 * n, in_ld, out_ld,
+                             variant == VALID ? VALID : INTERIOR, st, reference_order) != 0) return -1;
+    }
+    if (variant == VALID || variant == INTERIOR) return 0;
+
+    constexpr size_t E = 256;                                    // samples of a channel end that are copied out (>= 4 half windows, vector aligned)
+    const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
+    T *scratch = nullptr;
+    if (!sg::hip_ok(hipMallocAsync(reinterpret_cast<void **>(&scratch), 4 * channels * E * sizeof(T), st), "hipMallocAsync(channel ends)")) return -1;
+    T *in_a = scratch, *in_b = scratch + channels * E, *out_a = scratch + 2 * channels * E, *out_b = scratch + 3 * channels * E;
+    auto copy2d = [&](T *dst, size_t dst_ld, const T *src, size_t src_ld, size_t width) {
+        return sg::hip_ok(hipMemcpy2DAsync(dst, dst_ld * sizeof(T), src, src_ld * sizeof(T), width * sizeof(T), channels, hipMemcpyDeviceToDevice, st),
+                          "hipMemcpy2DAsync(channel ends)");
+    };
+    bool ok;
+    if (mode == (int)SAVGOL_BOUNDARY_PERIODIC) {
+        // ring of both ends: [in[L-128 .. L), in[0 .. 128)]; its interior outputs 128-n .. 128+n-1 are the channel's L-n .. L-1, 0 .. n-1
+        ok = copy2d(in_a, E, d_in + (length - E / 2), in_ld, E / 2) && copy2d(in_a + E / 2, E, d_in, in_ld, E / 2) &&
+             enqueue_batch<T>(who, f, in_a, out_a, channels, E, E, E, INTERIOR, st, reference_order) == 0 &&
+             copy2d(d_out + (length - n), out_ld, out_a + (E / 2 - n), E, n) && copy2d(d_out, out_ld, out_a + E / 2, E, n);
+    } else {
+        ok = copy2d(in_a, E, d_in, in_ld, E) && copy2d(in_b, E, d_in + (length - E), in_ld, E) &&
+             enqueue_batch<T>(who, f, in_a, out_a, 2 * channels, E, E, E, variant, st, reference_order) == 0 &&      // in_b / out_b follow in_a / out_a
+             copy2d(d_out, out_ld, out_a, E, n) && copy2d(d_out + (length - n), out_ld, out_b + (E - n), E, n);
+    }
+    if (!sg::hip_ok(hipFreeAsync(scratch, st), "hipFreeAsync(channel ends)")) ok = false;
+    return ok ? 0 : -1;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -162,3 +162,125 @@ def test_2d_batch_and_derivative_calls_are_graph_capturable(sg, torch_gpu):
     torch.cuda.synchronize()
     for o, w in zip(outs, want):
         assert torch.equal(o, w)
+
+
+def test_one_channel_longer_than_2_pow_32_samples(sg, sgo, torch_gpu):
+    """Maximum sizes: a single channel of 2^32 + 4099 samples (17 GB in, 17 GB out) -- every sample index, tile index and byte
+    offset past 32 bits.  The convolution is local, so windows of the output are checked against the oracle run on the
+    matching slices of the input: both ends (edge rows), and around 2^31 and 2^32 samples (4 GiB / 8 GiB / 16 GiB of bytes)."""
+    torch = torch_gpu
+    length = (1 << 32) + 4099
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2 * length * 4 + (4 << 30):
+        pytest.skip("not enough HBM free for a 2^32-sample channel")
+    x = torch.empty((1, length), dtype=torch.float32, device="cuda")
+    sg.synth(x)
+    y = torch.empty_like(x)
+    n = 32
+    for mode in (0, 2):                                         # POLYNOMIAL edge rows, PERIODIC wrap (index length-1 ... 0)
+        f = sg.Filter(n, 4, 0, 1.0, mode)
+        f.apply_batch(x, y, 1, length)
+        torch.cuda.synchronize()
+        # interior windows: oracle on [c - 2000 - n, c + 2000 + n), compared on the inner 4000 samples
+        for c in ((1 << 30), (1 << 31) - 7, (1 << 31) + 2048 * 3 + 5, (1 << 32) - 1, (1 << 32) + 2000):
+            lo, hi = c - 2000 - n, min(c + 2000 + n, length)
+            xs = x[0, lo:hi].cpu().numpy().astype(np.float64)[None]
+            ref = sgo.Filter(n, 4, 0, 1.0, 0).apply_f64(xs)[0][n:-n]
+            got = y[0, lo + n:hi - n].cpu().numpy()
+            assert normwise(got, ref) < 1e-6, (mode, c, normwise(got, ref))
+        if mode == 0:
+            # the two ends: the oracle on the first / last 4096 samples gives the same edge rows as on the whole channel
+            for sl in (slice(0, 4096), slice(length - 4096, length)):
+                xs = x[0, sl].cpu().numpy().astype(np.float64)[None]
+                ref = sgo.Filter(n, 4, 0, 1.0, 0).apply_f64(xs)[0]
+                got = y[0, sl].cpu().numpy()
+                keep = slice(0, 4096 - n) if sl.start == 0 else slice(n, 4096)
+                assert normwise(got[keep], ref[keep]) < 1e-6
+        else:
+            # PERIODIC: the first n outputs read the last n samples of the channel and vice versa
+            ring = torch.cat((x[0, length - 2048:], x[0, :2048])).cpu().numpy().astype(np.float64)[None]
+            ref = sgo.Filter(n, 4, 0, 1.0, 0).apply_f64(ring)[0]
+            got = torch.cat((y[0, length - 2048:], y[0, :2048])).cpu().numpy()
+            assert normwise(got[n:-n], ref[n:-n]) < 1e-6
+    # the reference's summation order on the same channel: bit-identical to the oracle's fp32 path, REFLECT edges included
+    L = sg.lib()
+    assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 1) == 0
+    try:
+        f = sg.Filter(n, 4, 0, 1.0, 1)
+        f.apply_batch(x, y, 1, length)
+        torch.cuda.synchronize()
+    finally:
+        L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 0)
+    for c in ((1 << 29) + n, (1 << 30) + n - 1, (1 << 32) + 17):
+        lo, hi = c - 1000 - n, c + 1000 + n
+        ref = sgo.Filter(n, 4, 0, 1.0, 0).apply(x[0, lo:hi].cpu().numpy())[n:-n]
+        assert np.array_equal(y[0, lo + n:hi - n].cpu().numpy().view(np.uint32), ref.view(np.uint32)), c
+    for sl, keep in ((slice(0, 4096), slice(0, 4096 - n)), (slice(length - 4096, length), slice(n, 4096))):
+        ref = sgo.Filter(n, 4, 0, 1.0, 1).apply(x[0, sl].cpu().numpy())
+        assert np.array_equal(y[0, sl].cpu().numpy()[keep].view(np.uint32), ref[keep].view(np.uint32))
+    # VALID on the long channel: out[j] = full[j + n]
+    v = torch.empty((1, length - 2 * n), dtype=torch.float32, device="cuda")
+    sg.Filter(n, 4, 0, 1.0, 0).apply_batch(x, v, 1, length, valid=True)
+    sg.Filter(n, 4, 0, 1.0, 0).apply_batch(x, y, 1, length)
+    torch.cuda.synchronize()
+    for c in (0, (1 << 29) - 5, (1 << 31), length - 2 * n - 3000):
+        assert torch.equal(v[0, c:c + 3000], y[0, c + n:c + n + 3000]), c
+    del x, y, v
+    torch.cuda.empty_cache()
+
+
+def test_fp64_channels_longer_than_one_launch(sg, sgo, torch_gpu):
+    """Three fp64 channels of 2^30 + 2^29 + 77 samples with an odd row pitch (unaligned rows): the sub-row path of the fp64 kernel."""
+    torch = torch_gpu
+    length, ld, ch, n = (1 << 30) + (1 << 29) + 77, (1 << 30) + (1 << 29) + 79, 3, 32
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2 * ch * ld * 8 + (4 << 30):
+        pytest.skip("not enough HBM free")
+    xb = torch.empty((ch, ld), dtype=torch.float64, device="cuda")
+    sg.synth(xb)
+    yb = torch.zeros_like(xb)
+    f = sg.Filter(n, 4, 2, 1.0, 3)                                  # CONSTANT edges, second derivative
+    f.apply_batch(xb, yb, ch, length, in_ld=ld, out_ld=ld, dtype="f64")
+    torch.cuda.synchronize()
+    o = sgo.Filter(n, 4, 2, 1.0, 3)
+    for c in (1, 2):
+        for mid in ((1 << 29) + n, (1 << 30) + n + 3, length - 3000):
+            lo, hi = mid - 1500 - n, min(mid + 1500 + n, length)
+            ref = o.apply_f64(xb[c, lo:hi].cpu().numpy()[None])[0][n:-n]
+            assert normwise(yb[c, lo + n:hi - n].cpu().numpy(), ref) < 1e-12, (c, mid)
+        for sl, keep in ((slice(0, 4096), slice(0, 4096 - n)), (slice(length - 4096, length), slice(n, 4096))):
+            ref = o.apply_f64(xb[c, sl].cpu().numpy()[None])[0]
+            assert normwise(yb[c, sl].cpu().numpy()[keep], ref[keep]) < 1e-12
+        assert torch.count_nonzero(yb[c, length:]).item() == 0      # the pad between rows is not written
+    del xb, yb
+    torch.cuda.empty_cache()
+
+
+def test_host_pointer_call_on_a_signal_longer_than_one_launch(sg, sgo, torch_gpu):
+    """savgol_apply / savgol_apply_valid on 2^30 + 12345 host samples (the reference takes a size_t length): bit-identical to the
+    oracle on windows across the segment boundaries and at both ends."""
+    import psutil
+    length, n = (1 << 30) + 12345, 5
+    if psutil.virtual_memory().available < 3 * length * 4 + (8 << 30):
+        pytest.skip("not enough host memory")
+    x = np.empty(length, np.float32)
+    blk = 1 << 24
+    rng = np.random.default_rng(7)
+    for a in range(0, length, blk):                                  # cheap deterministic fill, block by block
+        b = min(a + blk, length)
+        x[a:b] = np.sin(np.arange(a, b, dtype=np.float64) * 1e-3).astype(np.float32) + rng.random(b - a, np.float32) * 0.1
+    y = np.zeros_like(x)
+    f = sg.Filter(n, 3, 0, 1.0, 0)
+    f.apply(x, out=y)
+    o = sgo.Filter(n, 3, 0, 1.0, 0)
+    for c in (3000, (1 << 29) + n, (1 << 30) - 3, length - 3000):
+        lo, hi = c - 2000 - n, c + 2000 + n
+        ref = o.apply(x[lo:hi])[n:-n]
+        assert np.array_equal(y[lo + n:hi - n].view(np.uint32), ref.view(np.uint32)), c
+    for sl, keep in ((slice(0, 4096), slice(0, 4096 - n)), (slice(length - 4096, length), slice(n, 4096))):
+        ref = o.apply(x[sl])
+        assert np.array_equal(y[sl][keep].view(np.uint32), ref[keep].view(np.uint32))
+    v = f.apply_valid(x)
+    assert v.size == length - 2 * n
+    for c in (0, (1 << 29) - 7, length - 2 * n - 5000):
+        assert np.array_equal(v[c:c + 5000], y[c + n:c + n + 5000])
