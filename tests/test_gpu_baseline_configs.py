@@ -284,3 +284,37 @@ def test_host_pointer_call_on_a_signal_longer_than_one_launch(sg, sgo, torch_gpu
     assert v.size == length - 2 * n
     for c in (0, (1 << 29) - 7, length - 2 * n - 5000):
         assert np.array_equal(v[c:c + 5000], y[c + n:c + n + 5000])
+
+
+def test_one_frame_with_more_than_2_pow_31_pixels(sg, sgo, torch_gpu):
+    """Maximum sizes in 2-D: one 47000 x 46500 frame on a 46504 pitch (2.19e9 pixels, pixel offsets past 2^31, byte offsets past 2^33),
+    REFLECT border, both the bit-exact dense kernel and the separable one, checked on crops at the corners and deep inside."""
+    torch = torch_gpu
+    rows, cols, stride, n = 47000, 46500, 46504, 5
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3 * rows * stride * 4 + (4 << 30):
+        pytest.skip("not enough HBM free")
+    x = torch.empty((rows, stride), dtype=torch.float32, device="cuda")
+    sg.synth(x)
+    f = sg.Filter2D(n, n, 3)
+    o = sgo.Filter2D(n, n, 3)
+    crops = [(0, 0), (0, cols - 150), (rows - 150, 0), (rows - 150, cols - 150), (46180, 46200), (23000, 40000), (46700, 7)]
+    for method in (1, 2):
+        out = torch.full_like(x, -2.0)
+        f.apply_batch(x, out, rows, cols, 1, boundary=2, method=method, in_stride=stride, out_stride=stride)
+        torch.cuda.synchronize()
+        for (r0, c0) in crops:
+            ra, rb = max(r0 - n, 0), min(r0 + 150 + n, rows)
+            ca, cb = max(c0 - n, 0), min(c0 + 150 + n, cols)
+            sub = np.ascontiguousarray(x[ra:rb, ca:cb].cpu().numpy())
+            t = 0 if ra == 0 else n; l = 0 if ca == 0 else n
+            bt = sub.shape[0] - (0 if rb == rows else n); rt = sub.shape[1] - (0 if cb == cols else n)
+            got = out[ra + t:ra + bt, ca + l:ca + rt].cpu().numpy()
+            if method == 1:
+                assert np.array_equal(got, o.apply(sub, sub.shape[1], 2)[t:bt, l:rt]), (method, r0, c0)
+            else:
+                assert normwise(got, o.apply_f64acc(sub, sub.shape[1], 2)[t:bt, l:rt]) < 1e-6, (method, r0, c0)
+        assert torch.all(out[:, cols:] == -2.0)                     # the pitch padding is not written
+        del out
+    del x
+    torch.cuda.empty_cache()
