@@ -17,6 +17,7 @@ ap.add_argument("--length", type=int, default=1 << 20)
 ap.add_argument("--rounds", type=int, default=12)
 ap.add_argument("--f64", action="store_true", help="savgol_apply_batch_f64 on float64 data")
 ap.add_argument("--deriv", type=int, default=0)
+ap.add_argument("--zeros", action="store_true", help="all-zero input (data-dependent power)")
 a = ap.parse_args()
 
 
@@ -24,7 +25,7 @@ class Cfg(C.Structure):
     _fields_ = [("half_window", C.c_uint8), ("poly_order", C.c_uint8), ("derivative", C.c_uint8), ("time_step", C.c_float), ("boundary", C.c_int)]
 
 
-x = torch.randn((a.channels, a.length), dtype=torch.float64 if a.f64 else torch.float32, device="cuda")
+x = (torch.zeros if a.zeros else torch.randn)((a.channels, a.length), dtype=torch.float64 if a.f64 else torch.float32, device="cuda")
 y = torch.empty_like(x)
 st = torch.cuda.current_stream().cuda_stream
 libs = []
