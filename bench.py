@@ -348,6 +348,10 @@ def bench_image(sg, a):
         pix = Nimg * size * size
         res[name] = {"ms": round(ms, 3), "Mpix_per_s": round(pix / ms / 1e3, 1),
                      "roofline": roofline(8.0 * pix, ms, algorithmic_bytes_per_pixel=8)}
+        if a.method == 2:                                # the rolling kernel's committed counter passes, if taken on these sources
+            traffic, src = pmc_traffic(8.0 * pix, "r*_2d_config4_pmc_summary.json", SOURCES_2D)
+            res[name]["roofline"]["traffic"] = traffic
+            res[name]["roofline"]["traffic_source"] = src
     out = {"workload": f"BASELINE config 4{'' if Nimg == 512 and size == 4096 else ' (subset)'}: {Nimg} images x {size}x{size} fp32, n=7, order 3, "
                        f"method {a.method} ({'dense, bit-identical' if a.method == 1 else 'exact low-rank row+column passes'})",
            "modes": res}
@@ -422,23 +426,26 @@ def bench_config5_slice(sg, a, rank=0, dev=None, steps=2):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def kernel_source_sha():
+def kernel_source_sha(files=None):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from pmc_summary import kernel_source_sha as sha
-    return sha()
+    return sha(files)
 
 
-def pmc_traffic(alg_bytes):
+SOURCES_2D = ["sg_2d_roll.hip", "sg_2d.hpp", "sg_2d.hip"]            # what profiles/r*_2d_config4_pmc_summary.json is stamped with
+
+
+def pmc_traffic(alg_bytes, pattern="r*_1d_f32_n32_pmc_summary.json", files=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x2
     for gfx950 + WRITE_SIZE, separate passes: profiles/*_pmc_summary.json, written by tools/pmc_summary.py).  bench.py cannot
     collect counters itself, so it reports a committed summary ONLY when that summary was taken on the kernel sources
     this run is built from (sha256 of csrc/sg_k1d*, sg_pk.hpp and sg_api_1d.cpp, recorded in the summary) -- otherwise null."""
     import glob
     try:
-        cur = kernel_source_sha()
+        cur = kernel_source_sha(files)
     except Exception:
         return None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_1d_f32_n32_pmc_summary.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
@@ -625,6 +632,8 @@ def main():
                    "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": "f32", "config": cfg,
                    "roofline": roofline(8.0 * per_launch_pix, ms, kernel="sg2d_rolling_kernel<7,2>" if args.method == 2 else "sg2d_dense_roll_kernel<7>",
                                         launches_timed=len(events))}
+            if args.method == 2 and not args.rowband:
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(8.0 * per_launch_pix, "r*_2d_config4_pmc_summary.json", SOURCES_2D)
             if world == 1 and not args.no_cpu:
                 out["cpu_baseline"] = cpu_reference("image")
             print(json.dumps(out), flush=True)
