@@ -177,7 +177,8 @@ int    savgol_streambank_load(SavgolStreamBank *bank, const void *host_blob, voi
  * `images` frames, image k at base + k*image_pitch (elements), row pitch in elements.
  * Arithmetic of savgol2d_apply / savgol2d_apply_valid (src/savgol2d.c:356-456).
  * method: 0 = auto, 1 = direct dense window (bit-identical to the reference), 2 = exact low-rank
- * separable passes (rolling-window kernel for half windows <= 8, tile kernel above), 3 = the
+ * separable passes (rolling-window kernel for every half window up to the rank it is built for -- 4 terms
+ * to n = 8, 3 to n = 12, 2 to n = 16 -- the tile kernel otherwise), 3 = the
  * separable tile kernel for any half window (diagnostic).                                      */
 int savgol2d_apply_batch_f32(const Savgol2DFilter *filter,
                              const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,

@@ -61,7 +61,7 @@ inline unsigned choose_bands(int rows, unsigned long long images_x_strips, unsig
     return best;
 }
 
-// sg_2d_roll.hip: rolling-window kernel, half windows 1..12.  The file is compiled once per
+// sg_2d_roll.hip: rolling-window kernel, half windows 1..16.  The file is compiled once per
 // half-window group (SEP_ROLL_MIN_N..SEP_ROLL_MAX_N under the name SEP_ROLL_FN, see the Makefile) so the groups
 // build in parallel; each returns 0 = launched, 1 = not covered (other group, or the caller uses the tile kernel).
 int sg2d_launch_rolling_g0(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
@@ -69,6 +69,8 @@ int sg2d_launch_rolling_g1(int n, int terms, const Job2D &job, const float *fact
 int sg2d_launch_rolling_g2(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
 int sg2d_launch_rolling_g3(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
 int sg2d_launch_rolling_g4(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling_g5(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling_g6(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
 inline int sg2d_launch_rolling(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count,
                                hipStream_t st)
 {
@@ -76,7 +78,9 @@ inline int sg2d_launch_rolling(int n, int terms, const Job2D &job, const float *
     if (sg2d_launch_rolling_g1(n, terms, job, factors, scale, images, cu_count, st) == 0) return 0;
     if (sg2d_launch_rolling_g2(n, terms, job, factors, scale, images, cu_count, st) == 0) return 0;
     if (sg2d_launch_rolling_g3(n, terms, job, factors, scale, images, cu_count, st) == 0) return 0;
-    return sg2d_launch_rolling_g4(n, terms, job, factors, scale, images, cu_count, st);
+    if (sg2d_launch_rolling_g4(n, terms, job, factors, scale, images, cu_count, st) == 0) return 0;
+    if (sg2d_launch_rolling_g5(n, terms, job, factors, scale, images, cu_count, st) == 0) return 0;
+    return sg2d_launch_rolling_g6(n, terms, job, factors, scale, images, cu_count, st);
 }
 
 // two output frames (job.out, out1) from one walk over the input; both outputs have `terms` (<= 3) terms
@@ -85,6 +89,8 @@ int sg2d_launch_rolling2_g1(int n, int terms, const Job2D &job, const float *f0,
 int sg2d_launch_rolling2_g2(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1, unsigned images, int cu_count, hipStream_t st);
 int sg2d_launch_rolling2_g3(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1, unsigned images, int cu_count, hipStream_t st);
 int sg2d_launch_rolling2_g4(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling2_g5(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling2_g6(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1, unsigned images, int cu_count, hipStream_t st);
 inline int sg2d_launch_rolling2(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, float *out1,
                                 unsigned images, int cu_count, hipStream_t st)
 {
@@ -92,7 +98,9 @@ inline int sg2d_launch_rolling2(int n, int terms, const Job2D &job, const float 
     if (sg2d_launch_rolling2_g1(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st) == 0) return 0;
     if (sg2d_launch_rolling2_g2(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st) == 0) return 0;
     if (sg2d_launch_rolling2_g3(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st) == 0) return 0;
-    return sg2d_launch_rolling2_g4(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
+    if (sg2d_launch_rolling2_g4(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st) == 0) return 0;
+    if (sg2d_launch_rolling2_g5(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st) == 0) return 0;
+    return sg2d_launch_rolling2_g6(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
 }
 
 // sg_2d_dense.hip: the bit-exact dense kernel on packed math, square windows with half window <= DENSE_ROLL_MAX_N.

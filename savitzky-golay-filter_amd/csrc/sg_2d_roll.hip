@@ -1,4 +1,4 @@
-// sg_2d_roll.hip -- the 2-D fast path for half windows <= 12: rolling column windows in registers.
+// sg_2d_roll.hip -- the 2-D fast path for every half window (1..16): rolling column windows in registers.
 //
 // Same exact low-rank factorisation as sg_2d_sep.hip,  W(x,y) = sum_t G_t(y) Q_t(x)  (reference kernel:
 // src/savgol2d.c:188-265), applied vertical pass first:
@@ -198,11 +198,13 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     // pass's 14 + 16 NT independent multiply-adds.  (Issued after it, as the first version did, every row had the wave stall
     // on lgkmcnt three to four times with nothing to do.)
     constexpr int UNITS = NOUT * NT;
-    f32x4 hq[2][R::NQ];
+    // (n = 15, 16: one buffer and the reads right before their use -- a second 36-register window does not fit beside the row ring)
+    constexpr int NB = N >= 15 ? 1 : 2;
+    f32x4 hq[NB][R::NQ];
     auto fetch = [&](auto uc, int par) {
         constexpr int u = decltype(uc)::value, o = u / NT, t = u % NT;
 #pragma unroll
-        for (int q = 0; q < R::NQ; ++q) hq[u & 1][q] = *reinterpret_cast<const f32x4 *>(rd + ((par * NOUT + o) * NT + t) * R::BUFW + 4 * q);
+        for (int q = 0; q < R::NQ; ++q) hq[u & (NB - 1)][q] = *reinterpret_cast<const f32x4 *>(rd + ((par * NOUT + o) * NT + t) * R::BUFW + 4 * q);
     };
     // one unit's arithmetic on its fetched window, accumulated into r (the first term of an output starts it)
     auto hterm = [&](auto uc, f32x2 (&r)[2]) {
@@ -210,8 +212,8 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
         f32x2 e[2 * R::NQ + 1];
 #pragma unroll
         for (int q = 0; q < R::NQ; ++q) {
-            e[2 * q] = f32x2{hq[u & 1][q].x, hq[u & 1][q].y};
-            e[2 * q + 1] = f32x2{hq[u & 1][q].z, hq[u & 1][q].w};
+            e[2 * q] = f32x2{hq[u & (NB - 1)][q].x, hq[u & (NB - 1)][q].y};
+            e[2 * q + 1] = f32x2{hq[u & (NB - 1)][q].z, hq[u & (NB - 1)][q].w};
         }
         f32x2 pr[2 * N + 3];                                 // pr[j] = window floats (D+j, D+j+1)
 #pragma unroll
@@ -273,7 +275,8 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
         f32x2 r[2];
         static_for<UNITS>([&](auto uc) -> bool {
             constexpr int u = decltype(uc)::value;
-            if constexpr (u + 1 < UNITS) fetch(std::integral_constant<int, u + 1>{}, par);
+            if constexpr (NB == 1) fetch(uc, par);
+            else if constexpr (u + 1 < UNITS) fetch(std::integral_constant<int, u + 1>{}, par);
             // the row's last reads are issued: order them before the next iteration's writes into the same LDS row.  Without a
             // branch between the iterations the compiler is free to hoist a lane's next write above reads of OTHER columns that it
             // can prove distinct for that lane -- which are exactly the words its neighbours are about to read
@@ -301,7 +304,7 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             if constexpr (!R::STRAIGHT) { if (m > nout) return false; }     // uniform; iteration m = nout still stores row nout-1
             win[uu] = load_row(m + R::U - 1);                // slot of row m-1, which no later row needs
             wave_lds_sync();                                 // row m-1's vertical results (previous iteration) are written ...
-            fetch(std::integral_constant<int, 0>{}, uu & 1); // ... and its first window is on its way while row m's vertical pass runs
+            if constexpr (NB == 2) fetch(std::integral_constant<int, 0>{}, uu & 1);     // ... and its first window is on its way while row m's vertical pass runs
             __builtin_amdgcn_sched_barrier(0);
             vertical(std::integral_constant<int, (uu + 1) % R::U>{}, (uu + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -312,8 +315,8 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 }
 
 // terms per output the rolling kernel is built for: the taps live in SGPRs (2 * NT * NOUT * (N/2 + 1) pairs), which caps the
-// wide windows at 3 terms (1 when two outputs share the walk); everything else runs the tile kernel of sg_2d_sep.hip
-constexpr int roll_max_terms(int n, int nout) { return nout == 1 ? (n <= 8 ? SEP_MAX_TERMS : 3) : (n <= 8 ? 3 : 1); }
+// windows 9..12 at 3 terms and 13..16 at 2 (1 when two outputs share the walk); everything else runs the tile kernel of sg_2d_sep.hip
+constexpr int roll_max_terms(int n, int nout) { return nout == 1 ? (n <= 8 ? SEP_MAX_TERMS : (n <= 12 ? 3 : 2)) : (n <= 8 ? 3 : 1); }
 // waves per SIMD the register allocation must allow: the row ring alone is (2N+2) x 4 VGPRs
 // (n = 7 and n = 8 with three rows in flight and the two-output form at n = 6, rank 2, spill at 4 waves per SIMD: 300 / 20-108 / 12
 // bytes of scratch; tools/roll_resources.py lists every instantiation)

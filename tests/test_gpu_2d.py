@@ -181,10 +181,11 @@ def test_dense_packed_kernel_bit_exact_every_half_window(sg, sgo, torch_gpu, n):
                     assert same_bits(g[k], want), (n, rows, cols, order, dx, dy, b, k)
 
 
-@pytest.mark.parametrize("n", range(1, 9))
+@pytest.mark.parametrize("n", range(1, 17))
 def test_rolling_window_kernel_all_half_windows(sg, sgo, torch_gpu, n):
-    """The n <= 8 fast path (sg_2d_roll.hip): 16-byte aligned frames wide and tall enough for interior strips, several
-    row bands and both frame-edge strips; every rank 1..4 (orders 2..6 x derivative pairs); all boundary modes.
+    """The rolling-window path (sg_2d_roll.hip, every half window 1..16): 16-byte aligned frames wide and tall enough for interior
+    strips, several row bands and both frame-edge strips; every rank 1..4 (orders 2..6 x derivative pairs; ranks the wide windows do
+    not build fall through to the tile kernel); all boundary modes.
     Against the double-accumulation oracle, and against the tile kernel (method 3) that shares its factors."""
     torch = torch_gpu
     rng = np.random.default_rng(100 + n)
@@ -216,7 +217,14 @@ def test_rolling_window_kernel_all_half_windows(sg, sgo, torch_gpu, n):
                 else:
                     sel[:, :cols] = True
                 assert np.all(g[1][~sel] == -5.0)
-                assert normwise(g[1][sel], hi[sel]) < tol, (n, order, dx, dy, b, normwise(g[1][sel], hi[sel]))
+                err = normwise(g[1][sel], hi[sel])
+                bar = tol
+                if n > 8 and err >= tol:
+                    # wide windows x high orders cancel harder: the reference's own fp32 sum is 7e-6 ... 1.2e-5 from the double
+                    # oracle at n = 13..16, order 6, d = (0,2) (tools/diag_2d_accuracy.py); the bar there is "closer than the reference"
+                    ref32 = o.apply(x[1], cols, b if b else 1)
+                    bar = max(tol, 0.75 * normwise(ref32[sel], hi[sel]))
+                assert err < bar, (n, order, dx, dy, b, err, bar)
 
 
 def test_rolling_window_kernel_small_and_odd_frames(sg, sgo, torch_gpu):
@@ -224,7 +232,8 @@ def test_rolling_window_kernel_small_and_odd_frames(sg, sgo, torch_gpu):
     torch = torch_gpu
     rng = np.random.default_rng(77)
     for (n, rows, cols, stride, off) in [(7, 5, 9, 9, 0), (7, 1, 40, 41, 1), (3, 33, 1, 3, 0), (8, 17, 300, 301, 3), (5, 11, 11, 12, 0),
-                                         (7, 40, 263, 264, 0), (2, 700, 20, 20, 0)]:
+                                         (7, 40, 263, 264, 0), (2, 700, 20, 20, 0), (12, 9, 300, 300, 0), (16, 40, 21, 24, 0), (14, 1, 500, 501, 1),
+                                         (16, 300, 263, 264, 0)]:
         flat = np.zeros(rows * stride + 8, np.float32)
         img = flat[off:off + rows * stride].reshape(rows, stride)
         img[:, :cols] = rng.normal(0, 1, (rows, cols)).astype(np.float32)
