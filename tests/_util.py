@@ -16,3 +16,10 @@ def same_bits(a, b):
     """fp32 arrays equal bit for bit (so -0.0 != +0.0 and NaN payloads count), shapes included"""
     a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
     return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def fuzz(seed, iters):
+    """(seed, iterations) of a randomized test: the committed defaults, or a soak run's override --
+    SAVGOL_FUZZ_SEED shifts every seed, SAVGOL_FUZZ_SCALE multiplies every iteration count (tools/soak_gpu.sh)."""
+    import os
+    return seed + int(os.environ.get("SAVGOL_FUZZ_SEED", "0")), int(iters * float(os.environ.get("SAVGOL_FUZZ_SCALE", "1")))
