@@ -343,7 +343,8 @@ __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *mine = lds + wv * (2 * NOUT * NT * R::BUFW);      // two LDS rows per output and term, private to this wave
 
-    // persistent waves; blocks that share an XCD (blockIdx % 8) take neighbouring items (halo columns meet in L2)
+    // one item per wave by default (the loop runs once), or persistent waves striding over the items; blocks that share an XCD
+    // (blockIdx % 8) take neighbouring items (halo columns meet in L2)
     const unsigned nblk = gridDim.x;
     const unsigned blk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
     constexpr unsigned WPB = (unsigned)roll_wpb(N);
@@ -442,8 +443,12 @@ static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], co
     const int band_rows = (int)((job.rows + (int)bands - 1) / (int)bands);
     bands = (unsigned)((job.rows + band_rows - 1) / band_rows);
     const unsigned long long total = (unsigned long long)images * strips * bands;     // caller keeps this < 2^32
-    unsigned grid = (unsigned)cu_count * (unsigned)per_cu;
-    if (env_one && atoi(env_one)) grid = (unsigned)((total + WPB - 1) / WPB);
+    // One item per wave, blocks handed out by the hardware dispatcher in order -- as in the 1-D kernel, and for the same reason: the
+    // same items and bands on a persistent grid (resident waves striding over the items) are 1-5 % slower at every half window
+    // (n = 4: 1.89 vs 1.79 ms per 64 frames).  SAVGOL_HIP_ROLL_ONEWAVE=0 brings the persistent grid back for A/B runs; the band
+    // count is still chosen for whole rounds of the resident waves, which is also what keeps the tail of the dispatch short.
+    const bool persistent = env_one && atoi(env_one) == 0;
+    unsigned grid = persistent ? (unsigned)cu_count * (unsigned)per_cu : (unsigned)((total + WPB - 1) / WPB);
     if ((unsigned long long)grid * WPB > total) grid = (unsigned)((total + WPB - 1) / WPB);
     grid = (grid + 7u) & ~7u;
     int aligned = 0;
