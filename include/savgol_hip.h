@@ -188,9 +188,10 @@ int savgol2d_apply_batch_f32(const Savgol2DFilter *filter,
 /* Derivative frames (arithmetic of savgol2d_gradient / _hessian / _laplacian, src/savgol2d.c:462-618).  The Laplacian
  * uses the single summed kernel (scale_xx*Wxx + scale_yy*Wyy): no temporary frame, no add pass.  Outputs may be NULL
  * (skipped), like the reference.  Square windows use the separable kernels (fp32 rounding only vs the reference):
- * three Hessian frames, and any call with a half window above 8, come from ONE read of each input tile; one or two
- * frames with a half window <= 8 are one rolling-window launch each (faster).  Other window shapes:
- * one dense pass per output.                                                                                      */
+ * three Hessian frames, and frames whose rank the rolling-window kernel is not built for at that half window, come from
+ * ONE read of each input tile (tile kernel); one or two frames otherwise are rolling-window launches (the gradient of
+ * a half window <= 8: one launch for both frames; faster).  Other window shapes: one dense pass per
+ * output.                                                                                                           */
 int savgol2d_gradient_batch_f32(int half_win_x, int half_win_y, int poly_order,
                                 const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,
                                 float *d_grad_x, float *d_grad_y, int out_stride, size_t out_image_pitch,
