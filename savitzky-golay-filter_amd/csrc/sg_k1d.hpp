@@ -117,7 +117,7 @@ struct K1D {
     static constexpr int MIN_WAVES = sizeof(T) == 8 ? 3 : (VPL <= 4 ? 7 : VPL <= 6 ? 5 : 4);
     static_assert(2 * HV <= 64, "halo must fit one extra vector per lane");
     static_assert(WQ <= SV - VPL * 63, "lane 63's window must stay inside the slab");
-    static_assert(VPL == 4 || VPL == 6 || VPL == 8, "lane stride (VPL+1)*16 B must be conflict free for ds_read_b128");
+    static_assert(VPL == 4 || VPL == 6 || VPL == 8 || VPL == 12 || VPL == 16, "lane stride (VPL+1)*16 B must be conflict free for ds_read_b128");
 };
 
 // byte offset of slab vector v: one 16-B pad after every VPL vectors, so a lane's VPL vectors are contiguous and

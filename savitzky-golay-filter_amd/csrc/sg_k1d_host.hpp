@@ -13,17 +13,27 @@ namespace sg {
 struct alignas(8) Taps { union { float w[SAVGOL_MAX_WINDOW + 1]; double wd[(SAVGOL_MAX_WINDOW + 1) / 2]; }; };
 
 // 16-byte vectors of output each lane owns (tile = 64 lanes x VPL vectors of one channel).  Host and kernels must
-// agree.  The kernel supports 4, 6 and 8 (lane strides of 20 / 28 / 36 banks are all conflict free); 8 -> 8 KiB
-// tiles, 9.5 KB of LDS per wave, 4 waves per SIMD.  Smaller tiles buy occupancy (6 -> 5 waves/SIMD, 4 -> 7) but
-// A/B runs in one process (tools/ab_1d.py, n = 24/28/32) have 8 ahead by 1 % over 6 and 3-7 % over 4: the wide
-// windows are limited by VALU issue at the clock the chip sustains, not by latency hiding.
+// agree.  The kernel supports 4, 6, 8, 12 and 16 (lane strides of VPL+1 vectors are conflict free for ds_read_b128);
+// 8 -> 8 KiB tiles, 9.5 KB of LDS per wave, 4 waves per SIMD; 16 -> 16 KiB tiles, 2 waves per SIMD.
+// A/B runs in one process (tools/ab_1d.py, 32 GiB of traffic per launch):
+//   fp32, n >= 24 (block moments, laid out for 32 outputs per lane): 8.
+//   fp32, direct kernels: 4 / 6 / 8 within 0.5 % of each other; 16 is 2.5-5 % ahead for n <= 12 (n = 2: 5.81 -> 5.52 ms,
+//   n = 12: 5.77 -> 5.60), level at n = 16 and 5 % behind at n = 23 (64 accumulators and the window no longer fit) -> 16 up to 12.
+//   fp64: 16 is 2-5 % ahead up to n = 24 (n = 20: 5.82 -> 5.49 ms = 6.26 TB/s), 8 is 5 % ahead at n = 28 and 2.5 % at n = 32 -> 16 up to 24.
+// Bigger tiles mean fewer halo re-reads and fewer, longer waves; what they cost is registers.
 #ifndef SG_VPL_F32_WIDE
 #define SG_VPL_F32_WIDE 8          /* fp32, half_window >= 24; A/B builds override this */
 #endif
-#ifndef SG_VPL_NARROW
-#define SG_VPL_NARROW 8            /* every other kernel; A/B builds override this */
+constexpr int vectors_per_lane(size_t elem_size, int half_window)
+{
+#ifdef SG_VPL_F64
+    if (elem_size == 8) return SG_VPL_F64;                              /* A/B builds */
 #endif
-constexpr int vectors_per_lane(size_t elem_size, int half_window) { return (elem_size == 4 && half_window >= 24) ? SG_VPL_F32_WIDE : SG_VPL_NARROW; }
+#ifdef SG_VPL_NARROW
+    if (elem_size == 4 && half_window < 24) return SG_VPL_NARROW;       /* A/B builds */
+#endif
+    return elem_size == 8 ? (half_window <= 24 ? 16 : 8) : (half_window >= 24 ? SG_VPL_F32_WIDE : (half_window <= 12 ? 16 : 8));
+}
 
 struct Job1D {
     const void *in;
