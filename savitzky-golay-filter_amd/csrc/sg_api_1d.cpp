@@ -178,7 +178,11 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     }
 
     constexpr int E = 16 / (int)sizeof(T);
-    const int vpl = sg::vectors_per_lane(sizeof(T), f->config.half_window);
+    // tile width: the wide tile where one is built and the batch is big enough to keep the chip in whole rounds of them
+    int vpl = sg::vectors_per_lane(sizeof(T), f->config.half_window);
+    const int vpl_wide = sg::wide_vectors_per_lane(sizeof(T), f->config.half_window);
+    const int wide = vpl_wide != vpl && (unsigned long long)channels * ((length + 64u * vpl_wide * E - 1) / (64u * vpl_wide * E)) >= sg::WIDE_TILE_MIN_TILES;
+    if (wide) vpl = vpl_wide;
     const unsigned TW = 64u * (unsigned)vpl * E;
     const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
     const bool poly = (mode == SAVGOL_BOUNDARY_POLYNOMIAL);
@@ -258,7 +262,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
                          : moment_terms == 5 ? sg1d_launch_f32_moment_t5(n, &job, d_moment, blocks, st)
                                              : sg1d_launch_f32_moment_t7(n, &job, d_moment, blocks, st);
             if (rc != 0) return -1;
-        } else if (sg::launch_center<T>(n, job, taps, blocks, st) != 0) return -1;
+        } else if (sg::launch_center<T>(n, wide, job, taps, blocks, st) != 0) return -1;
     }
     if (d_edges) {
         // bit 0: multiply by dt_inv; bit 1: negate the leading-edge outputs (SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE, odd d only)

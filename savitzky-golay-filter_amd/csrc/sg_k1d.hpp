@@ -96,11 +96,11 @@ __device__ __forceinline__ int remap_index(int i, int L, int mode, bool &zero)
     return i;
 }
 
-template <typename T, int N>
+template <typename T, int N, int V = vectors_per_lane(sizeof(T), N)>
 struct K1D {
     typedef typename V16<T>::type VT;
     static constexpr int E    = V16<T>::E;
-    static constexpr int VPL  = vectors_per_lane(sizeof(T), N); // 16-B vectors of output per lane (sg_k1d_host.hpp)
+    static constexpr int VPL  = V;                           // 16-B vectors of output per lane (sg_k1d_host.hpp: narrow / wide tiles)
     static constexpr int R    = VPL * E;                     // outputs per lane
     static constexpr int TV   = 64 * VPL;                    // vectors of output per tile
     static constexpr int TW   = 64 * R;                      // outputs per tile
@@ -129,9 +129,9 @@ template <int VPL> __device__ __forceinline__ constexpr int slab_vec_off(int v) 
 // The inner product, "input stationary": walk the lane's window once, feed every input into all
 // the accumulators it touches.  acc[r] = sum_k w[k] * x[r + k + OFF], k ascending, one FMA chain.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int N>
-struct Conv {                      // generic form (used for fp64): one v_fma per tap per output
-    typedef K1D<T, N> K;
+template <typename T, int N, int V>
+struct Conv {                      // generic form: one v_fma per tap per output
+    typedef K1D<T, N, V> K;
     typedef typename K::VT VT;
     static __device__ __forceinline__ void run(const char *win, const Taps &taps, T (&acc)[K::R])
     {
@@ -160,9 +160,9 @@ struct Conv {                      // generic form (used for fp64): one v_fma pe
 // i = 2j + k + OFF.  The tap is broadcast out of an aligned SGPR pair with op_sel, so the 65 taps still
 // occupy 66 SGPRs; pairs that start at an odd i are assembled with one v_pk_mov_b32 each and then
 // shared by up to 16 accumulator pairs (sg_pk.hpp has the instructions).
-template <int N>
-struct Conv<float, N> {
-    typedef K1D<float, N> K;
+template <int N, int V>
+struct Conv<float, N, V> {
+    typedef K1D<float, N, V> K;
     // all accumulator pairs fed by the input pair that starts at window index I
     template <int I, int J = 0>
     static __device__ __forceinline__ void feed(f32x2 (&A)[K::R / 2], const f32x2 (&W)[33], const f32x2 x)
@@ -205,9 +205,9 @@ struct Conv<float, N> {
 // bit for bit (tap[2N-k] = +-tap[k]: only Gram terms of the derivative's parity are non-zero at t = 0), so the host
 // passes taps 0..N as doubles (33 SGPR pairs at N = 32, exact promotions of the fp32 table) and the kernel applies the
 // mirrored half through the sign of the input.  No conversion and no tap in a VGPR inside the loop.
-template <int N>
-struct Conv<double, N> {
-    typedef K1D<double, N> K;
+template <int N, int V>
+struct Conv<double, N, V> {
+    typedef K1D<double, N, V> K;
     // taps 0..N as doubles in SGPR pairs (33 x 2 SGPRs at N = 32); tap 2N-k = +-tap k is applied by flipping the
     // sign of the input instead (xs = +-x, one v_xor_b32 per input), so v_fmac_f64 takes the tap straight from SGPRs
     template <int I, int Rr = 0>
@@ -251,7 +251,7 @@ struct Conv<double, N> {
 template <typename T, int N, typename CV>
 __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename CV::Args &taps)
 {
-    typedef K1D<T, N> K;
+    typedef typename CV::K K;                                // tile geometry of the convolution policy (narrow or wide tiles)
     typedef typename K::VT VT;
     constexpr int E = K::E, R = K::R, TW = K::TW, NA = K::NA, HV = K::HV, VPL = K::VPL, TV = K::TV;
 
@@ -378,20 +378,22 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
 }
 
 // the plain sliding dot product: every output is 2N+1 multiply-adds (Conv<T, N> above)
-template <typename T, int N>
+template <typename T, int N, int V>
 struct DirectConv {
     typedef Taps Args;
-    static __device__ __forceinline__ void run(const char *win, const Taps &taps, T (&acc)[K1D<T, N>::R], unsigned flags)
+    typedef K1D<T, N, V> K;
+    static __device__ __forceinline__ void run(const char *win, const Taps &taps, T (&acc)[K::R], unsigned flags)
     {
-        if constexpr (sizeof(T) == 8) Conv<T, N>::run(win, taps, acc, (flags & JOB_ODD_TAPS) ? 0x80000000u : 0u);
-        else Conv<T, N>::run(win, taps, acc);
+        if constexpr (sizeof(T) == 8) Conv<T, N, V>::run(win, taps, acc, (flags & JOB_ODD_TAPS) ? 0x80000000u : 0u);
+        else Conv<T, N, V>::run(win, taps, acc);
     }
 };
 
-template <typename T, int N>
-__global__ __launch_bounds__(256, (K1D<T, N>::MIN_WAVES)) void sg1d_center_kernel(const Job1D job, const Taps taps)
+// V = vectors per lane: the narrow tile every job can use, or the wide one the host picks for big batches (sg_k1d_host.hpp)
+template <typename T, int N, int V>
+__global__ __launch_bounds__(256, (K1D<T, N, V>::MIN_WAVES)) void sg1d_center_kernel(const Job1D job, const Taps taps)
 {
-    sg1d_tile_body<T, N, DirectConv<T, N>>(job, taps);
+    sg1d_tile_body<T, N, DirectConv<T, N, V>>(job, taps);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -15,25 +15,35 @@ struct alignas(8) Taps { union { float w[SAVGOL_MAX_WINDOW + 1]; double wd[(SAVG
 // 16-byte vectors of output each lane owns (tile = 64 lanes x VPL vectors of one channel).  Host and kernels must
 // agree.  The kernel supports 4, 6, 8, 12 and 16 (lane strides of VPL+1 vectors are conflict free for ds_read_b128);
 // 8 -> 8 KiB tiles, 9.5 KB of LDS per wave, 4 waves per SIMD; 16 -> 16 KiB tiles, 2 waves per SIMD.
-// A/B runs in one process (tools/ab_1d.py, 32 GiB of traffic per launch):
-//   fp32, n >= 24 (block moments, laid out for 32 outputs per lane): 8.
-//   fp32, direct kernels: 4 / 6 / 8 within 0.5 % of each other; 16 is 2.5-5 % ahead for n <= 12 (n = 2: 5.81 -> 5.52 ms,
-//   n = 12: 5.77 -> 5.60), level at n = 16 and 5 % behind at n = 23 (64 accumulators and the window no longer fit) -> 16 up to 12.
-//   fp64: 16 is 2-5 % ahead up to n = 24 (n = 20: 5.82 -> 5.49 ms = 6.26 TB/s), 8 is 5 % ahead at n = 28 and 2.5 % at n = 32 -> 16 up to 24.
-// Bigger tiles mean fewer halo re-reads and fewer, longer waves; what they cost is registers.
+// Two tile widths are built where they differ, and the host picks per call (enqueue_batch):
+//   narrow (vectors_per_lane): 8 everywhere.  4 / 6 / 8 are within 0.5 % of each other on big batches (tools/ab_1d.py).
+//   wide (wide_vectors_per_lane): 16 for fp32 n <= 12 and fp64 n <= 24 -- 2-5 % faster on big batches (32 GiB per launch,
+//     A/B over eight placements of the buffers, tools/ab_1d_placements.py: fp32 n = 8: 5.76 -> 5.57 ms, fp64 n = 24: 5.81 -> 5.70;
+//     n = 2: 5.81 -> 5.52, fp64 n = 20: 5.82 -> 5.49 in single-placement runs): fewer halo re-reads and fewer, longer waves.
+//     Beyond those half windows the 64 accumulators and the window no longer fit (fp32 n = 23: 5 % slower, fp64 n = 28: 5 %
+//     slower), and on a SMALL job wide tiles are simply fewer waves: one 10^6-sample signal (BASELINE config 1) takes 24.6 us on
+//     245 wide tiles against 17.4 us on 489 narrow ones -- hence the choice by job size.
+//   fp32 n >= 24 (block moments) is laid out for 32 outputs per lane: 8 either way.
 #ifndef SG_VPL_F32_WIDE
 #define SG_VPL_F32_WIDE 8          /* fp32, half_window >= 24; A/B builds override this */
 #endif
+#ifndef SG_VPL_NARROW
+#define SG_VPL_NARROW 8            /* the narrow tile of every other kernel; A/B builds override this */
+#endif
 constexpr int vectors_per_lane(size_t elem_size, int half_window)
 {
-#ifdef SG_VPL_F64
-    if (elem_size == 8) return SG_VPL_F64;                              /* A/B builds */
-#endif
-#ifdef SG_VPL_NARROW
-    if (elem_size == 4 && half_window < 24) return SG_VPL_NARROW;       /* A/B builds */
-#endif
-    return elem_size == 8 ? (half_window <= 24 ? 16 : 8) : (half_window >= 24 ? SG_VPL_F32_WIDE : (half_window <= 12 ? 16 : 8));
+    return (elem_size == 4 && half_window >= 24) ? SG_VPL_F32_WIDE : SG_VPL_NARROW;
 }
+constexpr int wide_vectors_per_lane(size_t elem_size, int half_window)
+{
+#ifdef SG_VPL_NO_WIDE
+    return vectors_per_lane(elem_size, half_window);                    /* A/B builds */
+#else
+    return (elem_size == 8 ? half_window <= 24 : half_window <= 12) ? 16 : vectors_per_lane(elem_size, half_window);
+#endif
+}
+// a job gets the wide tile when it has at least this many of them (8 rounds of the 2048 waves the chip holds at 2 per SIMD)
+constexpr unsigned long long WIDE_TILE_MIN_TILES = 16384;
 
 struct Job1D {
     const void *in;
@@ -94,14 +104,14 @@ enum : unsigned {
 
 extern "C" {
 // one object per (type, half-window group), see the Makefile; each returns 1 if it owns n
-int sg1d_launch_f32_g0(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
-int sg1d_launch_f32_g1(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
-int sg1d_launch_f32_g2(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
-int sg1d_launch_f32_g3(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
-int sg1d_launch_f64_g0(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
-int sg1d_launch_f64_g1(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
-int sg1d_launch_f64_g2(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
-int sg1d_launch_f64_g3(int n, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f32_g0(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f32_g1(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f32_g2(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f32_g3(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f64_g0(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f64_g1(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f64_g2(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_f64_g3(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
 
 // the fp32 kernel for half window n (24..32) with `terms` block moments (3, 5 or 7); one object per term count; returns 0 when enqueued
 int sg1d_launch_f32_moment_t3(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
@@ -130,20 +140,20 @@ int sg_launch_scatter_f32(const float *src, size_t src_ld, void *base, size_t st
 
 namespace sg {
 
-template <typename T> int launch_center(int n, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st);
-template <> inline int launch_center<float>(int n, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st)
+template <typename T> int launch_center(int n, int wide, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st);
+template <> inline int launch_center<float>(int n, int wide, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st)
 {
-    const int hit = sg1d_launch_f32_g0(n, &job, &taps, grid, st) || sg1d_launch_f32_g1(n, &job, &taps, grid, st) ||
-                    sg1d_launch_f32_g2(n, &job, &taps, grid, st) || sg1d_launch_f32_g3(n, &job, &taps, grid, st);
+    const int hit = sg1d_launch_f32_g0(n, wide, &job, &taps, grid, st) || sg1d_launch_f32_g1(n, wide, &job, &taps, grid, st) ||
+                    sg1d_launch_f32_g2(n, wide, &job, &taps, grid, st) || sg1d_launch_f32_g3(n, wide, &job, &taps, grid, st);
     if (!hit) { sg_set_error("no fp32 kernel for half_window %d", n); return -1; }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sg_set_error("1-D kernel launch failed: %s", hipGetErrorString(e)); return -1; }
     return 0;
 }
-template <> inline int launch_center<double>(int n, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st)
+template <> inline int launch_center<double>(int n, int wide, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st)
 {
-    const int hit = sg1d_launch_f64_g0(n, &job, &taps, grid, st) || sg1d_launch_f64_g1(n, &job, &taps, grid, st) ||
-                    sg1d_launch_f64_g2(n, &job, &taps, grid, st) || sg1d_launch_f64_g3(n, &job, &taps, grid, st);
+    const int hit = sg1d_launch_f64_g0(n, wide, &job, &taps, grid, st) || sg1d_launch_f64_g1(n, wide, &job, &taps, grid, st) ||
+                    sg1d_launch_f64_g2(n, wide, &job, &taps, grid, st) || sg1d_launch_f64_g3(n, wide, &job, &taps, grid, st);
     if (!hit) { sg_set_error("no fp64 kernel for half_window %d", n); return -1; }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sg_set_error("1-D kernel launch failed: %s", hipGetErrorString(e)); return -1; }

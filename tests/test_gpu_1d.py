@@ -575,3 +575,35 @@ def test_long_host_signals_with_shifted_overlap_keep_the_serial_path(sg, sgo, to
     buf = base.copy()
     got = sg.lib().savgol_apply_valid(f.ptr, buf[:L].ctypes.data_as(C.POINTER(C.c_float)), L, buf[:L].ctypes.data_as(C.POINTER(C.c_float)))
     assert got == L - 10 and same_bits(buf[:L - 10], wantv)
+
+
+@pytest.mark.parametrize("dtype,n", [("f32", 1), ("f32", 5), ("f32", 12), ("f64", 3), ("f64", 16), ("f64", 24)])
+def test_wide_tile_kernels_on_batches_big_enough_to_select_them(sg, sgo, torch_gpu, dtype, n):
+    """Half windows <= 12 (fp32) / <= 24 (fp64) have a second, 16 KiB-per-wave tile that enqueue_batch picks from 16384 tiles up
+    (sg_k1d_host.hpp): 72 channels of 2^20 + 77 samples on a padded pitch select it.  All four boundary modes and VALID, sampled
+    channels against the oracle; the same call on a batch too small for the wide tile must give the same bits per channel."""
+    torch = torch_gpu
+    tdt, ndt, tol = (torch.float32, np.float32, TOL_F32) if dtype == "f32" else (torch.float64, np.float64, 1e-12)
+    ch, length, ld = 72, (1 << 20) + 77, (1 << 20) + 80
+    x = torch.empty((ch, ld), dtype=tdt, device="cuda")
+    sg.synth(x)
+    y = torch.full((ch, ld), -7.0, dtype=tdt, device="cuda")
+    sample = [0, 35, 71]
+    xs = x[sample, :length].cpu().numpy().astype(np.float64)
+    m = min(4, 2 * n)
+    for mode in range(4):
+        f = sg.Filter(n, m, 0, 1.0, mode)
+        f.apply_batch(x, y, ch, length, in_ld=ld, out_ld=ld, dtype=dtype)
+        torch.cuda.synchronize()
+        ref = sgo.Filter(n, m, 0, 1.0, mode).apply_f64(xs)
+        assert normwise(y[sample, :length].cpu().numpy(), ref) < tol, (mode, normwise(y[sample, :length].cpu().numpy(), ref))
+        assert torch.all(y[:, length:] == -7.0)
+        # two channels alone are a small job -> narrow tiles: same arithmetic per output, so the same bits
+        y2 = torch.full((2, ld), -7.0, dtype=tdt, device="cuda")
+        f.apply_batch(x[34:36], y2, 2, length, in_ld=ld, out_ld=ld, dtype=dtype)
+        assert torch.equal(y2[1, :length], y[35, :length]), mode
+    v = torch.full((ch, ld), -7.0, dtype=tdt, device="cuda")
+    sg.Filter(n, m, 0, 1.0, 0).apply_batch(x, v, ch, length, in_ld=ld, out_ld=ld, dtype=dtype, valid=True)
+    sg.Filter(n, m, 0, 1.0, 0).apply_batch(x, y, ch, length, in_ld=ld, out_ld=ld, dtype=dtype)
+    assert torch.equal(v[:, :length - 2 * n], y[:, n:length - n])
+    assert torch.all(v[:, length - 2 * n:] == -7.0)
