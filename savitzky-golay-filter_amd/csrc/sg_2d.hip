@@ -105,6 +105,48 @@ static int sep_factors_cached(const Savgol2DConfig *cfg, float *factors)
     return e.terms;
 }
 
+// The derivative entry points take a configuration, not a filter object: without these two caches every call repeated the host
+// least-squares solve (75 us at n = 7, 0.4-2.7 ms at n = 16 per gradient / Hessian call: tools/time_2d_host_overhead.py).
+// (a) the summed Laplacian kernel's factors per (n, order, deltas); (b) dense weight tables of rectangular windows per full config.
+struct SummedKey { int n, order; float dx, dy; };
+static int summed_factors_cached(const SummedKey &key, const double *Wsum, float *factors)
+{
+    struct Entry { SummedKey key; int terms; float f[SEP_MAX_TERMS * 2 * (2 * SAVGOL2D_MAX_HALF_WINDOW + 2)]; };
+    static std::mutex mu;
+    static Entry cache[16];
+    static int used = 0, next = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used; ++i)
+        if (memcmp(&cache[i].key, &key, sizeof(key)) == 0) {
+            if (factors) memcpy(factors, cache[i].f, sizeof(cache[i].f));
+            return cache[i].terms;
+        }
+    if (!Wsum) return -1;                                    // lookup only
+    Entry &e = cache[next];
+    next = (next + 1) % 16;
+    if (used < 16) ++used;
+    memset(&e, 0, sizeof(e));
+    e.key = key;
+    e.terms = sg2d_factors_from_kernel(Wsum, key.n, key.order, e.f, SEP_MAX_TERMS);
+    memcpy(factors, e.f, sizeof(e.f));
+    return e.terms;
+}
+
+// a filter object per distinct rectangular configuration, kept for the life of the process (a few KB each, at most 64)
+static const Savgol2DFilter *rect_filter_cached(const Savgol2DConfig *cfg, bool *owned)
+{
+    static std::mutex mu;
+    static std::vector<Savgol2DFilter *> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Savgol2DFilter *f : cache)
+        if (memcmp(&f->config, cfg, sizeof(*cfg)) == 0) { *owned = false; return f; }
+    Savgol2DFilter *f = savgol2d_create(cfg);
+    if (!f) return nullptr;
+    if (cache.size() < 64) { cache.push_back(f); *owned = false; }
+    else *owned = true;                                      // cache full: the caller destroys it
+    return f;
+}
+
 // SAVGOL_HIP_DENSE_KERNEL=1 forces the one-pixel-per-lane dense kernel (diagnostics / A-B timing)
 static int dense_kernel_env()
 {
@@ -307,11 +349,12 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
     if (nx != ny) {
         // rectangular windows: the dense kernel, one launch per output frame; the Laplacian is ONE launch with the summed
         // kernel sxx*Wxx + syy*Wyy (no temporary frame, no add pass, nothing but launches: capturable into a hipGraph)
-        Savgol2DFilter *fs[SEP_MAX_OUTPUTS] = {nullptr, nullptr, nullptr};
+        const Savgol2DFilter *fs[SEP_MAX_OUTPUTS] = {nullptr, nullptr, nullptr};
+        bool owned[SEP_MAX_OUTPUTS] = {false, false, false};
         int rc = 0;
         for (int i = 0; i < nspec && rc == 0; ++i) {
             cfg.deriv_x = (uint8_t)specs[i].dx; cfg.deriv_y = (uint8_t)specs[i].dy;
-            fs[i] = savgol2d_create(&cfg);
+            fs[i] = rect_filter_cached(&cfg, &owned[i]);
             if (!fs[i]) rc = -1;
         }
         if (rc == 0 && sum_into_one) {
@@ -332,7 +375,8 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
                 rc = enqueue_2d(who, fs[i], d_in, rows, cols, in_stride, (long long)in_pitch, specs[i].out, out_stride, (long long)out_pitch,
                                 images, boundary, 1, st);
         }
-        for (int i = 0; i < nspec; ++i) savgol2d_destroy(fs[i]);
+        for (int i = 0; i < nspec; ++i)
+            if (owned[i]) savgol2d_destroy(const_cast<Savgol2DFilter *>(fs[i]));
         return rc;
     }
 
@@ -343,22 +387,29 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
     memset(&plan, 0, sizeof(plan));
     int total_terms = 0;
     if (sum_into_one) {
-        for (int i = 0; i < ws * ws; ++i) Wsum[i] = 0.0;
-        for (int i = 0; i < nspec; ++i) {
-            cfg.deriv_x = (uint8_t)specs[i].dx; cfg.deriv_y = (uint8_t)specs[i].dy;
-            if (sg2d_kernel_double(&cfg, Wd) != 0) { sg_set_error("%s: weight computation failed", who); return -1; }
-            const double sc = (double)sg2d_scale(&cfg);
-            for (int k = 0; k < ws * ws; ++k) Wsum[k] += sc * Wd[k];
+        // (the only summed form is the Laplacian: d = (2,0) + (0,2), which the key takes for granted)
+        const SummedKey key = {n, order, delta_x, delta_y};
+        int t = summed_factors_cached(key, nullptr, factors);
+        if (t < 0) {
+            for (int i = 0; i < ws * ws; ++i) Wsum[i] = 0.0;
+            for (int i = 0; i < nspec; ++i) {
+                cfg.deriv_x = (uint8_t)specs[i].dx; cfg.deriv_y = (uint8_t)specs[i].dy;
+                if (sg2d_kernel_double(&cfg, Wd) != 0) { sg_set_error("%s: weight computation failed", who); return -1; }
+                const double sc = (double)sg2d_scale(&cfg);
+                for (int k = 0; k < ws * ws; ++k) Wsum[k] += sc * Wd[k];
+            }
+            t = summed_factors_cached(key, Wsum, factors);
         }
-        const int t = sg2d_factors_from_kernel(Wsum, n, order, factors, SEP_MAX_TERMS);
         if (t <= 0) { sg_set_error("%s: kernel is not separable with <= %d terms", who, SEP_MAX_TERMS); return -1; }
         plan.outputs = 1; plan.terms[0] = t; plan.scale[0] = 1.0f; plan.out[0] = specs[0].out;
         total_terms = t;
     } else {
         for (int i = 0; i < nspec; ++i) {
             cfg.deriv_x = (uint8_t)specs[i].dx; cfg.deriv_y = (uint8_t)specs[i].dy;
-            const int t = sg2d_separable_factors(&cfg, factors + (size_t)total_terms * 2 * (ws + 1), SEP_MAX_TERMS);
+            float one[SEP_MAX_TERMS * 2 * (2 * SAVGOL2D_MAX_HALF_WINDOW + 2)];
+            const int t = sep_factors_cached(&cfg, one);
             if (t <= 0) { sg_set_error("%s: kernel is not separable with <= %d terms", who, SEP_MAX_TERMS); return -1; }
+            memcpy(factors + (size_t)total_terms * 2 * (ws + 1), one, sizeof(float) * (size_t)t * 2 * (ws + 1));
             plan.terms[plan.outputs] = t; plan.scale[plan.outputs] = sg2d_scale(&cfg); plan.out[plan.outputs] = specs[i].out;
             plan.outputs++;
             total_terms += t;
