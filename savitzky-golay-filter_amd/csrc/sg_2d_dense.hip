@@ -130,7 +130,7 @@ __device__ __forceinline__ void dense_item(const Job2D &job, const float *__rest
         load_taps(wcur, R::WW - 1, pr[0]);
         static_for<R::WW>([&](auto wyc) -> bool {
             constexpr int wy = R::WW - 1 - decltype(wyc)::value;
-            if constexpr (wy > 0) load_taps(wnext, wy - 1, wy + 1 < R::WW ? acc[wy + 1][1] : pr[1]);
+            if constexpr (wy > 0) load_taps(wnext, wy - 1, wy + 1 < R::WW ? acc[wy + 1 < R::WW ? wy + 1 : 0][1] : pr[1]);   // (index clamped for the dead arm: -Warray-bounds)
             // the products of tap wx+1 are issued before the adds of tap wx (see sg_pk.hpp on asm results and s_nop)
             f32x2 p0 = pk_mul_here<0>(wcur[0], pr[0]), p1 = pk_mul_here<0>(wcur[0], pr[2]);
             static_for<R::WW>([&](auto wxc) -> bool {

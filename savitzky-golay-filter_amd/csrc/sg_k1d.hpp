@@ -114,7 +114,8 @@ struct K1D {
     static constexpr int WAVES = 4;                          // waves per block, each with its own slab
     // waves per SIMD the register allocation must allow (the LDS slabs allow as many blocks per CU)
     // (fp64 fits 128 VGPRs since its taps moved to SGPRs, but A/B'd in one process the 168-VGPR schedule is 2.5 % faster)
-    static constexpr int MIN_WAVES = sizeof(T) == 8 ? 3 : (VPL <= 4 ? 7 : VPL <= 6 ? 5 : 4);
+    // (the 12 / 16 KiB tiles hold 3 / 2 blocks per CU in LDS: asking for more only caps the registers for nothing)
+    static constexpr int MIN_WAVES = VPL >= 16 ? 2 : VPL >= 12 ? 3 : sizeof(T) == 8 ? 3 : (VPL <= 4 ? 7 : VPL <= 6 ? 5 : 4);
     static_assert(2 * HV <= 64, "halo must fit one extra vector per lane");
     static_assert(WQ <= SV - VPL * 63, "lane 63's window must stay inside the slab");
     static_assert(VPL == 4 || VPL == 6 || VPL == 8 || VPL == 12 || VPL == 16, "lane stride (VPL+1)*16 B must be conflict free for ds_read_b128");

@@ -17,14 +17,14 @@ struct alignas(8) Taps { union { float w[SAVGOL_MAX_WINDOW + 1]; double wd[(SAVG
 // 8 -> 8 KiB tiles, 9.5 KB of LDS per wave, 4 waves per SIMD; 16 -> 16 KiB tiles, 2 waves per SIMD.
 // Two tile widths are built where they differ, and the host picks per call (enqueue_batch):
 //   narrow (vectors_per_lane): 8 everywhere.  4 / 6 / 8 are within 0.5 % of each other on big batches (tools/ab_1d.py).
-//   wide (wide_vectors_per_lane): 16 for fp32 n <= 12 and fp64 n <= 24, 12 for fp32 n = 13..17 -- 2-5 % faster on big batches (32 GiB per launch,
+//   wide (wide_vectors_per_lane): 16 for fp32 n <= 12 and fp64 n <= 24, 12 for fp32 n = 13..18 -- 2-5 % faster on big batches (32 GiB per launch,
 //     A/B over eight placements of the buffers, tools/ab_1d_placements.py: fp32 n = 8: 5.76 -> 5.57 ms, fp64 n = 24: 5.81 -> 5.70;
 //     n = 2: 5.81 -> 5.52, fp64 n = 20: 5.82 -> 5.49 in single-placement runs): fewer halo re-reads and fewer, longer waves.
 //     Beyond those half windows the 64 accumulators and the window no longer fit (fp32 n = 23: 5 % slower, fp64 n = 28: 5 %
 //     slower), and on a SMALL job wide tiles are simply fewer waves: one 10^6-sample signal (BASELINE config 1) takes 24.6 us on
 //     245 wide tiles against 17.4 us on 489 narrow ones -- hence the choice by job size.
-//     fp32 n = 13..17: 12 vectors (12 KiB tiles) instead: 3-6 % faster (n = 13: 5.75 -> 5.41 ms, n = 17: 5.76 -> 5.58 over eight
-//     placements), level at n = 19, 4 % slower at n = 21; fp64 n >= 26: 12 is 3-4 % slower than 8.
+//     fp32 n = 13..18: 12 vectors (12 KiB tiles) instead: 2-6 % faster (n = 13: 5.75 -> 5.41 ms, n = 18: 5.72 -> 5.61 over eight
+//     placements), 1-2 % slower at n = 20, 4-6 % at n = 21, 23; fp64 n >= 26: 12 is 3-4 % slower than 8, 16 level (+-1.5 %) with 8.
 //   fp32 n >= 24 (block moments) is laid out for 32 outputs per lane: 8 either way.
 #ifndef SG_VPL_F32_WIDE
 #define SG_VPL_F32_WIDE 8          /* fp32, half_window >= 24; A/B builds override this */
@@ -36,13 +36,22 @@ constexpr int vectors_per_lane(size_t elem_size, int half_window)
 {
     return (elem_size == 4 && half_window >= 24) ? SG_VPL_F32_WIDE : SG_VPL_NARROW;
 }
+#ifndef SG_WIDE_F32_MAX16
+#define SG_WIDE_F32_MAX16 12         /* last fp32 half window with 16-vector wide tiles (A/B builds override these three) */
+#endif
+#ifndef SG_WIDE_F32_MAX12
+#define SG_WIDE_F32_MAX12 18         /* ... with 12-vector wide tiles above that */
+#endif
+#ifndef SG_WIDE_F64_MAX16
+#define SG_WIDE_F64_MAX16 24         /* last fp64 half window with 16-vector wide tiles */
+#endif
 constexpr int wide_vectors_per_lane(size_t elem_size, int half_window)
 {
 #ifdef SG_VPL_NO_WIDE
     return vectors_per_lane(elem_size, half_window);                    /* A/B builds */
 #else
-    if (elem_size == 4 && half_window >= 13 && half_window <= 17) return 12;
-    return (elem_size == 8 ? half_window <= 24 : half_window <= 12) ? 16 : vectors_per_lane(elem_size, half_window);
+    if (elem_size == 4 && half_window > SG_WIDE_F32_MAX16 && half_window <= SG_WIDE_F32_MAX12) return 12;
+    return (elem_size == 8 ? half_window <= SG_WIDE_F64_MAX16 : half_window <= SG_WIDE_F32_MAX16) ? 16 : vectors_per_lane(elem_size, half_window);
 #endif
 }
 // a job gets the wide tile when it has at least this many of them (8 rounds of the 2048 waves the chip holds at 2 per SIMD)

@@ -577,9 +577,9 @@ def test_long_host_signals_with_shifted_overlap_keep_the_serial_path(sg, sgo, to
     assert got == L - 10 and same_bits(buf[:L - 10], wantv)
 
 
-@pytest.mark.parametrize("dtype,n", [("f32", 1), ("f32", 5), ("f32", 12), ("f32", 15), ("f32", 17), ("f64", 3), ("f64", 16), ("f64", 24)])
+@pytest.mark.parametrize("dtype,n", [("f32", 1), ("f32", 5), ("f32", 12), ("f32", 15), ("f32", 18), ("f64", 3), ("f64", 16), ("f64", 24)])
 def test_wide_tile_kernels_on_batches_big_enough_to_select_them(sg, sgo, torch_gpu, dtype, n):
-    """Half windows <= 17 (fp32; 12 KiB tiles from 13 up) / <= 24 (fp64) have a second, 16 KiB-per-wave tile that enqueue_batch picks from 16384 tiles up
+    """Half windows <= 18 (fp32; 12 KiB tiles from 13 up) / <= 24 (fp64) have a second, 16 KiB-per-wave tile that enqueue_batch picks from 16384 tiles up
     (sg_k1d_host.hpp): 72 channels of 2^20 + 77 samples on a padded pitch select it.  All four boundary modes and VALID, sampled
     channels against the oracle; the same call on a batch too small for the wide tile must give the same bits per channel."""
     torch = torch_gpu
