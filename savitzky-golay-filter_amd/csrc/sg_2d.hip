@@ -494,33 +494,86 @@ int savgol2d_laplacian_batch_f32(int half_win_x, int half_win_y, int poly_order,
                                    static_cast<hipStream_t>(stream));
 }
 
-// ---- helper wrappers: one filter per requested output, as the reference (:462-618) ----
-static int one_derivative(int nx, int ny, int order, int dx, int dy, const float *input, int rows, int cols, int stride,
-                          float *output, float delta_x, float delta_y, Savgol2DBoundary boundary)
+// ---- helper wrappers (reference :462-618: one create / apply / destroy per requested output, each reading the input again) ----
+// Same outputs bit for bit -- the dense kernel per output, the Laplacian's fp32 add over the whole frame -- but the frame crosses
+// the host link once: one upload, one dense launch per output, one download per output.  The filters (host least squares) come
+// from the per-configuration cache the device entry points use.
+}  // extern "C"
+
+namespace sg {
+
+struct HostDeriv { int dx, dy; float *out; };
+
+static int host_derivatives(const char *who, int nx, int ny, int order, const HostDeriv *specs, int nspec, const float *input, int rows,
+                            int cols, int stride, float delta_x, float delta_y, int boundary, bool laplacian)
 {
-    Savgol2DConfig cfg;
-    memset(&cfg, 0, sizeof(cfg));
-    cfg.half_window_x = (uint8_t)nx; cfg.half_window_y = (uint8_t)ny; cfg.poly_order = (uint8_t)order;
-    cfg.deriv_x = (uint8_t)dx; cfg.deriv_y = (uint8_t)dy; cfg.delta_x = delta_x; cfg.delta_y = delta_y;
-    Savgol2DFilter *f = savgol2d_create(&cfg);
-    if (!f) return -1;
-    const int rc = savgol2d_apply(f, input, rows, cols, stride, output, stride, boundary);
-    savgol2d_destroy(f);
-    return rc;
+    if (nspec == 0) return 0;
+    const Savgol2DFilter *fs[SEP_MAX_OUTPUTS] = {nullptr, nullptr, nullptr};
+    bool owned[SEP_MAX_OUTPUTS] = {false, false, false};
+    auto release = [&]() { for (int i = 0; i < nspec; ++i) if (owned[i] && fs[i]) savgol2d_destroy(const_cast<Savgol2DFilter *>(fs[i])); };
+    for (int i = 0; i < nspec; ++i) {
+        Savgol2DConfig cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.half_window_x = (uint8_t)nx; cfg.half_window_y = (uint8_t)ny; cfg.poly_order = (uint8_t)order;
+        cfg.deriv_x = (uint8_t)specs[i].dx; cfg.deriv_y = (uint8_t)specs[i].dy; cfg.delta_x = delta_x; cfg.delta_y = delta_y;
+        if (nx < 0 || nx > 255 || ny < 0 || ny > 255 || order < 0 || order > 255) { release(); fprintf(stderr, "savgol2d_create: invalid configuration\n"); return -1; }
+        fs[i] = rect_filter_cached(&cfg, &owned[i]);
+        if (!fs[i]) { release(); return -1; }
+    }
+    const bool valid = boundary == SAVGOL2D_BOUNDARY_VALID;
+    if (!input || rows <= 0 || cols <= 0 || (valid && (rows - 2 * ny <= 0 || cols - 2 * nx <= 0))) { release(); return -1; }
+    DeviceCtx *ctx = ctx_get();
+    if (!ctx) { release(); fprintf(stderr, "%s: %s\n", who, savgol_hip_last_error()); return -1; }
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const int dstride = (cols + 3) & ~3;
+    const size_t frame = (size_t)rows * dstride;
+    float *d_in = static_cast<float *>(ctx_arena(ctx, sizeof(float) * frame * (size_t)(1 + nspec)));
+    if (!d_in) { release(); fprintf(stderr, "%s: %s\n", who, savgol_hip_last_error()); return -1; }
+    bool ok = hip_ok(hipMemcpy2D(d_in, sizeof(float) * dstride, input, sizeof(float) * stride, sizeof(float) * cols, rows, hipMemcpyHostToDevice),
+                     "H2D copy");
+    for (int i = 0; i < nspec && ok; ++i) {
+        float *d_out = d_in + frame * (size_t)(1 + i);
+        if (laplacian && valid) {
+            // reference :598-613: d2/dx2 lands inside the caller's frame, d2/dy2 inside a temporary (zeros here), then the WHOLE frame is
+            // added: the caller's border values pass through that add, so they have to be on the device too
+            if (i == 0) ok = hip_ok(hipMemcpy2D(d_out, sizeof(float) * dstride, specs[0].out, sizeof(float) * stride, sizeof(float) * cols, rows,
+                                                hipMemcpyHostToDevice), "H2D copy");
+            else ok = hip_ok(hipMemsetAsync(d_out, 0, sizeof(float) * frame, nullptr), "hipMemsetAsync");
+        }
+        ok = ok && enqueue_2d(who, fs[i], d_in, rows, cols, dstride, 0, d_out, dstride, 0, 1, boundary, 1, nullptr) == 0;
+    }
+    if (ok && laplacian) {
+        float *d_a = d_in + frame, *d_b = d_in + 2 * frame;
+        hipLaunchKernelGGL(sg2d_add_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, nullptr, d_a, d_b, rows, cols, dstride);
+        ok = hip_ok(hipGetLastError(), "add kernel") &&
+             hip_ok(hipMemcpy2D(specs[0].out, sizeof(float) * stride, d_a, sizeof(float) * dstride, sizeof(float) * cols, rows, hipMemcpyDeviceToHost),
+                    "D2H copy");
+    } else if (ok) {
+        const int r0 = valid ? ny : 0, c0 = valid ? nx : 0;
+        const int nr = valid ? rows - 2 * ny : rows, nc = valid ? cols - 2 * nx : cols;
+        for (int i = 0; i < nspec && ok; ++i)
+            ok = hip_ok(hipMemcpy2D(specs[i].out + (size_t)r0 * stride + c0, sizeof(float) * stride,
+                                    d_in + frame * (size_t)(1 + i) + (size_t)r0 * dstride + c0, sizeof(float) * dstride, sizeof(float) * nc, nr,
+                                    hipMemcpyDeviceToHost), "D2H copy");
+    }
+    release();
+    if (!ok) { fprintf(stderr, "%s: %s\n", who, savgol_hip_last_error()); return -1; }
+    return 0;
 }
+
+}  // namespace sg
+
+extern "C" {
 
 int savgol2d_gradient(int half_win_x, int half_win_y, int poly_order, const float *input, int rows, int cols, int stride,
                       float *grad_x, float *grad_y, float delta_x, float delta_y, Savgol2DBoundary boundary)
 {
-    if (grad_x) {
-        const int rc = one_derivative(half_win_x, half_win_y, poly_order, 1, 0, input, rows, cols, stride, grad_x, delta_x, delta_y, boundary);
-        if (rc != 0) return rc;
-    }
-    if (grad_y) {
-        const int rc = one_derivative(half_win_x, half_win_y, poly_order, 0, 1, input, rows, cols, stride, grad_y, delta_x, delta_y, boundary);
-        if (rc != 0) return rc;
-    }
-    return 0;
+    sg::HostDeriv specs[2];
+    int n = 0;
+    if (grad_x) specs[n++] = {1, 0, grad_x};
+    if (grad_y) specs[n++] = {0, 1, grad_y};
+    return sg::host_derivatives("savgol2d_gradient", half_win_x, half_win_y, poly_order, specs, n, input, rows, cols, stride, delta_x, delta_y,
+                                (int)boundary, false);
 }
 
 int savgol2d_hessian(int half_win_x, int half_win_y, int poly_order, const float *input, int rows, int cols, int stride,
@@ -530,15 +583,13 @@ int savgol2d_hessian(int half_win_x, int half_win_y, int poly_order, const float
         fprintf(stderr, "savgol2d_hessian: poly_order must be >= 2\n");
         return -1;
     }
-    float *outs[3] = {hess_xx, hess_xy, hess_yy};
-    const int dxs[3] = {2, 1, 0}, dys[3] = {0, 1, 2};
-    for (int i = 0; i < 3; ++i) {
-        if (!outs[i]) continue;
-        const int rc = one_derivative(half_win_x, half_win_y, poly_order, dxs[i], dys[i], input, rows, cols, stride, outs[i],
-                                      delta_x, delta_y, boundary);
-        if (rc != 0) return rc;
-    }
-    return 0;
+    sg::HostDeriv specs[3];
+    int n = 0;
+    if (hess_xx) specs[n++] = {2, 0, hess_xx};
+    if (hess_xy) specs[n++] = {1, 1, hess_xy};
+    if (hess_yy) specs[n++] = {0, 2, hess_yy};
+    return sg::host_derivatives("savgol2d_hessian", half_win_x, half_win_y, poly_order, specs, n, input, rows, cols, stride, delta_x, delta_y,
+                                (int)boundary, false);
 }
 
 int savgol2d_laplacian(int half_win_x, int half_win_y, int poly_order, const float *input, int rows, int cols, int stride,
@@ -549,38 +600,9 @@ int savgol2d_laplacian(int half_win_x, int half_win_y, int poly_order, const flo
         return -1;
     }
     if (!input || !output) return -1;
-    // d2/dx2 into `output`, d2/dy2 into a temporary frame, then output += temporary over the whole
-    // rows x cols frame (reference :598-613; in VALID mode the temporary's border is whatever the
-    // allocator returned there -- we use zeros, and the caller's border values pass through the add).
-    int rc = one_derivative(half_win_x, half_win_y, poly_order, 2, 0, input, rows, cols, stride, output, delta_x, delta_y, boundary);
-    if (rc != 0) return rc;
-    float *temp = static_cast<float *>(calloc((size_t)rows * stride, sizeof(float)));
-    if (!temp) return -1;
-    rc = one_derivative(half_win_x, half_win_y, poly_order, 0, 2, input, rows, cols, stride, temp, delta_x, delta_y, boundary);
-    if (rc == 0) {
-        sg::DeviceCtx *ctx = sg::ctx_get();
-        if (!ctx) { free(temp); return -1; }
-        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-        const size_t n = (size_t)rows * stride;
-        float *d_a = static_cast<float *>(sg::ctx_arena(ctx, 2 * n * sizeof(float)));
-        if (!d_a) { free(temp); return -1; }
-        float *d_b = d_a + n;
-        // rows x cols only: the caller's frame may be a sub-view whose last row ends at `cols`, not at `stride` (the
-        // reference touches cols floats per row, :609-613)
-        bool ok = sg::hip_ok(hipMemcpy2D(d_a, sizeof(float) * stride, output, sizeof(float) * stride, sizeof(float) * cols, rows,
-                                         hipMemcpyHostToDevice), "H2D copy") &&
-                  sg::hip_ok(hipMemcpy2D(d_b, sizeof(float) * stride, temp, sizeof(float) * stride, sizeof(float) * cols, rows,
-                                         hipMemcpyHostToDevice), "H2D copy");
-        if (ok) {
-            hipLaunchKernelGGL(sg::sg2d_add_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, nullptr, d_a, d_b, rows, cols, stride);
-            ok = sg::hip_ok(hipGetLastError(), "add kernel") &&
-                 sg::hip_ok(hipMemcpy2D(output, sizeof(float) * stride, d_a, sizeof(float) * stride, sizeof(float) * cols, rows,
-                                        hipMemcpyDeviceToHost), "D2H copy");
-        }
-        if (!ok) { fprintf(stderr, "savgol2d_laplacian: %s\n", savgol_hip_last_error()); rc = -1; }
-    }
-    free(temp);
-    return rc;
+    const sg::HostDeriv specs[2] = {{2, 0, output}, {0, 2, nullptr}};
+    return sg::host_derivatives("savgol2d_laplacian", half_win_x, half_win_y, poly_order, specs, 2, input, rows, cols, stride, delta_x, delta_y,
+                                (int)boundary, true);
 }
 
 }  // extern "C"
