@@ -57,7 +57,7 @@ const char *savgol_hip_version(void);
  * derivatives on the leading edge -- src/savgolFilter.c:773-777)  Affects the 1-D batch / apply
  * entry points only; the streaming path keeps the reference behaviour.                                           */
 enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1, SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2, SAVGOL_HIP_OPT_PLAIN_SUMMATION = 3,
-       SAVGOL_HIP_OPT_BOUNDARY_AWARE = 4 };
+       SAVGOL_HIP_OPT_BOUNDARY_AWARE = 4, SAVGOL_HIP_OPT_TILE_WIDTH = 5 };
 /* SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 1: the fp32 1-D batch / valid / strided DEVICE entry points sum each output in
  * the reference's own order (convolve_ilp, src/savgolFilter.c:547-580: four chains, separate multiply and add) and are
  * then bit-identical to the reference's savgol_apply; 1.5x (n=5) to 2.1x (n=32) slower than the default FMA kernel, which
@@ -74,7 +74,10 @@ enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1, SAVGOL_HIP_OPT_REFERENCE_SUMMATI
  *     push_full / flush / flush_leading: the first and last n outputs are the centre taps on the index-remapped window
  *     (get_padded_sample, :442-482), so push_full... + flush equals savgol_apply in that mode.  PERIODIC needs samples from the
  *     other end of the signal and keeps the polynomial rows.  Read when a stream or bank is created / a stream call is made;
- *     set it before.  Default 0: the reference's behaviour.                                                                  */
+ *     set it before.  Default 0: the reference's behaviour.
+ * SAVGOL_HIP_OPT_TILE_WIDTH: which of the two tile widths the 1-D batch kernels run with where both are built (fp32 half windows
+ *   <= 18, fp64 <= 24).  0 (default): by job size -- the 12 / 16 KiB tile from 16384 tiles up, the 8 KiB tile below; 1: always the
+ *   8 KiB tile; 2: always the wide one.  Same bits per output either way; a tuning and test knob.                                */
 int         savgol_hip_set_option(int option, int value);
 /* Diagnostic (host only, no device needed): the constant table the wide-window (24..32) fp32 kernel reads -- SAVGOL_HIP_MOMENT_TABLE_FLOATS
  * floats: centre taps [0,66), block basis phi[s-1][t] at [80,176), own-block coefficients c[s][J][2] at [176,400); layout in

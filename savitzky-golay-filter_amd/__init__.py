@@ -27,6 +27,7 @@ SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1
 SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2
 SAVGOL_HIP_OPT_PLAIN_SUMMATION = 3
 SAVGOL_HIP_OPT_BOUNDARY_AWARE = 4
+SAVGOL_HIP_OPT_TILE_WIDTH = 5
 
 
 class SavgolConfig(C.Structure):

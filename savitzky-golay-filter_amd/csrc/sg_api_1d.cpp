@@ -70,7 +70,8 @@ namespace {
 std::atomic<int> g_correct_leading_edge{0};
 std::atomic<int> g_reference_summation{0};      // SAVGOL_HIP_OPT_REFERENCE_SUMMATION: batch f32 calls in the reference's order
 std::atomic<int> g_plain_summation{0};          // SAVGOL_HIP_OPT_PLAIN_SUMMATION: no block moments at half_window 32
-std::atomic<int> g_boundary_aware{0};           // SAVGOL_HIP_OPT_BOUNDARY_AWARE: strided calls and streams honour config.boundary
+std::atomic<int> g_boundary_aware{0};
+std::atomic<int> g_tile_width{0};               // SAVGOL_HIP_OPT_TILE_WIDTH: 0 by job size, 1 narrow, 2 wide           // SAVGOL_HIP_OPT_BOUNDARY_AWARE: strided calls and streams honour config.boundary
 
 // wide-window fast path (half windows 24..32): the polynomial fit of a filter's centre taps (sg_k1d_moment_fit.cpp), cached per table content
 struct MomentFit { int n; float w[SAVGOL_MAX_WINDOW]; int terms; float table[sg::MOMENT_TABLE_FLOATS]; };
@@ -181,7 +182,9 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     // tile width: the wide tile where one is built and the batch is big enough to keep the chip in whole rounds of them
     int vpl = sg::vectors_per_lane(sizeof(T), f->config.half_window);
     const int vpl_wide = sg::wide_vectors_per_lane(sizeof(T), f->config.half_window);
-    const int wide = vpl_wide != vpl && (unsigned long long)channels * ((length + 64u * vpl_wide * E - 1) / (64u * vpl_wide * E)) >= sg::WIDE_TILE_MIN_TILES;
+    const int tile_mode = g_tile_width.load();
+    const int wide = vpl_wide != vpl && tile_mode != 1 &&
+                     (tile_mode == 2 || (unsigned long long)channels * ((length + 64u * vpl_wide * E - 1) / (64u * vpl_wide * E)) >= sg::WIDE_TILE_MIN_TILES);
     if (wide) vpl = vpl_wide;
     const unsigned TW = 64u * (unsigned)vpl * E;
     const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
@@ -455,6 +458,11 @@ int savgol_hip_set_option(int option, int value)
     if (option == SAVGOL_HIP_OPT_REFERENCE_SUMMATION) { g_reference_summation.store(value != 0); return 0; }
     if (option == SAVGOL_HIP_OPT_PLAIN_SUMMATION) { g_plain_summation.store(value != 0); return 0; }
     if (option == SAVGOL_HIP_OPT_BOUNDARY_AWARE) { g_boundary_aware.store(value != 0); return 0; }
+    if (option == SAVGOL_HIP_OPT_TILE_WIDTH) {
+        if (value < 0 || value > 2) { sg_set_error("savgol_hip_set_option: tile width %d (0 auto, 1 narrow, 2 wide)", value); return -1; }
+        g_tile_width.store(value);
+        return 0;
+    }
     sg_set_error("savgol_hip_set_option: unknown option %d", option);
     return -1;
 }

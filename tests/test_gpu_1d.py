@@ -607,3 +607,37 @@ def test_wide_tile_kernels_on_batches_big_enough_to_select_them(sg, sgo, torch_g
     sg.Filter(n, m, 0, 1.0, 0).apply_batch(x, y, ch, length, in_ld=ld, out_ld=ld, dtype=dtype)
     assert torch.equal(v[:, :length - 2 * n], y[:, n:length - n])
     assert torch.all(v[:, length - 2 * n:] == -7.0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_wide_and_narrow_tiles_give_the_same_bits_on_ragged_batches(sg, sgo, torch_gpu, dtype):
+    """SAVGOL_HIP_OPT_TILE_WIDTH forces either tile width, so the wide kernels also meet what big batches never contain: channels
+    shorter than one tile, lengths that end a few samples into a tile, unaligned rows, every boundary mode and VALID -- each against
+    the narrow tile bit for bit (same chain of multiply-adds per output) and, sampled, against the oracle."""
+    torch = torch_gpu
+    L = sg.lib()
+    tdt, tol = (torch.float32, TOL_F32) if dtype == "f32" else (torch.float64, 1e-12)
+    rng = np.random.default_rng(99)
+    half_windows = (1, 4, 9, 12, 13, 18) if dtype == "f32" else (2, 11, 17, 24)
+    try:
+        for n in half_windows:
+            for (ch, length, ld) in ((3, 2 * n + 1, 2 * n + 1), (2, 4099, 4101), (5, 12289 + n, 12292 + n), (1, 70001, 70001)):
+                x = torch.from_numpy(rng.normal(0, 1, (ch, ld))).to(tdt).cuda()
+                for mode in range(4):
+                    f = sg.Filter(n, min(4, 2 * n), 0, 1.0, mode)
+                    outs = []
+                    for width in (1, 2):
+                        assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_TILE_WIDTH, width) == 0
+                        y = torch.full((ch, ld), -3.0, dtype=tdt, device="cuda")
+                        f.apply_batch(x, y, ch, length, in_ld=ld, out_ld=ld, dtype=dtype)
+                        v = torch.full((ch, ld), -3.0, dtype=tdt, device="cuda")
+                        if length > 2 * n:
+                            f.apply_batch(x, v, ch, length, in_ld=ld, out_ld=ld, dtype=dtype, valid=True)
+                        outs.append((y, v))
+                    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, ch, length, mode)
+                    assert torch.all(outs[1][0][:, length:] == -3.0)
+                ref = sgo.Filter(n, min(4, 2 * n), 0, 1.0, 3).apply_f64(x[:, :length].cpu().numpy().astype(np.float64))
+                assert normwise(outs[1][0][:, :length].cpu().numpy(), ref) < tol, (n, ch, length)
+        assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_TILE_WIDTH, 3) == -1
+    finally:
+        L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_TILE_WIDTH, 0)
