@@ -136,6 +136,14 @@ int savgol_apply_strided_batch_f32(const SavgolFilter *filter,
 typedef struct SavgolStreamBank SavgolStreamBank;
 
 SavgolStreamBank *savgol_streambank_create(const SavgolConfig *config, size_t streams);
+/* Per-bank choice of the summation, fixed at create (the stream analogue of the 1-D batch path's fast default):
+ * SAVGOL_STREAMBANK_FMA: centre outputs of _push / _push_block / _push_full (after the filling tick) are fused multiply-adds --
+ *   one v_pk_fma_f32 per tap and stream pair instead of a multiply and an add (reference loop src/savgol_stream.c:25-38), half
+ *   the vector instructions of the block push.  NOT the reference's bits: <= 1e-6 (smoothing) / 2e-6 (derivatives) normwise of
+ *   the fp64 oracle, like the default 1-D batch kernels.  Edge rows (leading burst, _flush, _flush_leading), the resident
+ *   tick service and calls of >= 2^31 ticks keep the reference's order.  flags 0 == savgol_streambank_create.               */
+enum { SAVGOL_STREAMBANK_FMA = 1 };
+SavgolStreamBank *savgol_streambank_create_ex(const SavgolConfig *config, size_t streams, unsigned flags);
 void   savgol_streambank_destroy(SavgolStreamBank *bank);
 int    savgol_streambank_reset(SavgolStreamBank *bank, void *stream);
 /* one tick = one sample per stream.  Returns 1 when d_out[0..streams) holds centre outputs,

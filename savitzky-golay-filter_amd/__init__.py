@@ -28,6 +28,7 @@ SAVGOL_HIP_OPT_REFERENCE_SUMMATION = 2
 SAVGOL_HIP_OPT_PLAIN_SUMMATION = 3
 SAVGOL_HIP_OPT_BOUNDARY_AWARE = 4
 SAVGOL_HIP_OPT_TILE_WIDTH = 5
+SAVGOL_STREAMBANK_FMA = 1
 
 
 class SavgolConfig(C.Structure):
@@ -111,6 +112,7 @@ SIGNATURES = {
     "savgol_apply_strided_batch_f32": (C.c_int, [_F, _vp, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
     # savgol_hip.h: stream bank
     "savgol_streambank_create": (_vp, [C.POINTER(SavgolConfig), _sz]),
+    "savgol_streambank_create_ex": (_vp, [C.POINTER(SavgolConfig), _sz, C.c_uint]),
     "savgol_streambank_destroy": (None, [_vp]),
     "savgol_streambank_reset": (C.c_int, [_vp, _vp]),
     "savgol_streambank_push": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -339,9 +341,10 @@ class Stream:
 class StreamBank:
     """savgol_streambank_*: `streams` lock-step streams with their rings in HBM (torch tensors in/out)."""
 
-    def __init__(self, streams, half_window, poly_order, derivative=0, time_step=1.0):
+    def __init__(self, streams, half_window, poly_order, derivative=0, time_step=1.0, fma=False):
+        """fma=True: SAVGOL_STREAMBANK_FMA (fused multiply-adds: fast, not the reference's bits)."""
         cfg = SavgolConfig(half_window, poly_order, derivative, time_step, 0)
-        self.ptr = lib().savgol_streambank_create(C.byref(cfg), streams)
+        self.ptr = lib().savgol_streambank_create_ex(C.byref(cfg), streams, SAVGOL_STREAMBANK_FMA if fma else 0)
         if not self.ptr:
             raise RuntimeError(f"savgol_streambank_create failed: {last_error()}")
         self.streams, self.n = streams, half_window

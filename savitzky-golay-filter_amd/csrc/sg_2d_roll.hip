@@ -111,22 +111,37 @@ __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
     return a >= n ? n - 1 : a;
 }
 
-// One item: the strip of SW stored columns at sx, output rows yb .. yb+nout-1 of one frame.  VEC: the strip's 256
-// input columns are inside the frame, all its SW output columns are stored and rows are 16-byte aligned (one
-// dwordx4 load and store per lane per row); otherwise four remapped scalar loads and masked scalar stores (the
-// strips at the left / right frame edge, odd strides).
+// One item: a 256-column strip whose first loaded column is xload, output rows yb .. yb+nout-1 of one frame.  VAR:
+//   0  four remapped scalar loads and masked scalar stores per lane (frames narrower than a strip, odd strides or widths);
+//   1  an inner strip: its 256 input columns are inside the frame and rows are 16-byte aligned (one dwordx4 load and store per lane
+//      and row); the HL outermost lanes on either side are halo, the SW columns in between are stored;
+//   2  a strip that ends AT the frame's left (side 0) or right (side 1) edge, on vector loads too: the columns beyond the
+//      edge are not loaded through remapped indices but synthesised in the LDS row from the lane's own vertical results -- the
+//      remap is per column, so v_t(remapped column) is the vertical result of that column (reference src/savgol2d.c:428-445).
+//      Only the HL lanes on the inner side are halo: 256 - 4 HL columns are stored, so a 4096-column frame is 2 x 248 + 15 x 240:
+//      17 strips, all on vector loads (round 2: 18, two of them -- one nearly empty -- on the scalar path).
 // Row r of the band's input (frame row yb-N+r, remapped at the frame border) lives in ring slot r % U.  Output row m
 // needs rows m .. m+2N; while it is computed, row m+2N+P is already being loaded into the slot row m-1 left.
 // The two passes are skewed by one row: iteration m runs the vertical pass of row m and writes its results to one LDS
 // row, then reads row m-1's horizontal window from the other LDS row (written one iteration earlier, so the data
 // is there when the reads issue) and does row m-1's horizontal arithmetic and store.
-template <int N, int NT, int NOUT, bool VEC>
+//
+// BOX (NT = 2, NOUT = 1): the kernel is ADDITIVE, W(x, y) = A(x) + B(y) with B(0) = 0 -- every smoothing kernel of order <= 3
+// (BASELINE config 4) is: only 1, x^2, y^2 survive the window's symmetry.  Then
+//      out = A (*)x box_y(in)  +  box_x( B (*)y in )
+// and the two box factors are not multiply-add passes: box_y is a rolling sum down the ring (add the row that enters, subtract
+// the row that leaves; re-seeded from the ring every U rows, so the drift is bounded by U steps), box_x over a lane's four
+// outputs is one sum of the aligned pairs they share plus a sliding correction.  89 instead of 125 VALU instructions per row
+// of 256 columns at n = 7.
+template <int N, int NT, int NOUT, int VAR, bool BOX>
 __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *mine, const float *in, float *const (&outs)[NOUT],
-                                          int sx, int yb, int nout, int lane, int xlo, int xhi, int ylo, int yhi)
+                                          int xload, int side, int yb, int nout, int lane, int xlo, int xhi, int ylo, int yhi)
 {
     typedef Roll<N> R;
+    constexpr bool VEC = VAR != 0;
+    static_assert(!BOX || (NT == 2 && NOUT == 1), "the additive form is one output of two terms");
     static_assert(R::U % 2 == 0, "the LDS row alternates with the ring slot: U must be even");
-    const int c0 = sx - 4 * R::HL + 4 * lane;                // this lane's first column (frame coordinates)
+    const int c0 = xload + 4 * lane;                         // this lane's first column (frame coordinates)
     int ix0 = 0, ix1 = 0, ix2 = 0, ix3 = 0;
     if constexpr (!VEC) {
         ix0 = fix_index(c0, job.cols, job.boundary); ix1 = fix_index(c0 + 1, job.cols, job.boundary);
@@ -138,12 +153,13 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
         if constexpr (VEC) return *reinterpret_cast<const f32x4 *>(row + c0);
         else return f32x4{row[ix0], row[ix1], row[ix2], row[ix3]};
     };
-    const bool out_lane = lane >= R::HL && lane < 64 - R::HL;
+    const bool out_lane = VAR == 2 ? (side ? lane >= R::HL : lane < 64 - R::HL) : (lane >= R::HL && lane < 64 - R::HL);
+    const int edge_dist = side ? 63 - lane : lane;           // VAR 2: lanes between this one and the frame edge
     const int yend = yb + nout;                              // first frame row past this band
     __amdgpu_buffer_rsrc_t rsrc[NOUT];                       // VEC stores go through a buffer descriptor per output frame (range-checked)
     const __amdgpu_buffer_rsrc_t rsrc_none = __builtin_amdgcn_make_buffer_rsrc(outs[0], 0, 0, 0x00020000);     // zero records: drops every store
     const unsigned col_off = out_lane ? (unsigned)(c0 * 4) : 0x80000000u;
-    if constexpr (VEC && R::STRAIGHT) {
+    if constexpr (VAR == 1 && R::STRAIGHT) {
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
             rsrc[o] = __builtin_amdgcn_make_buffer_rsrc(outs[o], 0, (int)((long long)job.rows * job.out_stride * 4), 0x00020000);
@@ -153,9 +169,66 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 
     f32x4 win[R::U];
 
+    // VAR 2: the HL quads beyond the frame edge of LDS row `row`, from this lane's vertical results v (reference :428-445)
+    auto edge_pad = [&](float *row, const f32x4 v) {
+        if constexpr (VAR == 2) {
+            if (job.boundary != SAVGOL2D_BOUNDARY_VALID) {                      // uniform; VALID stores nothing that reads the pad
+                const float edge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, side ? v.w : v.x), side ? 63 : 0));
+                if (edge_dist < R::HL) {
+                    const f32x4 pad = reflect ? f32x4{v.w, v.z, v.y, v.x} : f32x4{edge, edge, edge, edge};
+                    const int pq = side ? R::HL + 64 + edge_dist : R::HL - 1 - edge_dist;
+                    *reinterpret_cast<f32x4 *>(row + 4 * pq) = pad;
+                }
+            }
+        }
+    };
+    f32x2 vbp[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};    // BOX: box sum of the previous output row minus its oldest input row
     // vertical pass of the output row whose first input row sits in slot u0 -> LDS row `par` (one row per output and term)
     auto vertical = [&](auto u0c, int par) {
         constexpr int u0 = decltype(u0c)::value;
+        if constexpr (BOX) {
+            // term 0, G = 1: the rolling box sum.  Slot u0 = 0 comes round once per U rows: re-seed from the ring there.
+            auto lo2 = [](const f32x4 q) { return f32x2{q.x, q.y}; };
+            auto hi2 = [](const f32x4 q) { return f32x2{q.z, q.w}; };
+            f32x2 vb0, vb1;
+            if constexpr (u0 == 0) {
+                vb0 = lo2(win[0]); vb1 = hi2(win[0]);
+#pragma unroll
+                for (int k = 1; k <= 2 * N; ++k) { vb0 = vb0 + lo2(win[k]); vb1 = vb1 + hi2(win[k]); }
+            } else {
+                vb0 = vbp[0] + lo2(win[(u0 + 2 * N) % R::U]);
+                vb1 = vbp[1] + hi2(win[(u0 + 2 * N) % R::U]);
+            }
+            vbp[0] = vb0 - lo2(win[u0]);                     // the row the next output row no longer sees
+            vbp[1] = vb1 - hi2(win[u0]);
+            const f32x4 vb = f32x4{vb0.x, vb0.y, vb1.x, vb1.y};
+            // term 1, B(y) with B(0) = 0: N folds and N multiply-adds per column pair
+            f32x2 v1[2], f[2][N];
+            auto fold = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const f32x4 a = win[(u0 + k) % R::U], b = win[(u0 + 2 * N - k) % R::U];
+                f[0][k] = lo2(a) + lo2(b);
+                f[1][k] = hi2(a) + hi2(b);
+            };
+            fold(std::integral_constant<int, 0>{});
+            static_for(std::make_integer_sequence<int, N>{}, [&](auto kc) -> bool {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k + 1 < N) fold(std::integral_constant<int, k + 1>{});
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if constexpr (k == 0) v1[c] = pk_mul_sgpr<0>(taps.g[0][1][0], f[c][0]);
+                    else pk_fma_sgpr<(k & 1)>(v1[c], taps.g[0][1][k >> 1], f[c][k]);
+                }
+                return true;
+            });
+            float *row0 = mine + (par * 2 + 0) * R::BUFW, *row1 = mine + (par * 2 + 1) * R::BUFW;
+            const f32x4 q1 = f32x4{v1[0].x, v1[0].y, v1[1].x, v1[1].y};
+            *reinterpret_cast<f32x4 *>(row0 + 4 * R::HL + 4 * lane) = vb;
+            *reinterpret_cast<f32x4 *>(row1 + 4 * R::HL + 4 * lane) = q1;
+            edge_pad(row0, vb);
+            edge_pad(row1, q1);
+            return;
+        }
         // Instruction order matters: the assembler pads an inline-asm result that is consumed within the next two
         // instructions with s_nop, so the fold of tap k+1 is issued before the multiply-adds of tap k and the
         // accumulator chains (2 column pairs x NT terms) are interleaved.
@@ -187,8 +260,11 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
                 return true;
             });
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                *reinterpret_cast<f32x4 *>(wr + ((par * NOUT + o) * NT + t) * R::BUFW) = f32x4{v[t][0].x, v[t][0].y, v[t][1].x, v[t][1].y};
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 q = f32x4{v[t][0].x, v[t][0].y, v[t][1].x, v[t][1].y};
+                *reinterpret_cast<f32x4 *>(wr + ((par * NOUT + o) * NT + t) * R::BUFW) = q;
+                edge_pad(mine + ((par * NOUT + o) * NT + t) * R::BUFW, q);
+            }
             return true;
         });
     };
@@ -214,6 +290,25 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
         for (int q = 0; q < R::NQ; ++q) {
             e[2 * q] = f32x2{hq[u & (NB - 1)][q].x, hq[u & (NB - 1)][q].y};
             e[2 * q + 1] = f32x2{hq[u & (NB - 1)][q].z, hq[u & (NB - 1)][q].w};
+        }
+        if constexpr (BOX && t == 1) {
+            // Q = 1: box sums of the lane's four outputs.  Output j sums window floats lo+j .. hi+j; P = the aligned pairs inside
+            // [lo, hi] (one packed add each, then the two halves), the rest is a sliding correction of single floats.
+            constexpr int lo = R::D, hi = R::D + 2 * N;
+            constexpr int plo = (lo + 1) / 2 * 2, phi = (hi + 1) / 2 * 2;            // aligned pairs plo, plo+2, .. < phi
+            auto wf = [&](int i) -> float { return (i & 1) ? e[i >> 1].y : e[i >> 1].x; };
+            f32x2 ps = e[plo >> 1];
+#pragma unroll
+            for (int i = plo + 2; i + 1 < phi; i += 2) ps = ps + e[i >> 1];
+            float s0 = ps.x + ps.y;
+            if constexpr (lo < plo) s0 += wf(lo);
+            if constexpr (hi >= phi) s0 += wf(hi);
+            const float s1 = s0 + (wf(hi + 1) - wf(lo));
+            const float s2 = s1 + (wf(hi + 2) - wf(lo + 1));
+            const float s3 = s2 + (wf(hi + 3) - wf(lo + 2));
+            r[0] = r[0] + f32x2{s0, s1};
+            r[1] = r[1] + f32x2{s2, s3};
+            return;
         }
         f32x2 pr[2 * N + 3];                                 // pr[j] = window floats (D+j, D+j+1)
 #pragma unroll
@@ -245,7 +340,7 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     // the store of frame row yo of output `o`
     auto store_row = [&](auto oc, const f32x2 (&r)[2], int yo) {
         constexpr int o = decltype(oc)::value;
-        if constexpr (VEC && R::STRAIGHT) {
+        if constexpr (VAR == 1 && R::STRAIGHT) {
             // ONE unconditional store instruction per row: a lane that must not store (strip halo, rows outside the band or the
             // stored range) gets an offset beyond the buffer and the hardware range check drops it.  A store under an `if` is a
             // branch, and behind a branch hipcc no longer knows how many memory operations are in flight: it then waits for
@@ -258,10 +353,13 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
                                                    (int)(col_off + (unsigned)(yo * job.out_stride * 4)), 0, 2 /* nt */);
         } else if (yo >= ylo && yo < yhi && yo < yend) {     // uniform
             float *orow = outs[o] + (long long)yo * job.out_stride;
-            if constexpr (VEC) {
+            if constexpr (VAR == 1) {
                 if (out_lane)
                     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, f32x4{r[0].x, r[0].y, r[1].x, r[1].y}),
                                                 reinterpret_cast<u32x4 *>(orow + c0));
+            } else if (VAR == 2 && out_lane && c0 >= xlo && c0 + 4 <= xhi) {
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, f32x4{r[0].x, r[0].y, r[1].x, r[1].y}),
+                                            reinterpret_cast<u32x4 *>(orow + c0));
             } else if (out_lane) {
                 if (c0 >= xlo && c0 < xhi) orow[c0] = r[0].x;
                 if (c0 + 1 >= xlo && c0 + 1 < xhi) orow[c0 + 1] = r[0].y;
@@ -333,7 +431,20 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #endif
 constexpr int roll_wpb(int n) { (void)n; return SG_ROLL_WPB; }
 
-template <int N, int NT, int NOUT>
+// Strips of a frame.  edge_layout (16-byte aligned rows, cols a multiple of 4 and >= 256): strip 0 starts at column 0 and the last
+// strip ends at the last column, both on vector loads (VAR 2) and storing 256 - 4 HL columns; the inner strips store SW columns
+// each, the last inner one may overlap the right edge strip (the same values are stored twice).  Otherwise strip s stores
+// columns [s SW, s SW + SW) and those that do not lie inside the frame with their halo take the scalar path (VAR 0).
+template <int N>
+__host__ __device__ inline unsigned roll_strips(int cols, bool edge_layout)
+{
+    typedef Roll<N> R;
+    constexpr int EW = 256 - 4 * R::HL;
+    if (!edge_layout) return (unsigned)((cols + R::SW - 1) / R::SW);
+    return 2u + (cols > 2 * EW ? (unsigned)((cols - 2 * EW + R::SW - 1) / R::SW) : 0u);
+}
+
+template <int N, int NT, int NOUT, bool BOX>
 __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
@@ -353,6 +464,7 @@ __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void
     const bool valid = job.boundary == SAVGOL2D_BOUNDARY_VALID;
     const int xlo = valid ? N : 0, xhi = valid ? job.cols - N : job.cols;
     const int ylo = valid ? N : 0, yhi = valid ? job.rows - N : job.rows;
+    const bool edge_layout = (aligned & 4) != 0;
 
     for (unsigned item = blk * WPB + (unsigned)wv; item < total_items; item += nwaves) {
         const unsigned strip = item % strips, ib = item / strips;
@@ -360,17 +472,28 @@ __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void
 #ifdef SG_ROLL_SKIP_EDGE_STRIPS                                   // timing experiment only (wrong frames): what do the frame-edge strips cost?
         if (strip == 0 || strip + 1 == strips) continue;
 #endif
-        const int sx = (int)strip * R::SW, yb = (int)band * band_rows;
+        const int yb = (int)band * band_rows;
         const int nout = job.rows - yb < band_rows ? job.rows - yb : band_rows;
         const float *in = job.in + (long long)img * job.in_pitch;
         float *outs[NOUT];
         outs[0] = job.out + (long long)img * job.out_pitch;
         if constexpr (NOUT > 1) outs[1] = out1 + (long long)img * job.out_pitch;
-        // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
-        if (aligned == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
-            roll_item<N, NT, NOUT, true>(job, taps, mine, in, outs, sx, yb, nout, lane, xlo, xhi, ylo, yhi);
-        else
-            roll_item<N, NT, NOUT, false>(job, taps, mine, in, outs, sx, yb, nout, lane, xlo, xhi, ylo, yhi);
+        // which variant of the item loop this strip runs, and where its 256 loaded columns start
+        int var, xload, side = 0;
+        if (edge_layout) {
+            constexpr int EW = 256 - 4 * R::HL;
+            var = (strip == 0 || strip + 1 == strips) ? 2 : 1;
+            side = strip == 0 ? 0 : 1;
+            xload = strip == 0 ? 0 : (strip + 1 == strips ? job.cols - 256 : EW + ((int)strip - 1) * R::SW - 4 * R::HL);
+        } else {
+            const int sx = (int)strip * R::SW;
+            xload = sx - 4 * R::HL;
+            // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
+            var = ((aligned & 3) == 3 && xload >= 0 && xload + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi) ? 1 : 0;
+        }
+        if (var == 1) roll_item<N, NT, NOUT, 1, BOX>(job, taps, mine, in, outs, xload, 0, yb, nout, lane, xlo, xhi, ylo, yhi);
+        else if (var == 2) roll_item<N, NT, NOUT, 2, BOX>(job, taps, mine, in, outs, xload, side, yb, nout, lane, xlo, xhi, ylo, yhi);
+        else roll_item<N, NT, NOUT, 0, BOX>(job, taps, mine, in, outs, xload, 0, yb, nout, lane, xlo, xhi, ylo, yhi);
     }
 }
 
@@ -416,49 +539,122 @@ static bool fill_taps(RollTaps<N, NT, NOUT> &taps, int o, const float *factors, 
     return true;
 }
 
-template <int N, int NT, int NOUT>
-static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], const float (&scale)[NOUT], float *out1, unsigned images,
-                       int cu_count, hipStream_t st)
+// Additive kernels (see roll_item, BOX): two terms, the first with a constant column factor G_0 and the second with a constant row
+// factor Q_1 -- what sg2d_factors_from_kernel returns for W(x, y) = A(x) + B(y): its G_0 is the normalised constant and, A being
+// orthogonal to G_1, Q_1 = sum_y G_1 B is the same for every x.  Rewritten as A'(x) + B'(y) with B'(0) = 0:
+//      A'(x) = scale (g0 Q_0(x) + G_1(0) q1),   B'(y) = scale q1 (G_1(y) - G_1(0)).
+template <int N>
+static bool fill_box_taps(RollTaps<N, 2, 1> &taps, const float *factors, float scale)
+{
+    const float *q0 = factors, *g0 = q0 + (2 * N + 2), *q1 = g0 + (2 * N + 2), *g1 = q1 + (2 * N + 2);
+    auto constant = [](const float *v) {
+        float lo = v[0], hi = v[0];
+        for (int k = 1; k <= 2 * N; ++k) { lo = fminf(lo, v[k]); hi = fmaxf(hi, v[k]); }
+        return hi - lo <= 4e-6f * fmaxf(fabsf(lo), fabsf(hi)) && lo != 0.0f;
+    };
+    float s1, s2;
+    if (!constant(g0) || !constant(q1) || !vector_parity(q0, N, &s1) || !vector_parity(g1, N, &s2) || s1 != 1.0f || s2 != 1.0f) return false;
+    double g0c = 0.0, q1c = 0.0;
+    for (int k = 0; k <= 2 * N; ++k) { g0c += g0[k]; q1c += q1[k]; }
+    g0c /= 2 * N + 1; q1c /= 2 * N + 1;
+    for (int k = 0; k <= N; ++k) {
+        // symmetric vectors: average the two halves (they differ in the last bit of the float factors)
+        const double qa = 0.5 * ((double)q0[k] + (double)q0[2 * N - k]), ga = 0.5 * ((double)g1[k] + (double)g1[2 * N - k]);
+        const float a = (float)((double)scale * (g0c * qa + (double)g1[N] * q1c));
+        const float b = (float)((double)scale * q1c * (ga - (double)g1[N]));
+        if (k & 1) { taps.q[0][0][k >> 1].y = a; taps.g[0][1][k >> 1].y = b; }
+        else       { taps.q[0][0][k >> 1].x = a; taps.g[0][1][k >> 1].x = b; }
+    }
+    taps.sy[0] = f32x2{1.0f, 1.0f};
+    taps.sx[0] = f32x2{1.0f, 1.0f};
+    return true;
+}
+
+static int roll_box_env()                                   // SAVGOL_HIP_ROLL_BOX=0: additive kernels run the general two-term form (A/B runs)
+{
+    static const int v = [] { const char *e = getenv("SAVGOL_HIP_ROLL_BOX"); return e ? atoi(e) : 1; }();
+    return v;
+}
+static int roll_edge_env()                                  // SAVGOL_HIP_ROLL_EDGE=0: round 2's strip layout (frame-edge strips on scalar loads)
+{
+    static const int v = [] { const char *e = getenv("SAVGOL_HIP_ROLL_EDGE"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+template <int N, int NT, int NOUT, bool BOX>
+static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *out1, unsigned images, int cu_count, hipStream_t st)
 {
     typedef Roll<N> R;
-    RollTaps<N, NT, NOUT> taps;
-    memset(&taps, 0, sizeof(taps));
-    for (int o = 0; o < NOUT; ++o)
-        if (!fill_taps<N, NT, NOUT>(taps, o, factors[o], scale[o])) return 1;
-
-    const unsigned strips = (unsigned)((job.cols + R::SW - 1) / R::SW);
-    static int per_cu = 0;                                   // resident blocks per CU of this instantiation
-    constexpr unsigned WPB = (unsigned)roll_wpb(N);
-    const size_t lds = sizeof(float) * WPB * 2 * NOUT * NT * R::BUFW;
-    if (per_cu == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT>, 64 * WPB, lds) != hipSuccess || nb < 1)
-            nb = WPB <= 8 ? 2 : 1;
-        per_cu = nb > (int)(16 / WPB) ? (int)(16 / WPB) : nb;
-    }
-    const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * WPB;
-    unsigned bands = choose_bands(job.rows, (unsigned long long)images * strips, nwaves, N, 0.3);   // warm-up rows are only loaded
-    static const char *env_bands = getenv("SAVGOL_HIP_ROLL_BANDS"), *env_one = getenv("SAVGOL_HIP_ROLL_ONEWAVE");     // tuning knobs
-    if (env_bands && atoi(env_bands) > 0 && atoi(env_bands) <= job.rows) bands = (unsigned)atoi(env_bands);
-    const int band_rows = (int)((job.rows + (int)bands - 1) / (int)bands);
-    bands = (unsigned)((job.rows + band_rows - 1) / band_rows);
-    const unsigned long long total = (unsigned long long)images * strips * bands;     // caller keeps this < 2^32
-    // One item per wave, blocks handed out by the hardware dispatcher in order -- as in the 1-D kernel, and for the same reason: the
-    // same items and bands on a persistent grid (resident waves striding over the items) are 1-5 % slower at every half window
-    // (n = 4: 1.89 vs 1.79 ms per 64 frames).  SAVGOL_HIP_ROLL_ONEWAVE=0 brings the persistent grid back for A/B runs; the band
-    // count is still chosen for whole rounds of the resident waves, which is also what keeps the tail of the dispatch short.
-    const bool persistent = env_one && atoi(env_one) == 0;
-    unsigned grid = persistent ? (unsigned)cu_count * (unsigned)per_cu : (unsigned)((total + WPB - 1) / WPB);
-    if ((unsigned long long)grid * WPB > total) grid = (unsigned)((total + WPB - 1) / WPB);
-    grid = (grid + 7u) & ~7u;
     int aligned = 0;
     if (job.in_stride % 4 == 0 && job.in_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.in) & 15u) == 0) aligned |= 1;
     if (job.out_stride % 4 == 0 && job.out_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.out) & 15u) == 0 &&
         (NOUT == 1 || (reinterpret_cast<uintptr_t>(out1) & 15u) == 0) &&
         (long long)job.rows * job.out_stride * 4 < 0x7fffff00ll) aligned |= 2;       // the store descriptor holds a 31-bit byte count
-    hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT>), dim3(grid), dim3(64 * WPB), lds, st, job, taps, out1, strips, bands, band_rows,
-                       (unsigned)total, aligned);
+    const bool edge_layout = aligned == 3 && job.cols % 4 == 0 && job.cols >= 256 && roll_edge_env() != 0;
+    if (edge_layout) aligned |= 4;
+    const unsigned strips = roll_strips<N>(job.cols, edge_layout);
+    static int per_cu = 0;                                   // resident blocks per CU of this instantiation
+    constexpr unsigned WPB = (unsigned)roll_wpb(N);
+    const size_t lds = sizeof(float) * WPB * 2 * NOUT * NT * R::BUFW;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT, BOX>, 64 * WPB, lds) != hipSuccess || nb < 1)
+            nb = WPB <= 8 ? 2 : 1;
+        per_cu = nb > (int)(16 / WPB) ? (int)(16 / WPB) : nb;
+    }
+    const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * WPB;
+    static const char *env_bands = getenv("SAVGOL_HIP_ROLL_BANDS"), *env_one = getenv("SAVGOL_HIP_ROLL_ONEWAVE");     // tuning knobs
+    // One item per wave, blocks handed out by the hardware dispatcher in order -- as in the 1-D kernel, and for the same reason: the
+    // same items and bands on a persistent grid (resident waves striding over the items) are 1-5 % slower at every half window
+    // (n = 4: 1.89 vs 1.79 ms per 64 frames).  SAVGOL_HIP_ROLL_ONEWAVE=0 brings the persistent grid back for A/B runs; the band
+    // count is still chosen for whole rounds of the resident waves, which is also what keeps the tail of the dispatch short.
+    const bool persistent = env_one && atoi(env_one) == 0;
+    // a launch indexes < 2^32 threads (HIP rejects gridDim.x * blockDim.x >= 2^32) and < 2^32 items: split over images
+    unsigned long long per_image;
+    unsigned bands;
+    int band_rows;
+    auto geometry = [&](unsigned long long imgs) {
+        bands = choose_bands(job.rows, imgs * strips, nwaves, N, 0.3);       // warm-up rows are only loaded
+        if (env_bands && atoi(env_bands) > 0 && atoi(env_bands) <= job.rows) bands = (unsigned)atoi(env_bands);
+        band_rows = (int)((job.rows + (int)bands - 1) / (int)bands);
+        bands = (unsigned)((job.rows + band_rows - 1) / band_rows);
+        per_image = (unsigned long long)strips * bands;
+    };
+    geometry(images);
+    const unsigned long long max_items = ((1ull << 32) - 4096) / 64;           // items == waves when not persistent
+    unsigned long long img_step = per_image ? max_items / per_image : images;
+    if (img_step == 0) { sg_set_error("2-D frame too large for one launch (%llu items)", per_image); return -1; }
+    if (img_step < images) geometry(img_step); else img_step = images;
+    for (unsigned long long i0 = 0; i0 < images; i0 += img_step) {
+        const unsigned long long ni = images - i0 < img_step ? images - i0 : img_step;
+        const unsigned long long total = ni * per_image;
+        unsigned grid = persistent ? (unsigned)cu_count * (unsigned)per_cu : (unsigned)((total + WPB - 1) / WPB);
+        if ((unsigned long long)grid * WPB > total) grid = (unsigned)((total + WPB - 1) / WPB);
+        grid = (grid + 7u) & ~7u;
+        Job2D part = job;
+        part.in = job.in + (long long)i0 * job.in_pitch;
+        part.out = job.out + (long long)i0 * job.out_pitch;
+        hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT, BOX>), dim3(grid), dim3(64 * WPB), lds, st, part, taps,
+                           out1 ? out1 + (long long)i0 * job.out_pitch : nullptr, strips, bands, band_rows, (unsigned)total, aligned);
+    }
     return 0;
+}
+
+template <int N, int NT, int NOUT>
+static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], const float (&scale)[NOUT], float *out1, unsigned images,
+                       int cu_count, hipStream_t st)
+{
+    if constexpr (NT == 2 && NOUT == 1) {
+        RollTaps<N, 2, 1> box;
+        memset(&box, 0, sizeof(box));
+        if (roll_box_env() != 0 && fill_box_taps<N>(box, factors[0], scale[0]))
+            return launch_roll_kernel<N, 2, 1, true>(job, box, out1, images, cu_count, st);
+    }
+    RollTaps<N, NT, NOUT> taps;
+    memset(&taps, 0, sizeof(taps));
+    for (int o = 0; o < NOUT; ++o)
+        if (!fill_taps<N, NT, NOUT>(taps, o, factors[o], scale[o])) return 1;
+    return launch_roll_kernel<N, NT, NOUT, false>(job, taps, out1, images, cu_count, st);
 }
 
 template <int N, int NT>

@@ -212,7 +212,7 @@ static int dispatch_block(int n, const float *ring, const float *samples, float 
 // One tick with every load in flight at once: half window known at compile time, so the 2n ring rows a stream needs
 // are 2n independent loads (the newest sample comes straight from `samples`), then the strictly ordered multiply-add
 // chain.  The generic kernel above waits for the ring in batches of 8.
-template <int N>
+template <int N, bool FMA>
 __global__ __launch_bounds__(256) void sg_bank_tick_n_kernel(float *__restrict__ ring, const float *__restrict__ samples,
                                                              float *__restrict__ out, size_t streams, const StreamTaps taps,
                                                              int wp_old, float dt_inv)
@@ -232,21 +232,37 @@ __global__ __launch_bounds__(256) void sg_bank_tick_n_kernel(float *__restrict__
     }
     v[WS - 1] = xnew;
     float acc = 0.0f;
+    if constexpr (FMA) {
+        // SAVGOL_STREAMBANK_FMA: fused multiply-adds on two chains (even taps, odd taps), as the block-push kernel's fast form
+        float odd = __fmul_rn(taps.w[1], v[1]);
+        acc = __fmul_rn(taps.w[0], v[0]);
 #pragma unroll
-    for (int i = 0; i < WS; ++i) acc = __fadd_rn(acc, __fmul_rn(taps.w[i], v[i]));
+        for (int i = 2; i < WS; ++i) {
+            if (i & 1) odd = __fmaf_rn(taps.w[i], v[i], odd);
+            else       acc = __fmaf_rn(taps.w[i], v[i], acc);
+        }
+        acc = __fadd_rn(acc, odd);
+    } else {
+#pragma unroll
+        for (int i = 0; i < WS; ++i) acc = __fadd_rn(acc, __fmul_rn(taps.w[i], v[i]));
+    }
     out[s] = __fmul_rn(acc, dt_inv);
 }
 
 template <int N>
-static int dispatch_tick(int n, float *ring, const float *samples, float *out, size_t streams, const StreamTaps &taps, int wp_old,
+static int dispatch_tick(int n, bool fma, float *ring, const float *samples, float *out, size_t streams, const StreamTaps &taps, int wp_old,
                          float dt_inv, hipStream_t st)
 {
     if (n == N) {
-        hipLaunchKernelGGL((sg_bank_tick_n_kernel<N>), dim3((unsigned)((streams + 255) / 256)), dim3(256), 0, st, ring, samples, out,
-                           streams, taps, wp_old, dt_inv);
+        if (fma)
+            hipLaunchKernelGGL((sg_bank_tick_n_kernel<N, true>), dim3((unsigned)((streams + 255) / 256)), dim3(256), 0, st, ring, samples, out,
+                               streams, taps, wp_old, dt_inv);
+        else
+            hipLaunchKernelGGL((sg_bank_tick_n_kernel<N, false>), dim3((unsigned)((streams + 255) / 256)), dim3(256), 0, st, ring, samples, out,
+                               streams, taps, wp_old, dt_inv);
         return 1;
     }
-    if constexpr (N < SAVGOL_MAX_HALF_WINDOW) return dispatch_tick<N + 1>(n, ring, samples, out, streams, taps, wp_old, dt_inv, st);
+    if constexpr (N < SAVGOL_MAX_HALF_WINDOW) return dispatch_tick<N + 1>(n, fma, ring, samples, out, streams, taps, wp_old, dt_inv, st);
     else return 0;
 }
 
@@ -529,7 +545,13 @@ extern "C" {
 
 SavgolStreamBank *savgol_streambank_create(const SavgolConfig *config, size_t streams)
 {
+    return savgol_streambank_create_ex(config, streams, 0u);
+}
+
+SavgolStreamBank *savgol_streambank_create_ex(const SavgolConfig *config, size_t streams, unsigned flags)
+{
     if (!config || streams == 0) { sg_set_error("savgol_streambank_create: bad arguments"); return nullptr; }
+    if (flags & ~(unsigned)SAVGOL_STREAMBANK_FMA) { sg_set_error("savgol_streambank_create_ex: unknown flags 0x%x", flags); return nullptr; }
     SavgolFilter *f = savgol_create(config);
     if (!f) { sg_set_error("savgol_streambank_create: invalid configuration"); return nullptr; }
     sg::DeviceCtx *ctx = sg::ctx_get();
@@ -540,6 +562,7 @@ SavgolStreamBank *savgol_streambank_create(const SavgolConfig *config, size_t st
     b->streams = streams;
     b->device = ctx->ordinal;
     b->dt_inv = sg::dt_inverse(f);
+    b->flags = flags;
     b->d_table = sg::filter_table(ctx, f);
     b->trail_base = sg::trailing_row_base(f);             // the option is read once, here
     const size_t bytes = sizeof(float) * (size_t)f->window_size * streams;
@@ -581,7 +604,7 @@ int savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float
         sg::StreamTaps taps;
         memset(&taps, 0, sizeof(taps));
         memcpy(taps.w, bank->filter->center_weights, sizeof(float) * ws);
-        sg::dispatch_tick<1>(bank->filter->config.half_window, bank->d_ring, d_samples, d_out, bank->streams, taps, bank->wp,
+        sg::dispatch_tick<1>(bank->filter->config.half_window, (bank->flags & SAVGOL_STREAMBANK_FMA) != 0, bank->d_ring, d_samples, d_out, bank->streams, taps, bank->wp,
                              bank->dt_inv, static_cast<hipStream_t>(stream));
     } else {
         hipLaunchKernelGGL(sg::sg_bank_tick_kernel, dim3(sg::bank_blocks(bank)), dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -642,7 +665,7 @@ int savgol_streambank_push_block(SavgolStreamBank *bank, const float *d_samples,
     if (!ctx) return -1;
     if (method_env() != 1 &&
         sg::sg_bank_roll_launch(bank->filter->config.half_window, bank->filter->center_weights, bank->d_ring, d_samples, d_out,
-                                bank->streams, bank->wp, bank->received, ticks, bank->dt_inv, ctx->cu_count, st) == 0) {
+                                bank->streams, bank->wp, bank->received, ticks, bank->dt_inv, (bank->flags & SAVGOL_STREAMBANK_FMA) ? 1 : 0, ctx->cu_count, st) == 0) {
         // rolling-window kernel (n <= 16) wrote the outputs; the newest samples still have to reach the ring
         hipLaunchKernelGGL(sg::sg_bank_store_tail_kernel, dim3((unsigned)((bank->streams + 255) / 256), 8), dim3(256), 0, st,
                            bank->d_ring, d_samples, bank->streams, ws, bank->wp, ticks);

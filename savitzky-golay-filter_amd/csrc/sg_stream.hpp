@@ -20,6 +20,7 @@ struct SavgolStreamBank {
     unsigned long long received, emitted;
     float         dt_inv;
     void         *service;           // sg::BankService while savgol_streambank_service_* is active, else NULL
+    unsigned      flags;             // SAVGOL_STREAMBANK_* of savgol_streambank_create_ex
 };
 
 namespace sg {
@@ -32,6 +33,6 @@ constexpr int STREAM_ROLL_MAX_N = 32;   // the rolling block-push kernel covers 
 // sg_stream_roll.hip: `ticks` pushes of every stream in one launch, outputs only (the caller updates the ring).
 // 0 = launched, 1 = not covered (ticks >= 2^31): use the LDS-tiled kernel of sg_stream.hip.
 int sg_bank_roll_launch(int n, const float *center_weights, const float *ring, const float *samples, float *out, size_t streams,
-                        int wp0, unsigned long long received0, size_t ticks, float dt_inv, int cu_count, hipStream_t st);
+                        int wp0, unsigned long long received0, size_t ticks, float dt_inv, int fma, int cu_count, hipStream_t st);
 
 }  // namespace sg

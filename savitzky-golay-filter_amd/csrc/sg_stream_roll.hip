@@ -51,7 +51,7 @@ struct BankJob {
 
 // One item: streams s0, s0+1 of every lane, output ticks t0 .. t0+nt-1.  Row r of the band = history index
 // t0 - 2N + r; output tick m needs rows m .. m+2N, row r lives in ring slot r % U.
-template <int N, bool VEC>
+template <int N, bool VEC, bool FMA>
 __device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTaps<N> &taps, size_t s0, size_t t0, int nt)
 {
     typedef SRoll<N> R;
@@ -78,6 +78,20 @@ __device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTa
             // sum = 0; sum += w[k] * x[k], k ascending, separate roundings.  The product of tap k+1 is issued before
             // the add of tap k so that no instruction consumes the result of the one just before it.
             f32x2 acc = f32x2{0.0f, 0.0f};
+            if constexpr (FMA) {
+                // the fast form (SAVGOL_STREAMBANK_FMA): one v_pk_fma_f32 per tap instead of a multiply and an add -- half the
+                // vector instructions.  Two chains (even taps, odd taps) so that no multiply-add waits for the one just before it;
+                // not the reference's rounding (one rounding per term, two partial sums): within 1e-6 / 2e-6 of the fp64 oracle.
+                f32x2 odd = pk_mul_sgpr<1>(taps.w[0], win[(u + 1) % R::U]);
+                acc = pk_mul_sgpr<0>(taps.w[0], win[u % R::U]);
+                static_for(std::make_integer_sequence<int, R::WS - 2>{}, [&](auto kc) -> bool {
+                    constexpr int k = decltype(kc)::value + 2;
+                    if constexpr (k & 1) pk_fma_sgpr<1>(odd, taps.w[k >> 1], win[(u + k) % R::U]);
+                    else                 pk_fma_sgpr<0>(acc, taps.w[k >> 1], win[(u + k) % R::U]);
+                    return true;
+                });
+                acc = acc + odd;
+            } else {
             f32x2 p = pk_mul_sgpr<0>(taps.w[0], win[u % R::U]);
             static_for(std::make_integer_sequence<int, R::WS>{}, [&](auto kc) -> bool {
                 constexpr int k = decltype(kc)::value;
@@ -87,6 +101,7 @@ __device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTa
                 p = pn;
                 return true;
             });
+            }
             const size_t t = t0 + (size_t)m;
             if (job.received0 + t + 1 >= (unsigned long long)R::WS) {            // uniform: an output exists (reference :166-170)
                 const f32x2 y = acc * f32x2{job.dt_inv, job.dt_inv};
@@ -104,7 +119,7 @@ __device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTa
 // holds the output that has seen a samples so far; an arriving sample is tap a for slot a, and the add writes its sum
 // into slot a+1 (walked from the top down, so that slot is already drained): every output still adds its taps in
 // ascending order onto 0, with separate roundings -- and the tick loop is 2(2N+1) instructions, not unrolled.
-template <int N, bool VEC>
+template <int N, bool VEC, bool FMA>
 __device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRollTaps<N> &taps, size_t s0, size_t t0, int nt)
 {
     typedef SRoll<N> R;
@@ -135,6 +150,20 @@ __device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRol
         f32x2 done;
         static_for<R::WS>([&](auto ic) -> bool {
             constexpr int a = R::WS - 1 - decltype(ic)::value;   // slot = tap index, 2N down to 0
+            if constexpr (FMA) {
+                // fast form: slot a+1 = tap a * x + slot a in ONE instruction (the chain of an output stays a single chain)
+                if constexpr (a == 0) {
+                    acc[1] = pk_mul_sgpr<0>(taps.w[0], x);
+                } else if constexpr (a == R::WS - 1) {
+                    done = acc[a];
+                    pk_fma_sgpr<(a & 1)>(done, taps.w[a >> 1], x);
+                } else {
+                    // acc[a + 1] = fma(w[a], x, acc[a]); three-address form so that the walk from the top down needs no copy
+                    if constexpr ((a & 1) == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(acc[a + 1]) : "s"(taps.w[a >> 1]), "v"(x), "v"(acc[a]));
+                    else                        asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(acc[a + 1]) : "s"(taps.w[a >> 1]), "v"(x), "v"(acc[a]));
+                }
+                return true;
+            }
             f32x2 p;
             if constexpr ((a & 1) == 0) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(taps.w[a >> 1]), "v"(x));
             else                        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(p) : "s"(taps.w[a >> 1]), "v"(x));
@@ -153,7 +182,7 @@ __device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRol
     }
 }
 
-template <int N>
+template <int N, bool FMA>
 __global__ __launch_bounds__(256) void sg_bank_roll_kernel(const BankJob job, const SRollTaps<N> taps)
 {
     const int lane = threadIdx.x & 63;
@@ -169,14 +198,14 @@ __global__ __launch_bounds__(256) void sg_bank_roll_kernel(const BankJob job, co
         const int nt = job.ticks - t0 < (size_t)job.band_ticks ? (int)(job.ticks - t0) : job.band_ticks;
         const bool vec = job.aligned && (size_t)strip * 128 + 128 <= job.streams;
         if constexpr (N <= STREAM_RING_MAX_N) {
-            if (vec) bank_roll_item<N, true>(job, taps, s0, t0, nt); else bank_roll_item<N, false>(job, taps, s0, t0, nt);
+            if (vec) bank_roll_item<N, true, FMA>(job, taps, s0, t0, nt); else bank_roll_item<N, false, FMA>(job, taps, s0, t0, nt);
         } else {
-            if (vec) bank_accroll_item<N, true>(job, taps, s0, t0, nt); else bank_accroll_item<N, false>(job, taps, s0, t0, nt);
+            if (vec) bank_accroll_item<N, true, FMA>(job, taps, s0, t0, nt); else bank_accroll_item<N, false, FMA>(job, taps, s0, t0, nt);
         }
     }
 }
 
-template <int N>
+template <int N, bool FMA>
 static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipStream_t st)
 {
     typedef SRoll<N> R;
@@ -188,7 +217,7 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
     static int per_cu = 0;                                   // resident blocks per CU of this instantiation
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg_bank_roll_kernel<N>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg_bank_roll_kernel<N, FMA>, 256, 0) != hipSuccess || nb < 1) nb = 2;
         per_cu = nb > 4 ? 4 : nb;
     }
     const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
@@ -205,28 +234,28 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
     grid = (grid + 7u) & ~7u;
     job.aligned = (job.streams % 2 == 0 && ((reinterpret_cast<uintptr_t>(job.samples) | reinterpret_cast<uintptr_t>(job.out) |
                                               reinterpret_cast<uintptr_t>(job.ring)) & 7u) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((sg_bank_roll_kernel<N>), dim3(grid), dim3(256), 0, st, job, taps);
+    hipLaunchKernelGGL((sg_bank_roll_kernel<N, FMA>), dim3(grid), dim3(256), 0, st, job, taps);
     return 0;
 }
 
 template <int N>
-static int dispatch_bank_roll(int n, const float *center, const BankJob &job, int cu_count, hipStream_t st)
+static int dispatch_bank_roll(int n, int fma, const float *center, const BankJob &job, int cu_count, hipStream_t st)
 {
-    if (n == N) return launch_bank_roll<N>(center, job, cu_count, st);
-    if constexpr (N < STREAM_ROLL_MAX_N) return dispatch_bank_roll<N + 1>(n, center, job, cu_count, st);
+    if (n == N) return fma ? launch_bank_roll<N, true>(center, job, cu_count, st) : launch_bank_roll<N, false>(center, job, cu_count, st);
+    if constexpr (N < STREAM_ROLL_MAX_N) return dispatch_bank_roll<N + 1>(n, fma, center, job, cu_count, st);
     else return 1;
 }
 
 // 0 = launched, 1 = half window not covered (the caller uses the LDS-tiled kernel).  ticks per call < 2^31 * band.
 int sg_bank_roll_launch(int n, const float *center_weights, const float *ring, const float *samples, float *out, size_t streams,
-                        int wp0, unsigned long long received0, size_t ticks, float dt_inv, int cu_count, hipStream_t st)
+                        int wp0, unsigned long long received0, size_t ticks, float dt_inv, int fma, int cu_count, hipStream_t st)
 {
     if (n < 1 || n > STREAM_ROLL_MAX_N || ticks == 0 || ticks > (size_t)0x7fffffff) return 1;
     BankJob job;
     memset(&job, 0, sizeof(job));
     job.ring = ring; job.samples = samples; job.out = out;
     job.streams = streams; job.ticks = ticks; job.received0 = received0; job.wp0 = wp0; job.dt_inv = dt_inv;
-    return dispatch_bank_roll<1>(n, center_weights, job, cu_count, st);
+    return dispatch_bank_roll<1>(n, fma, center_weights, job, cu_count, st);
 }
 
 }  // namespace sg

@@ -432,3 +432,48 @@ def test_opt_in_boundary_aware_streams_match_the_batch_filter(sg, sgo, torch_gpu
         L.savgol_streambank_destroy(bank.ptr); bank.ptr = None
     finally:
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_BOUNDARY_AWARE, 0)
+
+
+@pytest.mark.parametrize("n,m,d,dt", [(16, 2, 1, 1e-3), (5, 3, 0, 1.0), (1, 0, 0, 1.0), (17, 4, 2, 0.5), (32, 4, 0, 1.0), (24, 3, 1, 2.0)])
+def test_fma_bank_is_within_the_fp32_bar_of_the_fp64_oracle(sg, sgo, torch_gpu, n, m, d, dt):
+    """SAVGOL_STREAMBANK_FMA (savgol_streambank_create_ex): block push (sample ring n <= 16, accumulator ring above) and the
+    per-tick kernel with fused multiply-adds.  Not the reference's bits; the bar is the 1-D batch path's: <= 1e-6 (smoothing) /
+    2e-6 (derivatives) normwise of the double-accumulation oracle -- and never worse than the reference-order bank on the same
+    samples by more than that bar.  Edge rows keep the reference's order: push_full's burst and the flushes stay bit-exact."""
+    torch = torch_gpu
+    for S, off in ((65536 if n == 16 else 4096, 0), (777, 1)):
+        T = 12 * (2 * n + 1) + 5
+        g = torch.Generator(device="cuda").manual_seed(n * 77 + S)
+        flat = torch.randn(T * S + 4, generator=g, device="cuda", dtype=torch.float32)
+        xd = flat[off:off + T * S].view(T, S)
+        fast = sg.StreamBank(S, n, m, d, dt, fma=True)
+        ref = sg.StreamBank(S, n, m, d, dt)
+        got = torch.full((T, S), float("nan"), device="cuda")
+        want = torch.full((T, S), float("nan"), device="cuda")
+        cut = 3 * n + 1                                           # first call ends inside / after the filling phase
+        assert fast.push_block(xd, cut, got) + fast.push_block(xd[cut:], T - cut, got[cut:]) == T - 2 * n
+        assert ref.push_block(xd, T, want) == T - 2 * n
+        torch.cuda.synchronize()
+        assert torch.isnan(got[:2 * n]).all()
+        pick = [0, 1, S // 2, S - 1]
+        xh = xd[:, pick].cpu().numpy().astype(np.float64).T.copy()              # [stream][tick]
+        ref64 = sgo.Filter(n, m, d, dt).apply_f64(xh)[:, n:T - n]                  # centre outputs of tick t = batch output t - n
+        bar = 1e-6 if d == 0 else 2e-6
+        e_fast = normwise(got[2 * n:, pick].cpu().numpy().T, ref64)
+        e_ref = normwise(want[2 * n:, pick].cpu().numpy().T, ref64)
+        assert e_fast <= max(bar, e_ref), (n, S, e_fast, e_ref)
+        # whole banks: the two summations agree to the bar everywhere, and do differ somewhere (the flag selects another kernel)
+        assert normwise(got[2 * n:].cpu().numpy(), want[2 * n:].cpu().numpy()) <= 2 * bar
+        if n >= 5:
+            assert not torch.equal(got[2 * n:], want[2 * n:])
+        # per-tick pushes of the fast bank continue the sequence with the same bar
+        o1 = torch.zeros(S, dtype=torch.float32, device="cuda")
+        o2 = torch.zeros(S, dtype=torch.float32, device="cuda")
+        for t in range(4):
+            assert fast.push(xd[t], o1) == 1 and ref.push(xd[t], o2) == 1
+            assert normwise(o1.cpu().numpy(), o2.cpu().numpy()) <= 2 * bar
+        # edge rows stay in the reference's order
+        e1 = torch.zeros((n, S), dtype=torch.float32, device="cuda"); e2 = torch.zeros_like(e1)
+        assert fast.flush(e1, n) == ref.flush(e2, n) == n
+        assert torch.equal(e1.view(torch.int32), e2.view(torch.int32))
+    assert sg.lib().savgol_streambank_create_ex(None, 4, 1) is None

@@ -8,8 +8,8 @@ import torch
 S, T = 65536, 4096
 x = torch.randn((T, S), device="cuda")
 out = torch.empty_like(x)
-for n in (4, 8, 16, 17, 24, 32):
-    bank = sg.StreamBank(S, n, 2, 1, 1e-3)
+for n, fma in [(n, f) for n in (4, 8, 16, 17, 24, 32) for f in (False, True)]:
+    bank = sg.StreamBank(S, n, 2, 1, 1e-3, fma=fma)
     bank.push_block(x, T, out); torch.cuda.synchronize()
     ts = []
     for _ in range(5):
@@ -17,4 +17,4 @@ for n in (4, 8, 16, 17, 24, 32):
         e0.record(); bank.push_block(x, T, out); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     ms = min(ts)
-    print(f"n={n:2d}: {ms:.3f} ms per {T} ticks x {S} streams = {S*T/ms/1e6:.0f} Gsamples/s, {8*S*T/ms/1e6:.0f} GB/s")
+    print(f"n={n:2d} fma={int(fma)}: {ms:.3f} ms per {T} ticks x {S} streams = {S*T/ms/1e6:.0f} Gsamples/s, {8*S*T/ms/1e6:.0f} GB/s")
