@@ -79,6 +79,13 @@ enum { SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE = 1, SAVGOL_HIP_OPT_REFERENCE_SUMMATI
  *   <= 18, fp64 <= 24).  0 (default): by job size -- the 12 / 16 KiB tile from 16384 tiles up, the 8 KiB tile below; 1: always the
  *   8 KiB tile; 2: always the wide one.  Same bits per output either way; a tuning and test knob.                                */
 int         savgol_hip_set_option(int option, int value);
+/* The same switches PER CALL: the *_ex forms of the 1-D device entry points take them as flags, so two threads (or two
+ * calls) can run different summation orders or tile widths at the same time; the options above are only the DEFAULTS the
+ * non-_ex entry points use (savgol_hip_default_flags() returns them as flags).  A flag word is complete: an _ex call
+ * ignores the process-wide options.  TILE_NARROW and TILE_WIDE exclude each other; neither = by job size.               */
+enum { SAVGOL_BATCH_REFERENCE_SUMMATION = 1u, SAVGOL_BATCH_PLAIN_SUMMATION = 2u, SAVGOL_BATCH_TILE_NARROW = 4u, SAVGOL_BATCH_TILE_WIDE = 8u,
+       SAVGOL_BATCH_CORRECT_LEADING_EDGE = 16u, SAVGOL_BATCH_BOUNDARY_AWARE = 32u /* strided calls only */ };
+unsigned    savgol_hip_default_flags(void);
 /* Diagnostic (host only, no device needed): the constant table the wide-window (24..32) fp32 kernel reads -- SAVGOL_HIP_MOMENT_TABLE_FLOATS
  * floats: centre taps [0,66), block basis phi[s-1][t] at [80,176), own-block coefficients c[s][J][2] at [176,400); layout in
  * csrc/sg_k1d_host.hpp.  Returns the number of block moments the kernel will use (3, 5 or 7), 0 when the filter runs the
@@ -99,7 +106,8 @@ long savgol_export_header(const SavgolFilter *filter, const char *prefix, const 
  * Arithmetic of savgol_apply (reference src/savgolFilter.c:743-804): centre taps on the
  * interior, filter->config.boundary on the first/last n samples (POLYNOMIAL rows incl. the
  * reference's reversed leading edge; REFLECT / PERIODIC / CONSTANT by index remap).
- * d_in and d_out must not overlap (checked: -1).  length >= 2n+1, and any size_t beyond that, like the
+ * No row of d_in may share a byte with a row of d_out (checked: -1); interleaved layouts whose rows stay apart are fine
+ * (in = buf[:, 0, :], out = buf[:, 1, :] with equal pitches).  length >= 2n+1, and any size_t beyond that, like the
  * reference's: a channel longer than 2^30 samples is enqueued as sub-rows of 2^29 outputs plus its two
  * ends (same arithmetic per output; a little stream-ordered scratch for the ends).
  * f32: fp32 tables, fp32 FMA accumulation (within 1e-6 normwise of the fp64 oracle).
@@ -113,6 +121,12 @@ int savgol_apply_batch_f32(const SavgolFilter *filter, const float *d_in, float 
 int savgol_apply_batch_f64(const SavgolFilter *filter, const double *d_in, double *d_out,
                            size_t channels, size_t length, size_t in_ld, size_t out_ld,
                            void *stream);
+int savgol_apply_batch_f32_ex(const SavgolFilter *filter, const float *d_in, float *d_out,
+                              size_t channels, size_t length, size_t in_ld, size_t out_ld,
+                              unsigned flags, void *stream);
+int savgol_apply_batch_f64_ex(const SavgolFilter *filter, const double *d_in, double *d_out,
+                              size_t channels, size_t length, size_t in_ld, size_t out_ld,
+                              unsigned flags, void *stream);
 /* savgol_apply_valid (:821-850) per channel: writes length-2n samples at d_out[c*out_ld + 0..] */
 int savgol_apply_valid_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out,
                                  size_t channels, size_t length, size_t in_ld, size_t out_ld,
@@ -120,12 +134,22 @@ int savgol_apply_valid_batch_f32(const SavgolFilter *filter, const float *d_in, 
 int savgol_apply_valid_batch_f64(const SavgolFilter *filter, const double *d_in, double *d_out,
                                  size_t channels, size_t length, size_t in_ld, size_t out_ld,
                                  void *stream);
+int savgol_apply_valid_batch_f32_ex(const SavgolFilter *filter, const float *d_in, float *d_out,
+                                    size_t channels, size_t length, size_t in_ld, size_t out_ld,
+                                    unsigned flags, void *stream);
+int savgol_apply_valid_batch_f64_ex(const SavgolFilter *filter, const double *d_in, double *d_out,
+                                    size_t channels, size_t length, size_t in_ld, size_t out_ld,
+                                    unsigned flags, void *stream);
 /* savgol_apply_strided (:877-934) on device memory: element i of channel c is the float at
  * (char*)base + c*channel_pitch + i*stride + offset (bytes).  Edges are always POLYNOMIAL.     */
 int savgol_apply_strided_batch_f32(const SavgolFilter *filter,
                                    const void *d_in, size_t in_stride, size_t in_offset, size_t in_channel_pitch,
                                    void *d_out, size_t out_stride, size_t out_offset, size_t out_channel_pitch,
                                    size_t channels, size_t count, void *stream);
+int savgol_apply_strided_batch_f32_ex(const SavgolFilter *filter,
+                                      const void *d_in, size_t in_stride, size_t in_offset, size_t in_channel_pitch,
+                                      void *d_out, size_t out_stride, size_t out_offset, size_t out_channel_pitch,
+                                      size_t channels, size_t count, unsigned flags, void *stream);
 
 /* ---------------------------------------------------------------- stream bank --------- *
  * `streams` independent SavgolStream-equivalents advancing in lock step, state in HBM as a
@@ -215,6 +239,33 @@ int savgol2d_laplacian_batch_f32(int half_win_x, int half_win_y, int poly_order,
                                  const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,
                                  float *d_out, int out_stride, size_t out_image_pitch,
                                  size_t images, float delta_x, float delta_y, Savgol2DBoundary boundary, void *stream);
+
+/* ---------------------------------------------------------------- 2-D row bands (multi-GPU) --- *
+ * Frames too large for one GPU, or fewer frames than GPUs: every rank owns a horizontal band of rows of every frame and needs
+ * the half_window_y rows next to its band from the ranks above and below -- the only exchange step on the hot path (the
+ * reference filters whole frames: src/savgol2d.c:398-456; a band's rows must be the rows that call would have produced).
+ * savgol2d_rowband_plan: rank's rows [*row_lo, *row_hi) of a `rows`-row frame (savgol_hip_shard_range) and how many halo rows it
+ *   needs from above / below (half_window_y, or 0 at the frame's real top / bottom).  -1 when the bands would be thinner than
+ *   2 x half_window_y.
+ * savgol2d_apply_rowband_f32: filters one band, d_band = its band_rows x cols rows per image.  d_halo_up / d_halo_down: the
+ *   half_window_y rows just above / below the band (row 0 = the farthest-up row; halo_stride elements between rows,
+ *   halo_image_pitch between images), NULL where the band ends at the frame's real edge -- the boundary mode applies there
+ *   exactly as in savgol2d_apply_batch_f32.  All band_rows output rows are written (VALID: not the frame's own first / last
+ *   half_window_y rows, not the half_window_x border columns).  Enqueue-only plus a stream-ordered scratch allocation; the
+ *   FIRST launch (the band itself) does not read the halos.  Method 1 gives the whole-frame call's bits; method 2 its bits for
+ *   kernels of order > 3 or derivative kernels, and fp32 rounding (<= 4e-7 of the frame's maximum) for the additive smoothing
+ *   kernels, whose rolling column sums are re-seeded on a phase tied to the frame's row 0.
+ * The halo buffers are the caller's to fill: a device-to-device copy on one GPU, ncclSend / ncclRecv across GPUs --
+ * savgol2d_rowband_exchange_rccl in the optional lib/libsavgol_hip_rccl.so (csrc/sg_rowband_rccl.cpp; comm = an ncclComm_t,
+ * d_send_scratch = 2 * images * half_window_y * cols floats, halos received with halo_stride = cols and halo_image_pitch =
+ * half_window_y * cols; one message per neighbour and direction for the whole stack).                                   */
+int savgol2d_rowband_plan(int rows, int half_win_y, int rank, int world_size, int *row_lo, int *row_hi, int *halo_up, int *halo_down);
+int savgol2d_apply_rowband_f32(const Savgol2DFilter *filter,
+                               const float *d_band, int band_rows, int cols, int in_stride, size_t in_image_pitch,
+                               const float *d_halo_up, const float *d_halo_down, int halo_stride, size_t halo_image_pitch,
+                               float *d_out, int out_stride, size_t out_image_pitch,
+                               size_t images, Savgol2DBoundary boundary, int method, void *stream);
+/* (declared in savgol_hip_rccl.h -- that library is the only part that links librccl) */
 
 /* ---------------------------------------------------------------- bench utilities ----- *
  * Synthetic workload of SURVEY.md section 8(d), generated in HBM (never crosses PCIe):

@@ -29,6 +29,8 @@ SAVGOL_HIP_OPT_PLAIN_SUMMATION = 3
 SAVGOL_HIP_OPT_BOUNDARY_AWARE = 4
 SAVGOL_HIP_OPT_TILE_WIDTH = 5
 SAVGOL_STREAMBANK_FMA = 1
+SAVGOL_BATCH_REFERENCE_SUMMATION, SAVGOL_BATCH_PLAIN_SUMMATION, SAVGOL_BATCH_TILE_NARROW, SAVGOL_BATCH_TILE_WIDE = 1, 2, 4, 8
+SAVGOL_BATCH_CORRECT_LEADING_EDGE, SAVGOL_BATCH_BOUNDARY_AWARE = 16, 32
 
 
 class SavgolConfig(C.Structure):
@@ -110,6 +112,12 @@ SIGNATURES = {
     "savgol_apply_valid_batch_f32": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "savgol_apply_valid_batch_f64": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "savgol_apply_strided_batch_f32": (C.c_int, [_F, _vp, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
+    "savgol_apply_batch_f32_ex": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
+    "savgol_apply_batch_f64_ex": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
+    "savgol_apply_valid_batch_f32_ex": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
+    "savgol_apply_valid_batch_f64_ex": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
+    "savgol_apply_strided_batch_f32_ex": (C.c_int, [_F, _vp, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
+    "savgol_hip_default_flags": (C.c_uint, []),
     # savgol_hip.h: stream bank
     "savgol_streambank_create": (_vp, [C.POINTER(SavgolConfig), _sz]),
     "savgol_streambank_create_ex": (_vp, [C.POINTER(SavgolConfig), _sz, C.c_uint]),
@@ -137,6 +145,9 @@ SIGNATURES = {
     "savgol2d_gradient_batch_f32": (C.c_int, [C.c_int] * 3 + [_vp, C.c_int, C.c_int, C.c_int, _sz, _vp, _vp, C.c_int, _sz, _sz, C.c_float, C.c_float, C.c_int, _vp]),
     "savgol2d_hessian_batch_f32": (C.c_int, [C.c_int] * 3 + [_vp, C.c_int, C.c_int, C.c_int, _sz, _vp, _vp, _vp, C.c_int, _sz, _sz, C.c_float, C.c_float, C.c_int, _vp]),
     "savgol2d_laplacian_batch_f32": (C.c_int, [C.c_int] * 3 + [_vp, C.c_int, C.c_int, C.c_int, _sz, _vp, C.c_int, _sz, _sz, C.c_float, C.c_float, C.c_int, _vp]),
+    # savgol_hip.h: 2-D row bands
+    "savgol2d_rowband_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "savgol2d_apply_rowband_f32": (C.c_int, [_F2, _vp, C.c_int, C.c_int, C.c_int, _sz, _vp, _vp, C.c_int, _sz, _vp, C.c_int, _sz, _sz, C.c_int, C.c_int, _vp]),
     # savgol_hip.h: bench utilities
     "savgol_hip_synth_f32": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_uint64, _vp]),
     "savgol_hip_synth_f64": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_uint64, _vp]),
@@ -263,16 +274,16 @@ class Filter:
                                           dst.ctypes.data, out_stride, out_offset, count)
 
     # ---- device-pointer batch calls (torch tensors or raw addresses) ----
-    def apply_batch(self, d_in, d_out, channels, length, in_ld=None, out_ld=None, dtype="f32", valid=False, stream=None):
-        name = f"savgol_apply_{'valid_' if valid else ''}batch_{dtype}"
-        rc = getattr(lib(), name)(self.ptr, _addr(d_in), _addr(d_out), channels, length,
-                                  length if in_ld is None else in_ld,
-                                  (length - 2 * self.n if valid else length) if out_ld is None else out_ld,
-                                  _stream(stream))
+    def apply_batch(self, d_in, d_out, channels, length, in_ld=None, out_ld=None, dtype="f32", valid=False, stream=None, flags=None):
+        """flags=None: the process-wide defaults (savgol_hip_set_option); an int: the *_ex entry point with exactly these SAVGOL_BATCH_* flags."""
+        name = f"savgol_apply_{'valid_' if valid else ''}batch_{dtype}" + ("" if flags is None else "_ex")
+        args = [self.ptr, _addr(d_in), _addr(d_out), channels, length, length if in_ld is None else in_ld,
+                (length - 2 * self.n if valid else length) if out_ld is None else out_ld]
+        rc = getattr(lib(), name)(*args, *([] if flags is None else [flags]), _stream(stream))
         if rc != 0:
             raise RuntimeError(f"{name} returned {rc}: {last_error()}")
 
-    def apply_tensor(self, x, valid=False, stream=None):
+    def apply_tensor(self, x, valid=False, stream=None, flags=None):
         """x: contiguous 2-D torch tensor [channels, length] (float32 or float64) on the GPU."""
         import torch
         assert x.is_cuda and x.dim() == 2 and x.is_contiguous()
@@ -280,7 +291,7 @@ class Filter:
         ch, length = x.shape
         out_len = length - 2 * self.n if valid else length
         y = torch.empty((ch, out_len), dtype=x.dtype, device=x.device)
-        self.apply_batch(x, y, ch, length, length, out_len, dtype=dtype, valid=valid, stream=stream)
+        self.apply_batch(x, y, ch, length, length, out_len, dtype=dtype, valid=valid, stream=stream, flags=flags)
         return y
 
 

@@ -111,15 +111,15 @@ __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
     return a >= n ? n - 1 : a;
 }
 
-// One item: a 256-column strip whose first loaded column is xload, output rows yb .. yb+nout-1 of one frame.  VAR:
-//   0  four remapped scalar loads and masked scalar stores per lane (frames narrower than a strip, odd strides or widths);
-//   1  an inner strip: its 256 input columns are inside the frame and rows are 16-byte aligned (one dwordx4 load and store per lane
-//      and row); the HL outermost lanes on either side are halo, the SW columns in between are stored;
-//   2  a strip that ends AT the frame's left (side 0) or right (side 1) edge, on vector loads too: the columns beyond the
-//      edge are not loaded through remapped indices but synthesised in the LDS row from the lane's own vertical results -- the
-//      remap is per column, so v_t(remapped column) is the vertical result of that column (reference src/savgol2d.c:428-445).
-//      Only the HL lanes on the inner side are halo: 256 - 4 HL columns are stored, so a 4096-column frame is 2 x 248 + 15 x 240:
-//      17 strips, all on vector loads (round 2: 18, two of them -- one nearly empty -- on the scalar path).
+// One item: a 256-column strip whose first loaded column is xload, output rows yb .. yb+nout-1 of one frame.  VEC: the strip's 256
+// input columns are inside the frame, all its SW output columns are stored and rows are 16-byte aligned (one
+// dwordx4 load and store per lane per row); otherwise four remapped scalar loads and masked scalar stores (the
+// strips at the left / right frame edge, odd strides).
+// (Round 3 tried frame-edge strips on vector loads as well -- the columns beyond the edge synthesised in the LDS row from the
+// lane's own vertical results, 248 columns stored per edge strip, so that a 4096-column frame is 2 x 248 + 15 x 240 = 17 strips
+// instead of 18.  It lost 6-17 % at every width tried (3840 ... 4320 columns, n = 2 ... 12): the inner strips then start at
+// 248 + 240 k, and stores of neighbouring strips that meet inside a 64-byte half line are exactly what tools/membench2d.hip had
+// found to cost 7-10 %.  Removed again; profiles/r03_2d_experiments.txt has the numbers.)
 // Row r of the band's input (frame row yb-N+r, remapped at the frame border) lives in ring slot r % U.  Output row m
 // needs rows m .. m+2N; while it is computed, row m+2N+P is already being loaded into the slot row m-1 left.
 // The two passes are skewed by one row: iteration m runs the vertical pass of row m and writes its results to one LDS
@@ -133,12 +133,11 @@ __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
 // the row that leaves; re-seeded from the ring every U rows, so the drift is bounded by U steps), box_x over a lane's four
 // outputs is one sum of the aligned pairs they share plus a sliding correction.  89 instead of 125 VALU instructions per row
 // of 256 columns at n = 7.
-template <int N, int NT, int NOUT, int VAR, bool BOX>
+template <int N, int NT, int NOUT, bool VEC, bool BOX>
 __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *mine, const float *in, float *const (&outs)[NOUT],
-                                          int xload, int side, int yb, int nout, int lane, int xlo, int xhi, int ylo, int yhi)
+                                          int xload, int yb, int nout, int lane, int xlo, int xhi, int ylo, int yhi)
 {
     typedef Roll<N> R;
-    constexpr bool VEC = VAR != 0;
     static_assert(!BOX || (NT == 2 && NOUT == 1), "the additive form is one output of two terms");
     static_assert(R::U % 2 == 0, "the LDS row alternates with the ring slot: U must be even");
     const int c0 = xload + 4 * lane;                         // this lane's first column (frame coordinates)
@@ -150,16 +149,19 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     const bool reflect = job.boundary == SAVGOL2D_BOUNDARY_REFLECT;
     auto load_row = [&](int r) -> f32x4 {                    // rows past the band are clamped re-reads that are never used
         const float *row = in + (long long)fix_row(yb - N + r, job.rows, reflect) * job.in_stride;
+#ifdef SG_ROLL_NT_LOADS                                           // A/B builds: streaming loads (the strip's halo columns then miss L2 for the neighbour)
+        if constexpr (VEC) return __builtin_bit_cast(f32x4, __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(row + c0)));
+#else
         if constexpr (VEC) return *reinterpret_cast<const f32x4 *>(row + c0);
+#endif
         else return f32x4{row[ix0], row[ix1], row[ix2], row[ix3]};
     };
-    const bool out_lane = VAR == 2 ? (side ? lane >= R::HL : lane < 64 - R::HL) : (lane >= R::HL && lane < 64 - R::HL);
-    const int edge_dist = side ? 63 - lane : lane;           // VAR 2: lanes between this one and the frame edge
+    const bool out_lane = lane >= R::HL && lane < 64 - R::HL;
     const int yend = yb + nout;                              // first frame row past this band
     __amdgpu_buffer_rsrc_t rsrc[NOUT];                       // VEC stores go through a buffer descriptor per output frame (range-checked)
     const __amdgpu_buffer_rsrc_t rsrc_none = __builtin_amdgcn_make_buffer_rsrc(outs[0], 0, 0, 0x00020000);     // zero records: drops every store
     const unsigned col_off = out_lane ? (unsigned)(c0 * 4) : 0x80000000u;
-    if constexpr (VAR == 1 && R::STRAIGHT) {
+    if constexpr (VEC && R::STRAIGHT) {
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
             rsrc[o] = __builtin_amdgcn_make_buffer_rsrc(outs[o], 0, (int)((long long)job.rows * job.out_stride * 4), 0x00020000);
@@ -169,19 +171,6 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 
     f32x4 win[R::U];
 
-    // VAR 2: the HL quads beyond the frame edge of LDS row `row`, from this lane's vertical results v (reference :428-445)
-    auto edge_pad = [&](float *row, const f32x4 v) {
-        if constexpr (VAR == 2) {
-            if (job.boundary != SAVGOL2D_BOUNDARY_VALID) {                      // uniform; VALID stores nothing that reads the pad
-                const float edge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, side ? v.w : v.x), side ? 63 : 0));
-                if (edge_dist < R::HL) {
-                    const f32x4 pad = reflect ? f32x4{v.w, v.z, v.y, v.x} : f32x4{edge, edge, edge, edge};
-                    const int pq = side ? R::HL + 64 + edge_dist : R::HL - 1 - edge_dist;
-                    *reinterpret_cast<f32x4 *>(row + 4 * pq) = pad;
-                }
-            }
-        }
-    };
     f32x2 vbp[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};    // BOX: box sum of the previous output row minus its oldest input row
     // vertical pass of the output row whose first input row sits in slot u0 -> LDS row `par` (one row per output and term)
     auto vertical = [&](auto u0c, int par) {
@@ -225,8 +214,6 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             const f32x4 q1 = f32x4{v1[0].x, v1[0].y, v1[1].x, v1[1].y};
             *reinterpret_cast<f32x4 *>(row0 + 4 * R::HL + 4 * lane) = vb;
             *reinterpret_cast<f32x4 *>(row1 + 4 * R::HL + 4 * lane) = q1;
-            edge_pad(row0, vb);
-            edge_pad(row1, q1);
             return;
         }
         // Instruction order matters: the assembler pads an inline-asm result that is consumed within the next two
@@ -260,11 +247,8 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
                 return true;
             });
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const f32x4 q = f32x4{v[t][0].x, v[t][0].y, v[t][1].x, v[t][1].y};
-                *reinterpret_cast<f32x4 *>(wr + ((par * NOUT + o) * NT + t) * R::BUFW) = q;
-                edge_pad(mine + ((par * NOUT + o) * NT + t) * R::BUFW, q);
-            }
+            for (int t = 0; t < NT; ++t)
+                *reinterpret_cast<f32x4 *>(wr + ((par * NOUT + o) * NT + t) * R::BUFW) = f32x4{v[t][0].x, v[t][0].y, v[t][1].x, v[t][1].y};
             return true;
         });
     };
@@ -340,7 +324,7 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     // the store of frame row yo of output `o`
     auto store_row = [&](auto oc, const f32x2 (&r)[2], int yo) {
         constexpr int o = decltype(oc)::value;
-        if constexpr (VAR == 1 && R::STRAIGHT) {
+        if constexpr (VEC && R::STRAIGHT) {
             // ONE unconditional store instruction per row: a lane that must not store (strip halo, rows outside the band or the
             // stored range) gets an offset beyond the buffer and the hardware range check drops it.  A store under an `if` is a
             // branch, and behind a branch hipcc no longer knows how many memory operations are in flight: it then waits for
@@ -353,13 +337,10 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
                                                    (int)(col_off + (unsigned)(yo * job.out_stride * 4)), 0, 2 /* nt */);
         } else if (yo >= ylo && yo < yhi && yo < yend) {     // uniform
             float *orow = outs[o] + (long long)yo * job.out_stride;
-            if constexpr (VAR == 1) {
+            if constexpr (VEC) {
                 if (out_lane)
                     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, f32x4{r[0].x, r[0].y, r[1].x, r[1].y}),
                                                 reinterpret_cast<u32x4 *>(orow + c0));
-            } else if (VAR == 2 && out_lane && c0 >= xlo && c0 + 4 <= xhi) {
-                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, f32x4{r[0].x, r[0].y, r[1].x, r[1].y}),
-                                            reinterpret_cast<u32x4 *>(orow + c0));
             } else if (out_lane) {
                 if (c0 >= xlo && c0 < xhi) orow[c0] = r[0].x;
                 if (c0 + 1 >= xlo && c0 + 1 < xhi) orow[c0 + 1] = r[0].y;
@@ -431,19 +412,6 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #endif
 constexpr int roll_wpb(int n) { (void)n; return SG_ROLL_WPB; }
 
-// Strips of a frame.  edge_layout (16-byte aligned rows, cols a multiple of 4 and >= 256): strip 0 starts at column 0 and the last
-// strip ends at the last column, both on vector loads (VAR 2) and storing 256 - 4 HL columns; the inner strips store SW columns
-// each, the last inner one may overlap the right edge strip (the same values are stored twice).  Otherwise strip s stores
-// columns [s SW, s SW + SW) and those that do not lie inside the frame with their halo take the scalar path (VAR 0).
-template <int N>
-__host__ __device__ inline unsigned roll_strips(int cols, bool edge_layout)
-{
-    typedef Roll<N> R;
-    constexpr int EW = 256 - 4 * R::HL;
-    if (!edge_layout) return (unsigned)((cols + R::SW - 1) / R::SW);
-    return 2u + (cols > 2 * EW ? (unsigned)((cols - 2 * EW + R::SW - 1) / R::SW) : 0u);
-}
-
 template <int N, int NT, int NOUT, bool BOX>
 __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
@@ -464,7 +432,6 @@ __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void
     const bool valid = job.boundary == SAVGOL2D_BOUNDARY_VALID;
     const int xlo = valid ? N : 0, xhi = valid ? job.cols - N : job.cols;
     const int ylo = valid ? N : 0, yhi = valid ? job.rows - N : job.rows;
-    const bool edge_layout = (aligned & 4) != 0;
 
     for (unsigned item = blk * WPB + (unsigned)wv; item < total_items; item += nwaves) {
         const unsigned strip = item % strips, ib = item / strips;
@@ -478,22 +445,12 @@ __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void
         float *outs[NOUT];
         outs[0] = job.out + (long long)img * job.out_pitch;
         if constexpr (NOUT > 1) outs[1] = out1 + (long long)img * job.out_pitch;
-        // which variant of the item loop this strip runs, and where its 256 loaded columns start
-        int var, xload, side = 0;
-        if (edge_layout) {
-            constexpr int EW = 256 - 4 * R::HL;
-            var = (strip == 0 || strip + 1 == strips) ? 2 : 1;
-            side = strip == 0 ? 0 : 1;
-            xload = strip == 0 ? 0 : (strip + 1 == strips ? job.cols - 256 : EW + ((int)strip - 1) * R::SW - 4 * R::HL);
-        } else {
-            const int sx = (int)strip * R::SW;
-            xload = sx - 4 * R::HL;
-            // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
-            var = ((aligned & 3) == 3 && xload >= 0 && xload + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi) ? 1 : 0;
-        }
-        if (var == 1) roll_item<N, NT, NOUT, 1, BOX>(job, taps, mine, in, outs, xload, 0, yb, nout, lane, xlo, xhi, ylo, yhi);
-        else if (var == 2) roll_item<N, NT, NOUT, 2, BOX>(job, taps, mine, in, outs, xload, side, yb, nout, lane, xlo, xhi, ylo, yhi);
-        else roll_item<N, NT, NOUT, 0, BOX>(job, taps, mine, in, outs, xload, 0, yb, nout, lane, xlo, xhi, ylo, yhi);
+        const int sx = (int)strip * R::SW;
+        // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
+        if (aligned == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
+            roll_item<N, NT, NOUT, true, BOX>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+        else
+            roll_item<N, NT, NOUT, false, BOX>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
     }
 }
 
@@ -557,6 +514,17 @@ static bool fill_box_taps(RollTaps<N, 2, 1> &taps, const float *factors, float s
     double g0c = 0.0, q1c = 0.0;
     for (int k = 0; k <= 2 * N; ++k) { g0c += g0[k]; q1c += q1[k]; }
     g0c /= 2 * N + 1; q1c /= 2 * N + 1;
+    {   // Smoothing kernels only.  The summed Laplacian kernel of order <= 3 is additive too, but its taps cancel (sum 0): the box
+        // sums are then large against the output and their rounding shows -- 5e-6 of the output on the test frames, the general
+        // two-term form 2e-6.  Condition: |sum W| >= half of sum |W|.
+        double sum = 0.0, sum_abs = 0.0;
+        for (int y = 0; y <= 2 * N; ++y)
+            for (int x = 0; x <= 2 * N; ++x) {
+                const double w = g0c * (double)q0[x] + (double)g1[y] * q1c;
+                sum += w; sum_abs += std::fabs(w);
+            }
+        if (std::fabs(sum) < 0.5 * sum_abs) return false;
+    }
     for (int k = 0; k <= N; ++k) {
         // symmetric vectors: average the two halves (they differ in the last bit of the float factors)
         const double qa = 0.5 * ((double)q0[k] + (double)q0[2 * N - k]), ga = 0.5 * ((double)g1[k] + (double)g1[2 * N - k]);
@@ -575,12 +543,6 @@ static int roll_box_env()                                   // SAVGOL_HIP_ROLL_B
     static const int v = [] { const char *e = getenv("SAVGOL_HIP_ROLL_BOX"); return e ? atoi(e) : 1; }();
     return v;
 }
-static int roll_edge_env()                                  // SAVGOL_HIP_ROLL_EDGE=0: round 2's strip layout (frame-edge strips on scalar loads)
-{
-    static const int v = [] { const char *e = getenv("SAVGOL_HIP_ROLL_EDGE"); return e ? atoi(e) : 1; }();
-    return v;
-}
-
 template <int N, int NT, int NOUT, bool BOX>
 static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *out1, unsigned images, int cu_count, hipStream_t st)
 {
@@ -590,9 +552,7 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
     if (job.out_stride % 4 == 0 && job.out_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.out) & 15u) == 0 &&
         (NOUT == 1 || (reinterpret_cast<uintptr_t>(out1) & 15u) == 0) &&
         (long long)job.rows * job.out_stride * 4 < 0x7fffff00ll) aligned |= 2;       // the store descriptor holds a 31-bit byte count
-    const bool edge_layout = aligned == 3 && job.cols % 4 == 0 && job.cols >= 256 && roll_edge_env() != 0;
-    if (edge_layout) aligned |= 4;
-    const unsigned strips = roll_strips<N>(job.cols, edge_layout);
+    const unsigned strips = (unsigned)((job.cols + R::SW - 1) / R::SW);
     static int per_cu = 0;                                   // resident blocks per CU of this instantiation
     constexpr unsigned WPB = (unsigned)roll_wpb(N);
     const size_t lds = sizeof(float) * WPB * 2 * NOUT * NT * R::BUFW;
@@ -617,6 +577,9 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
         bands = choose_bands(job.rows, imgs * strips, nwaves, N, 0.3);       // warm-up rows are only loaded
         if (env_bands && atoi(env_bands) > 0 && atoi(env_bands) <= job.rows) bands = (unsigned)atoi(env_bands);
         band_rows = (int)((job.rows + (int)bands - 1) / (int)bands);
+        // the additive form re-seeds its rolling column sums every U rows of a band: bands that start on multiples of U keep that
+        // phase tied to the FRAME row, so a frame's bits do not depend on how many frames share the launch (the band count does)
+        if (BOX) band_rows = (band_rows + R::U - 1) / R::U * R::U;
         bands = (unsigned)((job.rows + band_rows - 1) / band_rows);
         per_image = (unsigned long long)strips * bands;
     };

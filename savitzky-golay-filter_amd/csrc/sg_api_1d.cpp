@@ -2,6 +2,7 @@
 // the device-pointer batch entry points of savgol_hip.h.  All arithmetic on samples happens in the
 // HIP kernels (sg_k1d.hpp); this file validates, picks tile geometry and enqueues.
 #include <atomic>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +10,7 @@
 #include <algorithm>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -67,30 +69,90 @@ extern "C" void savgol_destroy(SavgolFilter *filter) { free(filter); }
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-std::atomic<int> g_correct_leading_edge{0};
-std::atomic<int> g_reference_summation{0};      // SAVGOL_HIP_OPT_REFERENCE_SUMMATION: batch f32 calls in the reference's order
-std::atomic<int> g_plain_summation{0};          // SAVGOL_HIP_OPT_PLAIN_SUMMATION: no block moments at half_window 32
-std::atomic<int> g_boundary_aware{0};
-std::atomic<int> g_tile_width{0};               // SAVGOL_HIP_OPT_TILE_WIDTH: 0 by job size, 1 narrow, 2 wide           // SAVGOL_HIP_OPT_BOUNDARY_AWARE: strided calls and streams honour config.boundary
+// Process-wide DEFAULTS of the per-call flags (savgol_hip_set_option); the *_ex entry points take the flags themselves, so two
+// threads can run different summation orders / tile widths at the same time.
+std::atomic<unsigned> g_default_flags{0};
 
-// wide-window fast path (half windows 24..32): the polynomial fit of a filter's centre taps (sg_k1d_moment_fit.cpp), cached per table content
-struct MomentFit { int n; float w[SAVGOL_MAX_WINDOW]; int terms; float table[sg::MOMENT_TABLE_FLOATS]; };
-std::mutex g_moment_mu;
-std::vector<MomentFit *> g_moment_fits;         // never shrinks: one entry (1.9 KB) per distinct n = 32 filter of the process
+// Everything a batch call needs from a filter besides the samples, built once per distinct filter CONTENT and device: the
+// uploaded edge rows / reference-order table / moment table, the polynomial fit behind the moment table, the by-value taps and
+// the fp64 symmetry check.  Rounds 1-2 re-packed the edge rows (8.3 KB at n = 32), hashed them byte-wise and scanned the table
+// cache linearly on EVERY call, then scanned the moment fits under a second mutex: ~10 us per call at n = 32 (tools/time_batch_host.c).
+// A SavgolFilter is a caller-owned POD (callers do edit tables by hand), so the key is the content -- a word-wise hash of the
+// bytes the kernels read, ~0.2 us -- and a hit compares them.  Entries live as long as the process (queued launches and captured
+// graphs keep the device pointers).
+struct FilterPlan {
+    int    n = 0, ws = 0, device = -1;
+    std::vector<unsigned char> content;             // SavgolFilter bytes [0, used_bytes)
+    sg::Taps taps32, taps64;
+    int    sym = 0;                                 // fp64 path: 1 = centre taps (anti)symmetric bit for bit, 0 = tap sym_bad is not
+    int    sym_bad = 0;
+    bool   odd = false;
+    const float *d_edges = nullptr, *d_ref = nullptr, *d_moment = nullptr;
+    int    moment_terms = -1;                       // -1: not fitted yet
+    float  moment_table[sg::MOMENT_TABLE_FLOATS];
+};
+std::mutex g_plan_mu;
+std::unordered_multimap<uint64_t, FilterPlan *> g_plans;
 
-const MomentFit *moment_fit(const SavgolFilter *f)
+inline size_t filter_used_bytes(const SavgolFilter *f)
 {
-    std::lock_guard<std::mutex> lock(g_moment_mu);
-    const int n = f->config.half_window;
-    for (const MomentFit *m : g_moment_fits)
-        if (m->n == n && memcmp(m->w, f->center_weights, sizeof(float) * (size_t)(2 * n + 1)) == 0) return m;
-    MomentFit *m = new MomentFit();
-    m->n = n;
-    memset(m->w, 0, sizeof(m->w));
-    memcpy(m->w, f->center_weights, sizeof(float) * (size_t)(2 * n + 1));
-    m->terms = sg1d_moment_prepare(n, f->center_weights, m->table);
-    g_moment_fits.push_back(m);
-    return m;
+    return offsetof(SavgolFilter, edge_weights) + sizeof(f->edge_weights[0]) * (size_t)f->config.half_window;
+}
+
+// the plan of (filter content, device); `need` = which lazily built parts this call wants
+enum : unsigned { NEED_EDGES = 1, NEED_REF = 2, NEED_MOMENT = 4 };
+const FilterPlan *plan_get(DeviceCtx *ctx, const SavgolFilter *f, unsigned need)
+{
+    const size_t bytes = filter_used_bytes(f);
+    const uint64_t key = sg::hash64(f, bytes, 0x1d00u + (uint64_t)ctx->ordinal);
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    FilterPlan *p = nullptr;
+    auto range = g_plans.equal_range(key);
+    for (auto it = range.first; it != range.second; ++it)
+        if (it->second->device == ctx->ordinal && it->second->content.size() == bytes && memcmp(it->second->content.data(), f, bytes) == 0) { p = it->second; break; }
+    const int n = f->config.half_window, ws = f->window_size;
+    if (!p) {
+        p = new FilterPlan();
+        p->n = n; p->ws = ws; p->device = ctx->ordinal;
+        p->content.assign(reinterpret_cast<const unsigned char *>(f), reinterpret_cast<const unsigned char *>(f) + bytes);
+        memset(&p->taps32, 0, sizeof(p->taps32));
+        memset(&p->taps64, 0, sizeof(p->taps64));
+        memcpy(p->taps32.w, f->center_weights, sizeof(float) * ws);
+        // The fp64 kernel keeps taps 0..n as doubles in SGPRs and takes tap 2n-k = +-tap k from them.  Tables built by
+        // savgol_create are (anti)symmetric bit for bit (only Gram terms of the derivative's parity are non-zero at
+        // t = 0); a hand-edited table that is not cannot run on this path.
+        p->odd = (f->config.derivative & 1) != 0;
+        p->sym = 1;
+        for (int k = 0; k <= n; ++k) {
+            const float a = f->center_weights[k], b = f->center_weights[2 * n - k];
+            if (!(p->odd ? (a == -b) : (a == b))) { p->sym = 0; p->sym_bad = k; break; }
+            p->taps64.wd[k] = (double)a;
+        }
+        g_plans.emplace(key, p);
+    }
+    if ((need & NEED_EDGES) && !p->d_edges) {
+        float packed[SAVGOL_MAX_HALF_WINDOW * SAVGOL_MAX_WINDOW];               // rows packed [n][ws]
+        for (int e = 0; e < n; ++e) memcpy(packed + e * ws, f->edge_weights[e], sizeof(float) * ws);
+        p->d_edges = sg::ctx_table(ctx, packed, sizeof(float) * n * ws, 0x1d00u + (unsigned)n);
+        if (!p->d_edges) return nullptr;
+    }
+    if ((need & NEED_REF) && !p->d_ref) {
+        float packed[(SAVGOL_MAX_HALF_WINDOW + 1) * SAVGOL_MAX_WINDOW];         // centre row, then the edge rows
+        memcpy(packed, f->center_weights, sizeof(float) * ws);
+        for (int e = 0; e < n; ++e) memcpy(packed + (size_t)(1 + e) * ws, f->edge_weights[e], sizeof(float) * ws);
+        p->d_ref = sg::ctx_table(ctx, packed, sizeof(float) * (size_t)(n + 1) * ws, 0x1e00u + (unsigned)n);
+        if (!p->d_ref) return nullptr;
+    }
+    if ((need & NEED_MOMENT) && p->moment_terms < 0) {
+        // wide-window fast path (half windows 24..32): the polynomial fit of the centre taps (sg_k1d_moment_fit.cpp)
+        const int terms = sg1d_moment_prepare(n, f->center_weights, p->moment_table);
+        if (terms > 0) {
+            p->d_moment = sg::ctx_table(ctx, p->moment_table, sizeof(p->moment_table), 0x1f00u + (unsigned)n);
+            if (!p->d_moment) return nullptr;
+        }
+        p->moment_terms = terms;
+    }
+    return p;
 }
 
 enum Variant { FULL = 0, VALID = 1, FULL_POLY_EDGES = 2 /* strided: polynomial edges whatever the mode */,
@@ -118,43 +180,60 @@ constexpr size_t LAUNCH_MAX_LENGTH = (size_t)1 << 30;
 
 template <typename T>
 int enqueue_long(const char *who, const SavgolFilter *f, const T *d_in, T *d_out, size_t channels, size_t length,
-                 size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, bool reference_order);
+                 size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, unsigned flags);
+
+// d_in / d_out as pitched row sets [base + c ld, base + c ld + len): do any two rows share a byte?  The extents may interleave
+// (in = buf[:, 0, :], out = buf[:, 1, :] with both pitches 2 L) without any row touching another.
+template <typename T>
+bool rows_overlap(const T *d_in, size_t in_ld, size_t in_len, const T *d_out, size_t out_ld, size_t out_len, size_t channels)
+{
+    const uintptr_t a0 = (uintptr_t)d_in, a1 = a0 + ((channels - 1) * in_ld + in_len) * sizeof(T);
+    const uintptr_t b0 = (uintptr_t)d_out, b1 = b0 + ((channels - 1) * out_ld + out_len) * sizeof(T);
+    if (!(a0 < b1 && b0 < a1)) return false;                       // the whole extents are disjoint: the common case
+    if (in_ld != out_ld || channels == 1) return true;
+    // equal pitches: row i of one buffer can only meet rows of the other that start within one pitch of it
+    const uintptr_t pitch = in_ld * sizeof(T);
+    const uintptr_t d = a0 <= b0 ? (b0 - a0) % pitch : (pitch - (a0 - b0) % pitch) % pitch;      // offset of an output row inside the input's pitch
+    // input rows occupy [0, in_len) mod pitch, output rows [d, d + out_len) mod pitch
+    const uintptr_t il = in_len * sizeof(T), ol = out_len * sizeof(T);
+    return d < il || d + ol > pitch;
+}
 
 template <typename T>
 int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_out, size_t channels, size_t length,
-                  size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, bool reference_order = false)
+                  size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, unsigned flags)
 {
+    const bool reference_order = sizeof(T) == 4 && (flags & SAVGOL_BATCH_REFERENCE_SUMMATION) != 0;
+    const bool correct_edge = (flags & SAVGOL_BATCH_CORRECT_LEADING_EDGE) != 0;
     if (!f || !d_in || !d_out) { sg_set_error("%s: NULL pointer", who); return -1; }
     if (!filter_sane(f, who)) return -1;
     const int n = f->config.half_window, ws = f->window_size;
     if (length < (size_t)ws) { sg_set_error("%s: data length (%zu) < window size (%d)", who, length, ws); return -1; }
-    if (length > LAUNCH_MAX_LENGTH) return enqueue_long<T>(who, f, d_in, d_out, channels, length, in_ld, out_ld, variant, st, reference_order);
+    if (length > LAUNCH_MAX_LENGTH) return enqueue_long<T>(who, f, d_in, d_out, channels, length, in_ld, out_ld, variant, st, flags);
     const size_t out_len = (variant == VALID) ? length - 2 * (size_t)n : length;
     if (in_ld < length || out_ld < out_len) { sg_set_error("%s: row pitch smaller than the row", who); return -1; }
     if (channels == 0) return 0;
-    {   // tiles read their halo from the input while neighbouring tiles store: overlapping buffers would race
-        const uintptr_t a0 = (uintptr_t)d_in, a1 = a0 + ((channels - 1) * in_ld + length) * sizeof(T);
-        const uintptr_t b0 = (uintptr_t)d_out, b1 = b0 + ((channels - 1) * out_ld + out_len) * sizeof(T);
-        if (a0 < b1 && b0 < a1) { sg_set_error("%s: d_in and d_out overlap (the device batch calls are out of place)", who); return -1; }
-    }
+    // tiles read their halo from the input while neighbouring tiles store: overlapping rows would race
+    if (rows_overlap(d_in, in_ld, length, d_out, out_ld, out_len, channels)) { sg_set_error("%s: d_in and d_out overlap (the device batch calls are out of place)", who); return -1; }
 
     DeviceCtx *ctx = sg::ctx_get();
     if (!ctx) return -1;
+    const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
+    const bool poly = (mode == SAVGOL_BOUNDARY_POLYNOMIAL);
+    const bool want_edges = poly && variant != VALID && variant != INTERIOR;
+    const bool want_moment = sizeof(T) == 4 && !reference_order && n >= sg::MOMENT_MIN_N && n <= sg::MOMENT_MAX_N && !(flags & SAVGOL_BATCH_PLAIN_SUMMATION);
+    const FilterPlan *plan = plan_get(ctx, f, reference_order ? NEED_REF : ((want_edges ? NEED_EDGES : 0u) | (want_moment ? NEED_MOMENT : 0u)));
+    if (!plan) return -1;
 
     if constexpr (sizeof(T) == 4) {
         if (reference_order) {
             // one output per thread in the reference's own summation order: bit-identical to its savgol_apply
-            float packed[(SAVGOL_MAX_HALF_WINDOW + 1) * SAVGOL_MAX_WINDOW];
-            memcpy(packed, f->center_weights, sizeof(float) * ws);
-            for (int e = 0; e < n; ++e) memcpy(packed + (size_t)(1 + e) * ws, f->edge_weights[e], sizeof(float) * ws);
-            const float *d_table = sg::ctx_table(ctx, packed, sizeof(float) * (size_t)(n + 1) * ws, 0x1e00u + (unsigned)n);
-            if (!d_table) return -1;
-            const int rmode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
+            const float *d_table = plan->d_ref;
+            const int rmode = mode;
             const bool inner = variant == VALID || variant == INTERIOR;                 // no edge outputs at all
             const int lo = inner ? n : 0, hi = inner ? (int)length - n : (int)length;
             const int shift = (variant == VALID) ? n : 0;
-            const int negate = (rmode == SAVGOL_BOUNDARY_POLYNOMIAL && g_correct_leading_edge.load() && (f->config.derivative & 1)) ? 1 : 0;
-            const bool poly = rmode == SAVGOL_BOUNDARY_POLYNOMIAL;
+            const int negate = (poly && correct_edge && (f->config.derivative & 1)) ? 1 : 0;
             int rc;
             if (channels * length >= ((size_t)1 << 16) && length >= (size_t)4 * ws) {
                 // long batches: the packed kernel for everything the centre taps produce, the per-thread kernel for
@@ -182,13 +261,11 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     // tile width: the wide tile where one is built and the batch is big enough to keep the chip in whole rounds of them
     int vpl = sg::vectors_per_lane(sizeof(T), f->config.half_window);
     const int vpl_wide = sg::wide_vectors_per_lane(sizeof(T), f->config.half_window);
-    const int tile_mode = g_tile_width.load();
+    const int tile_mode = (flags & SAVGOL_BATCH_TILE_NARROW) ? 1 : ((flags & SAVGOL_BATCH_TILE_WIDE) ? 2 : 0);
     const int wide = vpl_wide != vpl && tile_mode != 1 &&
                      (tile_mode == 2 || (unsigned long long)channels * ((length + 64u * vpl_wide * E - 1) / (64u * vpl_wide * E)) >= sg::WIDE_TILE_MIN_TILES);
     if (wide) vpl = vpl_wide;
     const unsigned TW = 64u * (unsigned)vpl * E;
-    const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
-    const bool poly = (mode == SAVGOL_BOUNDARY_POLYNOMIAL);
 
     sg::Job1D job;
     memset(&job, 0, sizeof(job));
@@ -208,50 +285,22 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     if (((uintptr_t)d_in % 16 == 0) && (in_ld % E == 0)) job.flags |= sg::JOB_VEC_IN;
     if (((uintptr_t)d_out % 16 == 0) && (out_ld % E == 0) && (job.out_shift % E == 0)) job.flags |= sg::JOB_VEC_OUT;
 
-    sg::Taps taps;
-    memset(&taps, 0, sizeof(taps));
     if (sizeof(T) == 8) {
-        // The fp64 kernel keeps taps 0..n as doubles in SGPRs and takes tap 2n-k = +-tap k from them.  Tables built by
-        // savgol_create are (anti)symmetric bit for bit (only Gram terms of the derivative's parity are non-zero at
-        // t = 0); a hand-edited table that is not cannot run on this path.
-        const bool odd = (f->config.derivative & 1) != 0;
-        for (int k = 0; k <= n; ++k) {
-            const float a = f->center_weights[k], b = f->center_weights[2 * n - k];
-            if (!(odd ? (a == -b) : (a == b))) {
-                sg_set_error("%s: fp64 path needs the centre taps savgol_create builds (tap[k] == %stap[2n-k]); tap %d is not", who,
-                             odd ? "-" : "", k);
-                return -1;
-            }
-            taps.wd[k] = (double)a;
+        if (!plan->sym) {
+            sg_set_error("%s: fp64 path needs the centre taps savgol_create builds (tap[k] == %stap[2n-k]); tap %d is not", who,
+                         plan->odd ? "-" : "", plan->sym_bad);
+            return -1;
         }
-        if (odd) job.flags |= sg::JOB_ODD_TAPS;
-    } else {
-        memcpy(taps.w, f->center_weights, sizeof(float) * ws);
+        if (plan->odd) job.flags |= sg::JOB_ODD_TAPS;
     }
-
-    const float *d_edges = nullptr;
-    if (poly && variant != VALID && variant != INTERIOR) {
-        // rows packed [n][ws]
-        float packed[SAVGOL_MAX_HALF_WINDOW * SAVGOL_MAX_WINDOW];
-        for (int e = 0; e < n; ++e) memcpy(packed + e * ws, f->edge_weights[e], sizeof(float) * ws);
-        d_edges = sg::ctx_table(ctx, packed, sizeof(float) * n * ws, 0x1d00u + (unsigned)n);
-        if (!d_edges) return -1;
-    }
-
+    const sg::Taps &taps = sizeof(T) == 8 ? plan->taps64 : plan->taps32;
+    const float *d_edges = want_edges ? plan->d_edges : nullptr;
     // half windows 24..32, fp32: block moments replace the taps on the lanes' common block when the table is a polynomial
-    const float *d_moment = nullptr;
-    int moment_terms = 0;
-    if (sizeof(T) == 4 && n >= sg::MOMENT_MIN_N && n <= sg::MOMENT_MAX_N && !g_plain_summation.load()) {
-        const MomentFit *mf = moment_fit(f);
-        if (mf->terms) {
-            d_moment = sg::ctx_table(ctx, mf->table, sizeof(mf->table), 0x1f00u + (unsigned)n);
-            if (!d_moment) return -1;
-            moment_terms = mf->terms;
-        }
-    }
+    const float *d_moment = (want_moment && plan->moment_terms > 0) ? plan->d_moment : nullptr;
+    const int moment_terms = d_moment ? plan->moment_terms : 0;
 
-    // split so that a launch indexes < 2^31 tiles
-    const size_t max_ch = (size_t)0x7fffffffu / job.tiles_per_channel;
+    // split so that a launch stays below 2^24 blocks of four tiles (sg::MAX_TILES_PER_LAUNCH)
+    const size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / job.tiles_per_channel;
     for (size_t c0 = 0; c0 < channels; c0 += max_ch) {
         const size_t nc = (channels - c0 < max_ch) ? channels - c0 : max_ch;
         job.in = d_in + c0 * in_ld;
@@ -269,7 +318,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     }
     if (d_edges) {
         // bit 0: multiply by dt_inv; bit 1: negate the leading-edge outputs (SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE, odd d only)
-        const int eflags = (job.dt_inv != 1.0f ? 1 : 0) | ((g_correct_leading_edge.load() && (f->config.derivative & 1)) ? 2 : 0);
+        const int eflags = (job.dt_inv != 1.0f ? 1 : 0) | ((correct_edge && (f->config.derivative & 1)) ? 2 : 0);
         const int rc = sg::launch_edges<T>(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_edges,
                                            job.dt_inv, eflags, channels, st);
         if (rc != 0) { sg_set_error("%s: edge kernel launch failed", who); return -1; }
@@ -287,23 +336,19 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 int enqueue_long(const char *who, const SavgolFilter *f, const T *d_in, T *d_out, size_t channels, size_t length,
-                 size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, bool reference_order)
+                 size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, unsigned flags)
 {
     const size_t n = (size_t)f->config.half_window;
     const size_t out_len = (variant == VALID) ? length - 2 * n : length;
     if (in_ld < length || out_ld < out_len) { sg_set_error("%s: row pitch smaller than the row", who); return -1; }
     if (channels == 0) return 0;
-    {
-        const uintptr_t a0 = (uintptr_t)d_in, a1 = a0 + ((channels - 1) * in_ld + length) * sizeof(T);
-        const uintptr_t b0 = (uintptr_t)d_out, b1 = b0 + ((channels - 1) * out_ld + out_len) * sizeof(T);
-        if (a0 < b1 && b0 < a1) { sg_set_error("%s: d_in and d_out overlap (the device batch calls are out of place)", who); return -1; }
-    }
+    if (rows_overlap(d_in, in_ld, length, d_out, out_ld, out_len, channels)) { sg_set_error("%s: d_in and d_out overlap (the device batch calls are out of place)", who); return -1; }
     constexpr size_t SEG = (size_t)1 << 29;                       // outputs per sub-row (a multiple of the vector width: sub-rows stay 16-byte aligned)
     for (size_t a = n; a < length - n; a += SEG) {
         const size_t b = (length - n - a < SEG) ? length - n : a + SEG;
         // VALID stores out[g - n], INTERIOR out[g]: the same pointer offset serves both
         if (enqueue_batch<T>(who, f, d_in + (a - n), d_out + (a - n), channels, (b - a) + 2 * n, in_ld, out_ld,
-                             variant == VALID ? VALID : INTERIOR, st, reference_order) != 0) return -1;
+                             variant == VALID ? VALID : INTERIOR, st, flags) != 0) return -1;
     }
     if (variant == VALID || variant == INTERIOR) return 0;
 
@@ -320,11 +365,11 @@ int enqueue_long(const char *who, const SavgolFilter *f, const T *d_in, T *d_out
     if (mode == (int)SAVGOL_BOUNDARY_PERIODIC) {
         // ring of both ends: [in[L-128 .. L), in[0 .. 128)]; its interior outputs 128-n .. 128+n-1 are the channel's L-n .. L-1, 0 .. n-1
         ok = copy2d(in_a, E, d_in + (length - E / 2), in_ld, E / 2) && copy2d(in_a + E / 2, E, d_in, in_ld, E / 2) &&
-             enqueue_batch<T>(who, f, in_a, out_a, channels, E, E, E, INTERIOR, st, reference_order) == 0 &&
+             enqueue_batch<T>(who, f, in_a, out_a, channels, E, E, E, INTERIOR, st, flags) == 0 &&
              copy2d(d_out + (length - n), out_ld, out_a + (E / 2 - n), E, n) && copy2d(d_out, out_ld, out_a + E / 2, E, n);
     } else {
         ok = copy2d(in_a, E, d_in, in_ld, E) && copy2d(in_b, E, d_in + (length - E), in_ld, E) &&
-             enqueue_batch<T>(who, f, in_a, out_a, 2 * channels, E, E, E, variant, st, reference_order) == 0 &&      // in_b / out_b follow in_a / out_a
+             enqueue_batch<T>(who, f, in_a, out_a, 2 * channels, E, E, E, variant, st, flags) == 0 &&      // in_b / out_b follow in_a / out_a
              copy2d(d_out, out_ld, out_a, E, n) && copy2d(d_out + (length - n), out_ld, out_b + (E - n), E, n);
     }
     if (!sg::hip_ok(hipFreeAsync(scratch, st), "hipFreeAsync(channel ends)")) ok = false;
@@ -364,18 +409,16 @@ PipeStreams *pipe_streams(DeviceCtx *ctx)
 int host_apply_pipelined(const char *who, DeviceCtx *ctx, const SavgolFilter *f, const float *input, float *output, size_t L, Variant variant)
 {
     if (!filter_sane(f, who)) return -1;
-    const int n = f->config.half_window, ws = f->window_size;
+    const int n = f->config.half_window;
     PipeStreams *ps = pipe_streams(ctx);
     if (!ps) { sg_set_error("%s: could not create copy streams", who); return -1; }
     const size_t ld = (L + 3) & ~(size_t)3;
     float *d_in = static_cast<float *>(sg::ctx_arena(ctx, 2 * ld * sizeof(float)));
     if (!d_in) return -1;
     float *d_out = d_in + ld;
-    float packed[(SAVGOL_MAX_HALF_WINDOW + 1) * SAVGOL_MAX_WINDOW];
-    memcpy(packed, f->center_weights, sizeof(float) * ws);
-    for (int e = 0; e < n; ++e) memcpy(packed + (size_t)(1 + e) * ws, f->edge_weights[e], sizeof(float) * ws);
-    const float *d_table = sg::ctx_table(ctx, packed, sizeof(float) * (size_t)(n + 1) * ws, 0x1e00u + (unsigned)n);
-    if (!d_table) return -1;
+    const FilterPlan *plan = plan_get(ctx, f, NEED_REF);
+    if (!plan) return -1;
+    const float *d_table = plan->d_ref;
     const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
     const int shift = (variant == VALID) ? n : 0;
     const float dt_inv = dt_inverse(f);
@@ -427,7 +470,7 @@ int host_apply_pipelined(const char *who, DeviceCtx *ctx, const SavgolFilter *f,
     if (rc != 0) abort_flag = true;
     // the 32 outputs at either end: boundary handling of every mode, reversed leading edge, VALID's narrower range
     if (rc == 0) {
-        const int negate = (mode == SAVGOL_BOUNDARY_POLYNOMIAL && g_correct_leading_edge.load() && (f->config.derivative & 1)) ? 1 : 0;
+        const int negate = (mode == SAVGOL_BOUNDARY_POLYNOMIAL && (g_default_flags.load() & SAVGOL_BATCH_CORRECT_LEADING_EDGE) && (f->config.derivative & 1)) ? 1 : 0;
         const int e_lo0 = (variant == VALID) ? n : 0, e_hi1 = (variant == VALID) ? (int)L - n : (int)L;
         if (sg1d_launch_reference_order_f32(d_in, d_out, (long long)ld, (long long)ld, (long long)L, n, d_table, dt_inv, mode, e_lo0, (int)lo, shift,
                                             negate, 1, ps->up) != 0 ||
@@ -450,17 +493,21 @@ int host_apply_pipelined(const char *who, DeviceCtx *ctx, const SavgolFilter *f,
 
 extern "C" {
 
-int sg_option_boundary_aware(void) { return g_boundary_aware.load(); }
+int sg_option_boundary_aware(void) { return (g_default_flags.load() & SAVGOL_BATCH_BOUNDARY_AWARE) ? 1 : 0; }
+
+unsigned savgol_hip_default_flags(void) { return g_default_flags.load(); }
 
 int savgol_hip_set_option(int option, int value)
 {
-    if (option == SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE) { g_correct_leading_edge.store(value != 0); return 0; }
-    if (option == SAVGOL_HIP_OPT_REFERENCE_SUMMATION) { g_reference_summation.store(value != 0); return 0; }
-    if (option == SAVGOL_HIP_OPT_PLAIN_SUMMATION) { g_plain_summation.store(value != 0); return 0; }
-    if (option == SAVGOL_HIP_OPT_BOUNDARY_AWARE) { g_boundary_aware.store(value != 0); return 0; }
+    auto set = [](unsigned bit, bool on) { if (on) g_default_flags.fetch_or(bit); else g_default_flags.fetch_and(~bit); };
+    if (option == SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE) { set(SAVGOL_BATCH_CORRECT_LEADING_EDGE, value != 0); return 0; }
+    if (option == SAVGOL_HIP_OPT_REFERENCE_SUMMATION) { set(SAVGOL_BATCH_REFERENCE_SUMMATION, value != 0); return 0; }
+    if (option == SAVGOL_HIP_OPT_PLAIN_SUMMATION) { set(SAVGOL_BATCH_PLAIN_SUMMATION, value != 0); return 0; }
+    if (option == SAVGOL_HIP_OPT_BOUNDARY_AWARE) { set(SAVGOL_BATCH_BOUNDARY_AWARE, value != 0); return 0; }
     if (option == SAVGOL_HIP_OPT_TILE_WIDTH) {
         if (value < 0 || value > 2) { sg_set_error("savgol_hip_set_option: tile width %d (0 auto, 1 narrow, 2 wide)", value); return -1; }
-        g_tile_width.store(value);
+        set(SAVGOL_BATCH_TILE_NARROW, value == 1);
+        set(SAVGOL_BATCH_TILE_WIDE, value == 2);
         return 0;
     }
     sg_set_error("savgol_hip_set_option: unknown option %d", option);
@@ -473,49 +520,164 @@ int savgol_hip_moment_table(const SavgolFilter *filter, float *table)
     return sg1d_moment_prepare(filter->config.half_window, filter->center_weights, table);
 }
 
+// the host-pointer drop-in calls: always the reference's summation order; the two semantic switches follow the process defaults
+static unsigned host_call_flags()
+{
+    return SAVGOL_BATCH_REFERENCE_SUMMATION | (g_default_flags.load() & (SAVGOL_BATCH_CORRECT_LEADING_EDGE | SAVGOL_BATCH_BOUNDARY_AWARE));
+}
+
+static bool flags_ok(const char *who, unsigned flags)
+{
+    const unsigned known = SAVGOL_BATCH_REFERENCE_SUMMATION | SAVGOL_BATCH_PLAIN_SUMMATION | SAVGOL_BATCH_TILE_NARROW | SAVGOL_BATCH_TILE_WIDE |
+                           SAVGOL_BATCH_CORRECT_LEADING_EDGE | SAVGOL_BATCH_BOUNDARY_AWARE;
+    if ((flags & ~known) || ((flags & SAVGOL_BATCH_TILE_NARROW) && (flags & SAVGOL_BATCH_TILE_WIDE))) {
+        sg_set_error("%s: bad flags 0x%x", who, flags);
+        return false;
+    }
+    return true;
+}
+
+int savgol_apply_batch_f32_ex(const SavgolFilter *filter, const float *d_in, float *d_out, size_t channels, size_t length,
+                              size_t in_ld, size_t out_ld, unsigned flags, void *stream)
+{
+    if (!flags_ok("savgol_apply_batch_f32_ex", flags)) return -1;
+    return enqueue_batch<float>("savgol_apply_batch_f32", filter, d_in, d_out, channels, length, in_ld, out_ld, FULL, static_cast<hipStream_t>(stream), flags);
+}
+
+int savgol_apply_batch_f64_ex(const SavgolFilter *filter, const double *d_in, double *d_out, size_t channels, size_t length,
+                              size_t in_ld, size_t out_ld, unsigned flags, void *stream)
+{
+    if (!flags_ok("savgol_apply_batch_f64_ex", flags)) return -1;
+    return enqueue_batch<double>("savgol_apply_batch_f64", filter, d_in, d_out, channels, length, in_ld, out_ld, FULL, static_cast<hipStream_t>(stream), flags);
+}
+
+int savgol_apply_valid_batch_f32_ex(const SavgolFilter *filter, const float *d_in, float *d_out, size_t channels, size_t length,
+                                    size_t in_ld, size_t out_ld, unsigned flags, void *stream)
+{
+    if (!flags_ok("savgol_apply_valid_batch_f32_ex", flags)) return -1;
+    return enqueue_batch<float>("savgol_apply_valid_batch_f32", filter, d_in, d_out, channels, length, in_ld, out_ld, VALID, static_cast<hipStream_t>(stream), flags);
+}
+
+int savgol_apply_valid_batch_f64_ex(const SavgolFilter *filter, const double *d_in, double *d_out, size_t channels, size_t length,
+                                    size_t in_ld, size_t out_ld, unsigned flags, void *stream)
+{
+    if (!flags_ok("savgol_apply_valid_batch_f64_ex", flags)) return -1;
+    return enqueue_batch<double>("savgol_apply_valid_batch_f64", filter, d_in, d_out, channels, length, in_ld, out_ld, VALID, static_cast<hipStream_t>(stream), flags);
+}
+
 int savgol_apply_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out, size_t channels, size_t length,
                            size_t in_ld, size_t out_ld, void *stream)
 {
     return enqueue_batch<float>("savgol_apply_batch_f32", filter, d_in, d_out, channels, length, in_ld, out_ld, FULL,
-                                static_cast<hipStream_t>(stream), g_reference_summation.load() != 0);
+                                static_cast<hipStream_t>(stream), g_default_flags.load());
 }
 
 int savgol_apply_batch_f64(const SavgolFilter *filter, const double *d_in, double *d_out, size_t channels, size_t length,
                            size_t in_ld, size_t out_ld, void *stream)
 {
     return enqueue_batch<double>("savgol_apply_batch_f64", filter, d_in, d_out, channels, length, in_ld, out_ld, FULL,
-                                 static_cast<hipStream_t>(stream));
+                                 static_cast<hipStream_t>(stream), g_default_flags.load());
 }
 
 int savgol_apply_valid_batch_f32(const SavgolFilter *filter, const float *d_in, float *d_out, size_t channels,
                                  size_t length, size_t in_ld, size_t out_ld, void *stream)
 {
     return enqueue_batch<float>("savgol_apply_valid_batch_f32", filter, d_in, d_out, channels, length, in_ld, out_ld,
-                                VALID, static_cast<hipStream_t>(stream), g_reference_summation.load() != 0);
+                                VALID, static_cast<hipStream_t>(stream), g_default_flags.load());
 }
 
 int savgol_apply_valid_batch_f64(const SavgolFilter *filter, const double *d_in, double *d_out, size_t channels,
                                  size_t length, size_t in_ld, size_t out_ld, void *stream)
 {
     return enqueue_batch<double>("savgol_apply_valid_batch_f64", filter, d_in, d_out, channels, length, in_ld, out_ld,
-                                 VALID, static_cast<hipStream_t>(stream));
+                                 VALID, static_cast<hipStream_t>(stream), g_default_flags.load());
 }
 
 int savgol_apply_strided_batch_f32(const SavgolFilter *filter, const void *d_in, size_t in_stride, size_t in_offset,
                                    size_t in_channel_pitch, void *d_out, size_t out_stride, size_t out_offset,
                                    size_t out_channel_pitch, size_t channels, size_t count, void *stream)
 {
+    return savgol_apply_strided_batch_f32_ex(filter, d_in, in_stride, in_offset, in_channel_pitch, d_out, out_stride, out_offset,
+                                             out_channel_pitch, channels, count, g_default_flags.load(), stream);
+}
+
+int savgol_apply_strided_batch_f32_ex(const SavgolFilter *filter, const void *d_in, size_t in_stride, size_t in_offset,
+                                      size_t in_channel_pitch, void *d_out, size_t out_stride, size_t out_offset,
+                                      size_t out_channel_pitch, size_t channels, size_t count, unsigned flags, void *stream)
+{
     const char *who = "savgol_apply_strided_batch_f32";
+    if (!flags_ok(who, flags)) return -1;
     if (!filter || !d_in || !d_out) { sg_set_error("%s: NULL pointer", who); return -1; }
     if (!filter_sane(filter, who)) return -1;
     if (count < (size_t)filter->window_size) { sg_set_error("%s: count < window size", who); return -1; }
     if (channels == 0) return 0;
     DeviceCtx *ctx = sg::ctx_get();
     if (!ctx) return -1;
-    // gather the field into dense rows, filter, scatter back.  The two dense frames are this call's own, allocated and freed in
-    // stream order (hipMallocAsync / hipFreeAsync): no shared arena, no lock, no synchronise -- the call only enqueues.
-    const size_t ld = (count + 3) & ~(size_t)3;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const int n = filter->config.half_window;
+    const Variant variant = (flags & SAVGOL_BATCH_BOUNDARY_AWARE) ? FULL : FULL_POLY_EDGES;
+
+    // ---- one pass over the records: the field is gathered while a tile is staged and scattered when its results leave
+    //      (sg1d_strided_kernel).  Needs 4-byte aligned fields (dword loads), samples a launch can index, and -- tiles read their
+    //      halo while other tiles store -- input and output FIELDS that share no byte.  The same array with another field offset
+    //      (the usual in-place AoS case) qualifies; the same field in place does not and takes the staged path below. ----
+    const uintptr_t ia = (uintptr_t)d_in + in_offset, oa = (uintptr_t)d_out + out_offset;
+    const bool aligned = ia % 4 == 0 && oa % 4 == 0 && in_stride % 4 == 0 && out_stride % 4 == 0 && in_channel_pitch % 4 == 0 && out_channel_pitch % 4 == 0 &&
+                         in_stride >= 4 && out_stride >= 4;
+    bool disjoint;
+    {
+        const uintptr_t ie = ia + (channels - 1) * in_channel_pitch + (count - 1) * in_stride + 4, oe = oa + (channels - 1) * out_channel_pitch + (count - 1) * out_stride + 4;
+        if (ie <= oa || oe <= ia) disjoint = true;                          // the two arrays do not overlap at all
+        else if (in_stride == out_stride && in_channel_pitch == out_channel_pitch && in_channel_pitch % in_stride == 0) {
+            // one record grid: the fields are disjoint iff their offsets inside a record are at least 4 bytes apart (cyclically)
+            const uintptr_t d = (ia <= oa ? oa - ia : ia - oa) % in_stride;
+            disjoint = d >= 4 && in_stride - d >= 4;
+        } else disjoint = false;
+    }
+    if (!(flags & SAVGOL_BATCH_REFERENCE_SUMMATION) && aligned && disjoint && count <= LAUNCH_MAX_LENGTH) {
+        const int mode = (variant == FULL) ? (int)filter->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
+        const bool poly = mode == SAVGOL_BOUNDARY_POLYNOMIAL;
+        const FilterPlan *plan = plan_get(ctx, filter, poly ? NEED_EDGES : 0u);
+        if (!plan) return -1;
+        sg::JobStrided job;
+        memset(&job, 0, sizeof(job));
+        job.in_pitch = (long long)in_channel_pitch; job.out_pitch = (long long)out_channel_pitch;
+        job.in_stride = (long long)in_stride; job.out_stride = (long long)out_stride;
+        job.length = (unsigned)count;
+        const unsigned TW = 64u * (unsigned)SG_VPL_NARROW * 4u;
+        job.tiles_per_channel = (unsigned)((count + TW - 1) / TW);
+        sg::division_magic(job.tiles_per_channel, &job.tpc_magic, &job.tpc_shift);
+        job.dt_inv = dt_inverse(filter);
+        job.store_lo = poly ? (unsigned)n : 0u;
+        job.store_hi = poly ? (unsigned)(count - n) : (unsigned)count;
+        job.flags = ((unsigned)mode & sg::JOB_MODE_MASK);
+        if (mode < 0 || mode > 255) job.flags = 255u;
+        if (job.dt_inv != 1.0f) job.flags |= sg::JOB_SCALE;
+        const size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / job.tiles_per_channel;
+        for (size_t c0 = 0; c0 < channels; c0 += max_ch) {
+            const size_t nc = (channels - c0 < max_ch) ? channels - c0 : max_ch;
+            job.in = reinterpret_cast<const char *>(ia) + c0 * in_channel_pitch;
+            job.out = reinterpret_cast<char *>(oa) + c0 * out_channel_pitch;
+            job.total_tiles = (unsigned)(nc * job.tiles_per_channel);
+            unsigned blocks = (job.total_tiles + 3u) / 4u;
+            blocks = (blocks + 7u) & ~7u;
+            if (sg::launch_strided(n, job, plan->taps32, blocks, st) != 0) return -1;
+        }
+        if (poly) {
+            const int eflags = (job.dt_inv != 1.0f ? 1 : 0) | (((flags & SAVGOL_BATCH_CORRECT_LEADING_EDGE) && (filter->config.derivative & 1)) ? 2 : 0);
+            if (sg1d_launch_edges_strided_f32(reinterpret_cast<const void *>(ia), reinterpret_cast<void *>(oa), (long long)in_channel_pitch, (long long)out_channel_pitch,
+                                              (long long)in_stride, (long long)out_stride, (long long)count, n, plan->d_edges, job.dt_inv, eflags, channels, st) != 0) {
+                sg_set_error("%s: edge kernel launch failed", who);
+                return -1;
+            }
+        }
+        return 0;
+    }
+
+    // ---- staged path (the reference's summation order, unaligned or overlapping fields, channels beyond 2^30 samples): gather the
+    //      field into dense rows, filter, scatter back.  The two dense frames are this call's own, allocated and freed in stream
+    //      order (hipMallocAsync / hipFreeAsync): no shared arena, no lock, no synchronise -- the call only enqueues. ----
+    const size_t ld = (count + 3) & ~(size_t)3;
     float *dense = nullptr;
     if (!sg::hip_ok(hipMallocAsync(reinterpret_cast<void **>(&dense), 2 * channels * ld * sizeof(float), st), "hipMallocAsync(strided scratch)")) return -1;
     float *result = dense + channels * ld;
@@ -524,7 +686,7 @@ int savgol_apply_strided_batch_f32(const SavgolFilter *filter, const void *d_in,
         sg_set_error("%s: gather launch failed", who);
         rc = -1;
     }
-    if (rc == 0 && enqueue_batch<float>(who, filter, dense, result, channels, count, ld, ld, g_boundary_aware.load() ? FULL : FULL_POLY_EDGES, st, g_reference_summation.load() != 0) != 0) rc = -1;
+    if (rc == 0 && enqueue_batch<float>(who, filter, dense, result, channels, count, ld, ld, variant, st, flags) != 0) rc = -1;
     if (rc == 0 && sg_launch_scatter_f32(result, ld, d_out, out_stride, out_offset, out_channel_pitch, channels, count, st) != 0) {
         sg_set_error("%s: scatter launch failed", who);
         rc = -1;
@@ -564,7 +726,7 @@ int savgol_apply(const SavgolFilter *filter, const float *input, float *output, 
     if (!d_in) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
     float *d_out = d_in + ld;
     bool ok = sg::hip_ok(hipMemcpyAsync(d_in, input, length * sizeof(float), hipMemcpyHostToDevice, nullptr), "H2D copy");
-    ok = ok && enqueue_batch<float>("savgol_apply", filter, d_in, d_out, 1, length, ld, ld, FULL, nullptr, /*reference order*/ true) == 0;
+    ok = ok && enqueue_batch<float>("savgol_apply", filter, d_in, d_out, 1, length, ld, ld, FULL, nullptr, host_call_flags()) == 0;
     ok = ok && sg::hip_ok(hipMemcpy(output, d_out, length * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");
     if (!ok) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
     return 0;
@@ -590,7 +752,7 @@ size_t savgol_apply_valid(const SavgolFilter *filter, const float *input, size_t
     if (!d_in) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
     float *d_out = d_in + ld;
     bool ok = sg::hip_ok(hipMemcpyAsync(d_in, input, input_length * sizeof(float), hipMemcpyHostToDevice, nullptr), "H2D copy");
-    ok = ok && enqueue_batch<float>("savgol_apply_valid", filter, d_in, d_out, 1, input_length, ld, ld, VALID, nullptr, /*reference order*/ true) == 0;
+    ok = ok && enqueue_batch<float>("savgol_apply_valid", filter, d_in, d_out, 1, input_length, ld, ld, VALID, nullptr, host_call_flags()) == 0;
     ok = ok && sg::hip_ok(hipMemcpy(output, d_out, out_len * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");
     if (!ok) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
     return out_len;
@@ -613,7 +775,7 @@ int savgol_apply_strided(const SavgolFilter *filter, const void *input, size_t i
     const char *ib = static_cast<const char *>(input) + in_offset;
     for (size_t i = 0; i < count; ++i) memcpy(&stage[i], ib + i * in_stride, sizeof(float));
     bool ok = sg::hip_ok(hipMemcpy(d_in, stage, count * sizeof(float), hipMemcpyHostToDevice), "H2D copy");
-    ok = ok && enqueue_batch<float>("savgol_apply_strided", filter, d_in, d_out, 1, count, ld, ld, g_boundary_aware.load() ? FULL : FULL_POLY_EDGES, nullptr, /*reference order*/ true) == 0;
+    ok = ok && enqueue_batch<float>("savgol_apply_strided", filter, d_in, d_out, 1, count, ld, ld, (host_call_flags() & SAVGOL_BATCH_BOUNDARY_AWARE) ? FULL : FULL_POLY_EDGES, nullptr, host_call_flags()) == 0;
     ok = ok && sg::hip_ok(hipMemcpy(stage, d_out, count * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");
     if (!ok) { fprintf(stderr, "savgol_apply_strided: %s\n", savgol_hip_last_error()); return -1; }
     char *ob = static_cast<char *>(output) + out_offset;

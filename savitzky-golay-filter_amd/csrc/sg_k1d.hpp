@@ -398,6 +398,96 @@ __global__ __launch_bounds__(256, (K1D<T, N, V>::MIN_WAVES)) void sg1d_center_ke
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same tile on array-of-structs data (reference savgol_apply_strided, savgolFilter.c:877-934: every window is copied out
+// of the records into a 65-float stack buffer, :904-906).  Here the FIELD is gathered while the tile is staged -- lane l takes
+// samples l, l + 64, ... of tile + halo, one dword load each, straight into the slab -- and scattered from the slab when the
+// results leave: one pass over the records instead of round 2's gather kernel -> dense kernels -> scatter kernel (three passes
+// and two dense scratch frames).  Everything between staging and store is the dense kernel's (Conv<float, N>, same slab).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256, (K1D<float, N, SG_VPL_NARROW>::MIN_WAVES)) void sg1d_strided_kernel(const JobStrided job, const Taps taps)
+{
+    typedef K1D<float, N, SG_VPL_NARROW> K;
+    constexpr int R = K::R, TW = K::TW, NA = K::NA, VPL = K::VPL;
+    __shared__ __attribute__((aligned(16))) char smem[K::WAVES * K::SLAB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *slab = smem + wave * K::SLAB;
+
+    const unsigned nb8 = gridDim.x >> 3;
+    unsigned blk = blockIdx.x;
+    if (blk < nb8 * 8u) blk = (blk & 7u) * nb8 + (blk >> 3);
+    const unsigned tile = blk * K::WAVES + wave;
+    if (tile >= job.total_tiles) return;                                  // wave-uniform
+    const int L = (int)job.length;
+    const int mode = (int)(job.flags & JOB_MODE_MASK);
+    const unsigned c = job.tpc_shift >= 32 ? tile : (__umulhi(tile, job.tpc_magic) >> job.tpc_shift);
+    const int ts = (int)(tile - c * job.tiles_per_channel) * TW;
+    const char *__restrict__ row = job.in + (long long)c * job.in_pitch;
+    char *__restrict__ orow = job.out + (long long)c * job.out_pitch;
+
+    // slab byte offset of element i = lane + 64 k: vector i/4 = lane/4 + 16 k, and with VPL = 8 the pad count splits the same way
+    static_assert(VPL == 8, "the element <-> slab offset split below is written for 8 vectors per lane");
+    char *const mine = slab + 16 * ((lane >> 2) + (lane >> 5)) + 4 * (lane & 3);
+    constexpr int KSTEP = 16 * 18;                                        // 16 vectors + 2 pads per 64 elements
+    constexpr int NK = (K::SL + 63) / 64;
+
+    // ---- stage tile + halo: sample g = ts - NA + i of this channel's field ----
+    if (ts - NA >= 0 && ts + TW + NA <= L) {
+        const char *p = row + (long long)(ts - NA + lane) * job.in_stride;
+        float x[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+            if (lane + 64 * k < K::SL) x[k] = *reinterpret_cast<const float *>(p + (long long)(64 * k) * job.in_stride);
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+            if (lane + 64 * k < K::SL) *reinterpret_cast<float *>(mine + k * KSTEP) = x[k];
+    } else {
+        // channel ends: samples outside the row through the boundary mode's remap (get_padded_sample, :442-482); POLYNOMIAL
+        // (and anything unknown) reads zeros there -- the outputs that would see them are the edge kernel's, not stored here
+#pragma unroll 4
+        for (int k = 0; k < NK; ++k) {
+            const int i = lane + 64 * k;
+            int g = ts - NA + i;
+            if (i < K::SL && g < L + NA) {
+                bool zero = false;
+                if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
+                const float x = zero ? 0.0f : *reinterpret_cast<const float *>(row + (long long)g * job.in_stride);
+                *reinterpret_cast<float *>(mine + k * KSTEP) = x;
+            }
+        }
+    }
+    wave_lds_sync();
+
+    float acc[R];
+    Conv<float, N, SG_VPL_NARROW>::run(slab + 16 * (lane * (VPL + 1)), taps, acc);
+    if (job.flags & JOB_SCALE) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] *= job.dt_inv;
+    }
+    wave_lds_sync();                                   // all window reads done before overwrite
+#pragma unroll
+    for (int s = 0; s < VPL; ++s)
+        *reinterpret_cast<float4 *>(slab + 16 * (lane * (VPL + 1) + s)) = float4{acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]};
+    wave_lds_sync();
+
+    // ---- results out of the slab, element lane + 64 k of the tile -> its record ----
+    const int lo = (int)job.store_lo, hi = (int)job.store_hi;
+    char *q = orow + (long long)(ts + lane) * job.out_stride;
+    if (ts >= lo && ts + TW <= hi) {
+#pragma unroll
+        for (int k = 0; k < TW / 64; ++k)
+            *reinterpret_cast<float *>(q + (long long)(64 * k) * job.out_stride) = *reinterpret_cast<const float *>(mine + k * KSTEP);
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < TW / 64; ++k) {
+            const int g = ts + lane + 64 * k;
+            if (g >= lo && g < hi) *reinterpret_cast<float *>(q + (long long)(64 * k) * job.out_stride) = *reinterpret_cast<const float *>(mine + k * KSTEP);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // POLYNOMIAL edge rows (reference savgolFilter.c:773-784): for each channel end, n outputs, each
 // its own 2n+1-tap row of edge_weights.  One wave per (channel, end); lanes hold the taps
 // (lane l: taps l and l+64), the dot product is a wavefront butterfly reduction.

@@ -54,6 +54,10 @@ constexpr int wide_vectors_per_lane(size_t elem_size, int half_window)
     return (elem_size == 8 ? half_window <= SG_WIDE_F64_MAX16 : half_window <= SG_WIDE_F32_MAX16) ? 16 : vectors_per_lane(elem_size, half_window);
 #endif
 }
+// Tiles one launch may hold: the tile kernels run one tile per wave and four waves per 256-thread block, and HIP rejects a launch
+// whose gridDim.x * blockDim.x reaches 2^32 (hip_runtime_api.h), i.e. 2^24 blocks.  Bigger jobs (tens of millions of short
+// channels) are split over channels by the host.
+constexpr unsigned MAX_TILES_PER_LAUNCH = 4u * ((1u << 24) - 8u);
 // a job gets the wide tile when it has at least this many of them (8 rounds of the 2048 waves the chip holds at 2 per SIMD)
 constexpr unsigned long long WIDE_TILE_MIN_TILES = 16384;
 
@@ -69,6 +73,21 @@ struct Job1D {
     unsigned    out_shift;              // ... at out[c*out_ld + g - out_shift]
     float       dt_inv;
     unsigned    flags;                  // FLAG_* below; boundary mode in the low byte
+};
+// The fused strided (array-of-structs) kernel, sg1d_strided_kernel<N> (reference savgol_apply_strided, src/savgolFilter.c:877-934):
+// sample i of channel c is the float at in + c * in_pitch + i * in_stride (bytes; the field offset is folded into `in`), all
+// 4-byte aligned.  Same tiles, same slab and the same inner product as the dense kernel; only the staging loads and the
+// stores walk records.
+struct JobStrided {
+    const char *in;
+    char       *out;
+    long long   in_pitch, out_pitch;    // bytes between channels
+    long long   in_stride, out_stride;  // bytes between elements
+    unsigned    length;
+    unsigned    tiles_per_channel, total_tiles, tpc_magic, tpc_shift;
+    unsigned    store_lo, store_hi;     // sample indices whose result is stored
+    float       dt_inv;
+    unsigned    flags;                  // boundary mode in the low byte, JOB_SCALE
 };
 // Division by an invariant on the scalar unit (gfx950 has s_mul_hi_u32 but no scalar divide; left as `/` the compiler
 // runs the float-reciprocal sequence on the VECTOR unit, ~25 instructions per tile in a kernel that is VALU-issue bound).
@@ -120,6 +139,13 @@ int sg1d_launch_f32_g0(int n, int wide, const sg::Job1D *job, const sg::Taps *ta
 int sg1d_launch_f32_g1(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
 int sg1d_launch_f32_g2(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
 int sg1d_launch_f32_g3(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
+// fused strided kernel, fp32, one launcher per half-window group (same objects as the dense fp32 kernels); 1 if this group owns n
+int sg1d_launch_strided_f32_g0(int n, const sg::JobStrided *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_strided_f32_g1(int n, const sg::JobStrided *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_strided_f32_g2(int n, const sg::JobStrided *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_strided_f32_g3(int n, const sg::JobStrided *job, const sg::Taps *taps, unsigned grid, void *stream);
+int sg1d_launch_edges_strided_f32(const void *in, void *out, long long in_pitch, long long out_pitch, long long in_stride, long long out_stride,
+                                  long long L, int n, const float *d_edges, float dt_inv, int flags, size_t channels, void *st);
 int sg1d_launch_f64_g0(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
 int sg1d_launch_f64_g1(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
 int sg1d_launch_f64_g2(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
@@ -169,6 +195,16 @@ template <> inline int launch_center<double>(int n, int wide, const Job1D &job, 
     if (!hit) { sg_set_error("no fp64 kernel for half_window %d", n); return -1; }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sg_set_error("1-D kernel launch failed: %s", hipGetErrorString(e)); return -1; }
+    return 0;
+}
+
+inline int launch_strided(int n, const JobStrided &job, const Taps &taps, unsigned grid, hipStream_t st)
+{
+    const int hit = sg1d_launch_strided_f32_g0(n, &job, &taps, grid, st) || sg1d_launch_strided_f32_g1(n, &job, &taps, grid, st) ||
+                    sg1d_launch_strided_f32_g2(n, &job, &taps, grid, st) || sg1d_launch_strided_f32_g3(n, &job, &taps, grid, st);
+    if (!hit) { sg_set_error("no strided kernel for half_window %d", n); return -1; }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sg_set_error("strided kernel launch failed: %s", hipGetErrorString(e)); return -1; }
     return 0;
 }
 

@@ -42,7 +42,25 @@ struct Dispatch1D {
     }
 };
 
+#ifdef SG_FN_STRIDED
+template <int N, int HI>
+static int dispatch_strided(int n, const JobStrided &job, const Taps &taps, unsigned grid, hipStream_t st)
+{
+    if (n == N) { hipLaunchKernelGGL((sg1d_strided_kernel<N>), dim3(grid), dim3(256), 0, st, job, taps); return 1; }
+    if constexpr (N < HI) return dispatch_strided<N + 1, HI>(n, job, taps, grid, st);
+    else return 0;
+}
+#endif
+
 }  // namespace sg
+
+#ifdef SG_FN_STRIDED
+// the fused strided kernel of this group's half windows (fp32 objects only); 1 if this group owns n
+extern "C" int SG_FN_STRIDED(int n, const sg::JobStrided *job, const sg::Taps *taps, unsigned grid, void *stream)
+{
+    return sg::dispatch_strided<SG_NLO, SG_NHI>(n, *job, *taps, grid, static_cast<hipStream_t>(stream));
+}
+#endif
 
 // returns 1 if this group owns half window n (kernel enqueued), 0 otherwise
 extern "C" int SG_FN(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream)

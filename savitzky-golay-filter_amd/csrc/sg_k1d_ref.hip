@@ -199,7 +199,9 @@ extern "C" int sg1d_launch_refpk_f32(const float *in, float *out, long long in_l
     division_magic(job.tiles_per_channel, &job.tpc_magic, &job.tpc_shift);
     job.vec_in = (in_ld % 4 == 0);
     job.vec_out = (out_ld % 4 == 0) && (out_shift % 4 == 0);
-    const size_t max_ch = (size_t)0x7fffffffu / job.tiles_per_channel;
+    // one tile per wave, four waves per block: a launch holds < 2^24 blocks (HIP rejects gridDim.x * blockDim.x >= 2^32)
+    size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / job.tiles_per_channel;
+    if (max_ch == 0) max_ch = 1;                     // cannot happen: a channel of 2^30 samples is 2^21 tiles
     for (size_t c0 = 0; c0 < channels; c0 += max_ch) {
         const size_t nc = channels - c0 < max_ch ? channels - c0 : max_ch;
         job.in = in + c0 * in_ld; job.out = out + c0 * out_ld;

@@ -49,13 +49,6 @@ DeviceCtx *ctx_get()
     return g_ctx[dev];
 }
 
-static uint64_t fnv1a(const void *p, size_t n, uint64_t h)
-{
-    const unsigned char *b = static_cast<const unsigned char *>(p);
-    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
-    return h;
-}
-
 // Entries are never freed while the process lives: callers keep the returned pointer past the call -- a stream bank for its
 // whole life, a captured hipGraph for as long as it is replayed, a launch that is still queued -- so evicting (round 1 dropped
 // the oldest half at 256 entries) handed out memory that later kernels still read.  A table is at most 9 KB and there is one
@@ -63,10 +56,11 @@ static uint64_t fnv1a(const void *p, size_t n, uint64_t h)
 // compares the content, not just the 64-bit key.
 const float *ctx_table(DeviceCtx *ctx, const void *host, size_t bytes, uint64_t salt)
 {
-    const uint64_t key = fnv1a(host, bytes, 0xcbf29ce484222325ull ^ salt);
+    const uint64_t key = hash64(host, bytes, salt);
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-    for (const TableEntry &t : ctx->tables)
-        if (t.key == key && t.bytes == bytes && memcmp(t.host.data(), host, bytes) == 0) return t.dev;
+    auto range = ctx->tables.equal_range(key);
+    for (auto it = range.first; it != range.second; ++it)
+        if (it->second.bytes == bytes && memcmp(it->second.host.data(), host, bytes) == 0) return it->second.dev;
     float *dev = nullptr;
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&dev), bytes), "hipMalloc(weight table)")) return nullptr;
     if (!hip_ok(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(weight table)")) {
@@ -76,7 +70,7 @@ const float *ctx_table(DeviceCtx *ctx, const void *host, size_t bytes, uint64_t 
     TableEntry e;
     e.key = key; e.bytes = bytes; e.dev = dev;
     e.host.assign(static_cast<const unsigned char *>(host), static_cast<const unsigned char *>(host) + bytes);
-    ctx->tables.push_back(std::move(e));
+    ctx->tables.emplace(key, std::move(e));
     return dev;
 }
 

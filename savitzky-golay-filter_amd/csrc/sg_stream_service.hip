@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -196,22 +197,49 @@ static bool launch_service(int n, const ServiceArgs &args, const float *cw, unsi
     else return false;
 }
 
+// How many waves of the service kernel for half window n the device holds at once: every wave of the service must be resident
+// (a wave that is not scheduled never answers the doorbell), and the n = 32 instance keeps 260+ VGPRs of accumulators -- one wave
+// per SIMD.  Occupancy API x compute units of THIS device (a partition may have fewer than 256).
+template <int N>
+static long service_resident_waves(int n, int cu_count)
+{
+    if (n == N) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg_bank_service_kernel<N>, 64, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); return -1; }
+        return (long)nb * cu_count;
+    }
+    if constexpr (N < SAVGOL_MAX_HALF_WINDOW) return service_resident_waves<N + 1>(n, cu_count);
+    else return -1;
+}
+
 // Can the host really store into fine-grained device memory on this box?  isLargeBar says the BAR covers the memory, not that
 // the allocation is mapped for the CPU; a store into an unmapped one is a SIGSEGV / SIGBUS.  Probed ONCE per process under a
 // guard (handlers saved and restored around the single store), because the alternative is to crash the caller.
+// Multithreaded hosts: the probe runs once, under a mutex; the handler only jumps when the fault happened on the probing thread
+// inside the probe window (thread-local flag) -- a fault of any other thread during that window puts the previous handler back
+// and returns, so the faulting instruction runs again and reaches the handler it would have reached without us.
 static sigjmp_buf g_probe_jmp;
-static void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
+static thread_local volatile sig_atomic_t tl_probing = 0;
+static struct sigaction g_probe_old_segv, g_probe_old_bus;
+static void probe_fault(int sig)
+{
+    if (tl_probing) siglongjmp(g_probe_jmp, 1);
+    sigaction(sig, sig == SIGSEGV ? &g_probe_old_segv : &g_probe_old_bus, nullptr);
+}
 static bool host_can_write_device_memory(void *p)
 {
+    static std::mutex mu;
     static int verdict = -1;                                 // -1 unknown, 0 no, 1 yes
+    std::lock_guard<std::mutex> lock(mu);
     if (verdict >= 0) return verdict == 1;
-    struct sigaction old_segv, old_bus, sa;
+    struct sigaction sa;
     memset(&sa, 0, sizeof(sa));
     sa.sa_handler = probe_fault;
     sigemptyset(&sa.sa_mask);
-    sigaction(SIGSEGV, &sa, &old_segv);
-    sigaction(SIGBUS, &sa, &old_bus);
+    sigaction(SIGSEGV, &sa, &g_probe_old_segv);
+    sigaction(SIGBUS, &sa, &g_probe_old_bus);
     if (sigsetjmp(g_probe_jmp, 1) == 0) {
+        tl_probing = 1;
         volatile unsigned long long *w = static_cast<volatile unsigned long long *>(p);
         w[0] = 0x5347u;
         _mm_sfence();
@@ -221,9 +249,16 @@ static bool host_can_write_device_memory(void *p)
     } else {
         verdict = 0;
     }
-    sigaction(SIGSEGV, &old_segv, nullptr);
-    sigaction(SIGBUS, &old_bus, nullptr);
+    tl_probing = 0;
+    sigaction(SIGSEGV, &g_probe_old_segv, nullptr);
+    sigaction(SIGBUS, &g_probe_old_bus, nullptr);
     return verdict == 1;
+}
+
+static double service_timeout_s()                            // SAVGOL_HIP_SERVICE_TIMEOUT_MS: how long a tick waits for every wave (tests shorten it)
+{
+    static const double v = [] { const char *e = getenv("SAVGOL_HIP_SERVICE_TIMEOUT_MS"); const int ms = e ? atoi(e) : 0; return ms > 0 ? ms * 1e-3 : 5.0; }();
+    return v;
 }
 
 static void service_free(BankService *s)
@@ -277,7 +312,17 @@ int savgol_streambank_service_start(SavgolStreamBank *bank, unsigned idle_ms)
     s->idle_ms = idle_ms ? idle_ms : 1000;
     if (const char *e = getenv("SAVGOL_HIP_SERVICE_BELLS")) { const int b = atoi(e); if (b >= 1 && b <= (int)sg::SERVICE_BELLS) s->bells = (unsigned)b; }      // tuning knob
     hipDeviceProp_t prop;
-    bool ok = sg::hip_ok(hipGetDeviceProperties(&prop, bank->device), who) && sg::hip_ok(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), who);
+    bool ok = sg::hip_ok(hipGetDeviceProperties(&prop, bank->device), who);
+    if (ok) {
+        const long fit = sg::service_resident_waves<1>(bank->filter->config.half_window, prop.multiProcessorCount);
+        if (fit < (long)waves) {
+            sg_set_error("%s: %zu streams need %zu resident waves but this device holds %ld of the half_window %d service kernel at once "
+                         "(%d compute units); use savgol_streambank_push", who, bank->streams, waves, fit, bank->filter->config.half_window,
+                         prop.multiProcessorCount);
+            ok = false;
+        }
+    }
+    ok = ok && sg::hip_ok(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), who);
     unsigned *done = nullptr;
     ok = ok && sg::hip_ok(hipHostMalloc(reinterpret_cast<void **>(&done), sizeof(unsigned) * waves, hipHostMallocCoherent | hipHostMallocMapped), who) &&
          sg::hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->done_dev), done, 0), who);
@@ -330,8 +375,24 @@ int savgol_streambank_service_tick(SavgolStreamBank *bank, const float *d_sample
             const unsigned d = s->done_host[w];
             if (d == (unsigned)seq) { ++w; continue; }
             if (d == sg::SERVICE_EXITED) { exited = true; break; }
-            if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
-                sg_set_error("%s: no answer from the resident kernel for 5 s (wave %u reports %u, expected %llu)", who, w, d, seq);
+            if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > sg::service_timeout_s()) {
+                // Some waves may have taken this tick (accumulators advanced, slot wp of the ring and part of d_out written), the
+                // bank's counters have not moved.  Do not leave that kernel resident: stop it -- waves still waiting for this tick
+                // first, then those already waiting for the next one; a wave that never became resident leaves on its idle
+                // time-out -- and mark the service not running.  The next tick relaunches from the bank's state, which is
+                // idempotent: the warm-up reads the 2n newest ring slots, and slot wp is not one of them.
+                for (int phase = 0; phase < 2; ++phase) {
+                    const unsigned long long sq = seq + (unsigned)phase;
+                    for (unsigned b = 0; b < sg::SERVICE_BELLS; ++b) { mb[b].seq_a = sq; mb[b].seq_b = sq | (sg::SERVICE_CMD_STOP << 62); }
+                    _mm_sfence();
+                    const auto p0 = std::chrono::steady_clock::now();
+                    while (phase == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - p0).count() < 0.02) {}
+                }
+                (void)hipStreamSynchronize(s->stream);
+                (void)hipGetLastError();
+                s->running = false;
+                sg_set_error("%s: no answer from the resident kernel for %.1f s (wave %u reports %u, expected %llu); the service kernel was "
+                             "stopped and restarts from the bank's state on the next tick", who, sg::service_timeout_s(), w, d, seq);
                 return -1;
             }
         }

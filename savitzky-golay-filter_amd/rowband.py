@@ -34,6 +34,8 @@ class RowBand:
         spans = [shard_range(rows, self.world, r) for r in range(self.world)]
         if self.world > 1 and min(hi - lo for lo, hi in spans) < ny:
             raise ValueError(f"row bands thinner than the half window ({ny}): use fewer ranks")
+        # apply_overlapped / apply_c rebuild an artificial edge from the band's own 2*ny rows next to it
+        self.thin = self.world > 1 and min(hi - lo for lo, hi in spans) < 2 * ny
         self.top = ny if self.rank > 0 else 0                 # halo rows received from above / below
         self.bottom = ny if self.rank < self.world - 1 else 0
 
@@ -93,6 +95,23 @@ class RowBand:
             r.wait()
         return bufs.get("up"), bufs.get("dn")
 
+    def apply_c(self, filter2d, local, boundary=1, method=0, stream=None):
+        """The same through the C ABI (savgol2d_apply_rowband_f32, csrc/sg_2d_rowband.hip): post the exchange, enqueue the
+        band + its edge strips in ONE call given the received halo rows.  `local`: [images, own, cols] fp32 on the GPU."""
+        from . import lib, last_error, _addr, _stream
+        images, own, cols = local.shape
+        if self.thin:
+            raise ValueError(f"row bands thinner than 2 x half window ({2 * self.ny}): use fewer ranks")
+        local = local.contiguous()
+        up, dn = self.finish_exchange(self.start_exchange(local))
+        out = torch.empty_like(local)
+        rc = lib().savgol2d_apply_rowband_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols,
+                                              _addr(up) if up is not None else None, _addr(dn) if dn is not None else None,
+                                              cols, self.ny * cols, _addr(out), cols, own * cols, images, boundary, method, _stream(stream))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return out
+
     def apply_overlapped(self, local, apply_fn):
         """Filter this rank's band with the halo exchange in flight.
 
@@ -104,6 +123,9 @@ class RowBand:
         No extended copy of the band is made; the strips are 3*ny/own of the work (0.5 % for 4096-row bands, ny = 7)."""
         images, own, cols = local.shape
         ny = self.ny
+        if self.thin:
+            # bands of ny .. 2*ny - 1 rows: the 3*ny-row strips would reach past the band -- the simple form handles them
+            return self.apply(self.exchange(local), apply_fn)
         handle = self.start_exchange(local)
         out = apply_fn(local)
         up, dn = self.finish_exchange(handle)

@@ -488,6 +488,10 @@ def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu, n):
                                   (4, 1, 0, 2e-6, 0.25), (4, 2, 1, 2e-5, 1e-3)]:          # time_step != 1: the dt_inv multiply after the sum
         f = sg.Filter(n, m, d, dt, mode)
         ref = sgo.Filter(n, m, d, dt, mode).apply_f64(xh)
+        if d == 2:
+            # second derivatives at half windows 24..32 are ill-conditioned in fp32 (taps of both signs, ~1e-4 of the input): the
+            # bar is the reference's OWN fp32 error on the same samples (oracle's bit-exact restatement), not a fixed 2e-5
+            tol = max(1e-6, normwise(sgo.Filter(n, m, d, dt, mode).apply(xh.astype(np.float32)), ref))
         a = f.apply_tensor(x).cpu().numpy()
         assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 1) == 0
         try:
@@ -641,3 +645,186 @@ def test_wide_and_narrow_tiles_give_the_same_bits_on_ragged_batches(sg, sgo, tor
         assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_TILE_WIDTH, 3) == -1
     finally:
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_TILE_WIDTH, 0)
+
+
+@pytest.mark.parametrize("n", [24, 25, 26, 27, 28, 29, 30, 31, 32, 5, 12, 16, 20])
+def test_fp32_kernels_are_never_worse_than_the_reference_itself(sg, sgo, torch_gpu, n):
+    """some fp32 bars are wider than north_star's 1e-6 (2e-6 for derivatives, 2e-5 for d = 2 at wide
+    windows).  What justifies them is conditioning, not the kernels -- shown here: for every (m <= 6, d <= 2, boundary mode) at
+    this half window the default device kernel (FMA sum; block moments from n = 24) is within
+        max(1e-6, the error of the REFERENCE's own fp32 savgol_apply on the same samples)
+    of the double-accumulation oracle, the reference's error being the oracle's bit-exact fp32 restatement of
+    /root/reference/src/savgolFilter.c:743-804 (pinned to the compiled reference in tests/test_oracle_pinned.py).  Smoothing
+    filters must meet 1e-6 outright."""
+    torch = torch_gpu
+    x = torch.empty((5, 40000 + 17 * n), dtype=torch.float32, device="cuda")
+    sg.synth(x, channel0=3 * n)
+    xh = x.cpu().numpy()
+    worst = 0.0
+    for m in range(0, 7):
+        for d in range(0, min(m, 2) + 1):
+            for mode, dt in ((0, 1.0), (1, 1.0), (2, 0.5), (3, 1.0)):
+                o = sgo.Filter(n, m, d, dt, mode)
+                ref64 = o.apply_f64(xh.astype(np.float64))
+                e_ref = normwise(o.apply(xh), ref64)
+                got = sg.Filter(n, m, d, dt, mode).apply_tensor(x).cpu().numpy()
+                e = normwise(got, ref64)
+                bar = 1e-6 if d == 0 else max(1e-6, e_ref)
+                assert e <= bar, (n, m, d, mode, e, e_ref)
+                worst = max(worst, e / bar)
+    assert worst <= 1.0
+
+
+@pytest.mark.parametrize("n,m,d,dt", [(1, 1, 0, 1.0), (5, 3, 0, 1.0), (16, 2, 1, 1e-3), (24, 4, 0, 1.0), (32, 4, 0, 1.0), (32, 4, 2, 0.5), (13, 5, 1, 1.0)])
+def test_fused_strided_kernel(sg, sgo, torch_gpu, n, m, d, dt):
+    """savgol_apply_strided_batch_f32 on 4-byte aligned, disjoint fields runs ONE kernel that gathers the field while it stages a
+    tile and scatters from the slab (sg1d_strided_kernel; reference savgolFilter.c:877-934).  Against the fp64 oracle on the
+    field (1e-6 / 2e-6; polynomial edges whatever config.boundary says), the other fields untouched bit for bit; record sizes of
+    2, 3, 5 and 16 floats; separate arrays and the SAME array with another field (in-place AoS); counts that end inside a tile,
+    a single short row; the staged path (same field in place; REFERENCE_SUMMATION -> the reference's bits) still there."""
+    torch = torch_gpu
+    L = sg.lib()
+    rng = np.random.default_rng(100 * n + m)
+    tol = 1e-6 if d == 0 else 2e-6
+    for rec, ch, count in ((2, 3, 5000), (3, 2, 2 * n + 1), (5, 4, 2048 + 2 * n + 3), (16, 2, 6200)):
+        aos = rng.normal(0, 1, (ch, count, rec)).astype(np.float32)
+        aos[:, :, 1] = signal(rng, (ch, count)).astype(np.float32)
+        ref64 = sgo.Filter(n, m, d, dt, 0).apply_f64(aos[:, :, 1].astype(np.float64))
+        if d == 2:
+            tol = max(2e-6, normwise(sgo.Filter(n, m, d, dt, 0).apply(aos[:, :, 1]), ref64))
+        f = sg.Filter(n, m, d, dt, sg.SAVGOL_BOUNDARY_REFLECT)                  # must be ignored
+        # (a) separate arrays, field 1 -> field 0 of records of the same size
+        src = torch.from_numpy(aos).cuda()
+        dst_h = rng.normal(0, 1, (ch, count, rec)).astype(np.float32)
+        dst = torch.from_numpy(dst_h).cuda()
+        assert L.savgol_apply_strided_batch_f32(f.ptr, src.data_ptr(), rec * 4, 4, count * rec * 4, dst.data_ptr(), rec * 4, 0, count * rec * 4,
+                                                ch, count, None) == 0, sg.last_error()
+        out = dst.cpu().numpy()
+        assert normwise(out[:, :, 0], ref64) < tol, (rec, normwise(out[:, :, 0], ref64))
+        assert same_bits(out[:, :, 1:], dst_h[:, :, 1:]) and same_bits(src.cpu().numpy(), aos)
+        # (b) the same array, field 1 -> field rec-1 (in-place AoS): still the fused kernel
+        both = torch.from_numpy(aos).cuda()
+        assert L.savgol_apply_strided_batch_f32(f.ptr, both.data_ptr(), rec * 4, 4, count * rec * 4, both.data_ptr(), rec * 4, (rec - 1) * 4 if rec > 2 else 0,
+                                                count * rec * 4, ch, count, None) == 0, sg.last_error()
+        out2 = both.cpu().numpy()
+        tgt = rec - 1 if rec > 2 else 0
+        assert same_bits(out2[:, :, tgt], out[:, :, 0])                          # same kernel, same bits as (a)
+        keep = [k for k in range(rec) if k != tgt]
+        assert same_bits(out2[:, :, keep], aos[:, :, keep])
+        # (c) REFERENCE_SUMMATION: the staged path, bit-identical to the reference's savgol_apply_strided
+        refd = torch.from_numpy(aos).cuda()
+        assert L.savgol_apply_strided_batch_f32_ex(f.ptr, refd.data_ptr(), rec * 4, 4, count * rec * 4, refd.data_ptr(), rec * 4, 4, count * rec * 4,
+                                                   ch, count, sg.SAVGOL_BATCH_REFERENCE_SUMMATION, None) == 0, sg.last_error()
+        want32 = sgo.Filter(n, m, d, dt, 0).apply(aos[:, :, 1])
+        assert same_bits(refd.cpu().numpy()[:, :, 1], want32)
+        # (d) same field in place without the flag: staged path with the fast kernels, still within the bar
+        inpl = torch.from_numpy(aos).cuda()
+        assert L.savgol_apply_strided_batch_f32(f.ptr, inpl.data_ptr(), rec * 4, 4, count * rec * 4, inpl.data_ptr(), rec * 4, 4, count * rec * 4,
+                                                ch, count, None) == 0
+        assert normwise(inpl.cpu().numpy()[:, :, 1], ref64) < tol
+    # boundary-aware flag: the configured mode instead of the polynomial rows, per call
+    for mode in (1, 2, 3):
+        rec, ch, count = 4, 3, 4321
+        aos = rng.normal(0, 1, (ch, count, rec)).astype(np.float32)
+        f = sg.Filter(n, m, d, dt, mode)
+        src = torch.from_numpy(aos).cuda(); dst = torch.zeros_like(src)
+        assert L.savgol_apply_strided_batch_f32_ex(f.ptr, src.data_ptr(), 16, 8, count * 16, dst.data_ptr(), 16, 12, count * 16, ch, count,
+                                                   sg.SAVGOL_BATCH_BOUNDARY_AWARE, None) == 0, sg.last_error()
+        ref64 = sgo.Filter(n, m, d, dt, mode).apply_f64(aos[:, :, 2].astype(np.float64))
+        bar = tol if d < 2 else max(tol, normwise(sgo.Filter(n, m, d, dt, mode).apply(aos[:, :, 2]), ref64))
+        assert normwise(dst.cpu().numpy()[:, :, 3], ref64) < bar, mode
+        assert not dst.cpu().numpy()[:, :, :3].any()
+    assert L.savgol_apply_strided_batch_f32_ex(f.ptr, src.data_ptr(), 16, 8, count * 16, dst.data_ptr(), 16, 12, count * 16, ch, count, 1 << 20, None) == -1
+
+
+def test_per_call_flags_from_concurrent_threads(sg, sgo, torch_gpu):
+    """the summation order / tile width / edge fix were process-global atomics.  The *_ex entry points take
+    them per call: four threads run four different flag words on the same filter at the same time, each must get exactly what
+    its flags ask for (the reference's bits; the plain 65-tap sum; the default block-moment kernel; the corrected leading edge),
+    and the process defaults stay untouched."""
+    import threading
+    torch = torch_gpu
+    L = sg.lib()
+    n, m = 32, 4
+    x = torch.empty((64, 30011), dtype=torch.float32, device="cuda")
+    sg.synth(x)
+    xh = x.cpu().numpy()
+    f = sg.Filter(n, m, 1, 1.0, 0)                                   # derivative 1: the leading-edge sign matters
+    base = {"default": 0, "reference": sg.SAVGOL_BATCH_REFERENCE_SUMMATION, "plain": sg.SAVGOL_BATCH_PLAIN_SUMMATION,
+            "edge": sg.SAVGOL_BATCH_CORRECT_LEADING_EDGE | sg.SAVGOL_BATCH_REFERENCE_SUMMATION}
+    want = {k: f.apply_tensor(x, flags=v).cpu().numpy() for k, v in base.items()}          # one thread first
+    ref32 = sgo.Filter(n, m, 1, 1.0, 0).apply(xh)
+    assert same_bits(want["reference"], ref32)
+    assert not np.array_equal(want["default"], want["plain"]) and not np.array_equal(want["default"], want["reference"])
+    assert same_bits(want["edge"][:, :n], -ref32[:, :n]) and same_bits(want["edge"][:, n:], ref32[:, n:])
+    assert L.savgol_hip_default_flags() == 0
+    errors = []
+
+    def worker(name):
+        try:
+            s = torch.cuda.Stream()
+            y = torch.empty_like(x)
+            for _ in range(40):
+                f.apply_batch(x, y, x.shape[0], x.shape[1], stream=s, flags=base[name])
+            s.synchronize()
+            if not same_bits(y.cpu().numpy(), want[name]):
+                errors.append(name)
+        except Exception as e:                                       # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in base for _ in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert L.savgol_hip_default_flags() == 0
+    # the process-wide options are the defaults of the non-_ex calls, and show up in default_flags()
+    assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 1) == 0
+    try:
+        assert L.savgol_hip_default_flags() == sg.SAVGOL_BATCH_REFERENCE_SUMMATION
+        assert same_bits(f.apply_tensor(x).cpu().numpy(), want["reference"])
+        assert same_bits(f.apply_tensor(x, flags=0).cpu().numpy(), want["default"])          # an _ex call ignores the defaults
+    finally:
+        L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 0)
+
+
+def test_interleaved_rows_are_not_an_overlap(sg, sgo, torch_gpu):
+    """in = buf[:, 0, :], out = buf[:, 1, :] (equal pitches 2 L) never share a byte; the extent test of round 2 refused
+    them.  Rows that do touch are still refused."""
+    torch = torch_gpu
+    ch, length = 6, 5000
+    f = sg.Filter(8, 3)
+    buf = torch.zeros((ch, 2, length), dtype=torch.float32, device="cuda")
+    src = torch.empty((ch, length), device="cuda"); sg.synth(src)
+    buf[:, 0, :] = src
+    f.apply_batch(buf[:, 0, :], buf[:, 1, :], ch, length, in_ld=2 * length, out_ld=2 * length)
+    ref = sgo.Filter(8, 3).apply_f64(src.cpu().numpy().astype(np.float64))
+    assert normwise(buf[:, 1, :].cpu().numpy(), ref) < TOL_F32
+    assert torch.equal(buf[:, 0, :], src)
+    flat = buf.view(-1)
+    with pytest.raises(RuntimeError, match="overlap"):                   # output rows start inside the input rows
+        f.apply_batch(flat, flat[length // 2:], ch, length, in_ld=2 * length, out_ld=2 * length)
+
+
+def test_many_short_channels_split_below_the_launch_limit(sg, sgo, torch_gpu):
+    """one tile per wave means gridDim.x * 256 threads per launch, and HIP rejects 2^32: more than 2^26 tiles (here
+    70 M channels of 65 samples, 18 GB in + 18 GB out) must be split by the host, in the default and in the reference order."""
+    torch = torch_gpu
+    free, _ = torch.cuda.mem_get_info()
+    ch, length = 70_000_000, 65
+    if free < 2 * ch * length * 4 + (4 << 30):
+        pytest.skip("needs 40 GB of free HBM")
+    f = sg.Filter(32, 4, 0, 1.0, 1)
+    x = torch.empty((ch, length), dtype=torch.float32, device="cuda")
+    sg.synth(x[:1 << 20]); x[1 << 20:] = x[:1 << 20].repeat((ch + (1 << 20) - 1) // (1 << 20), 1)[:ch - (1 << 20)]
+    pick = [0, 1, (1 << 26) - 1, 1 << 26, (1 << 26) + 12345, ch - 1]
+    xh = x[pick].cpu().numpy()
+    for flags, check in ((0, lambda y: normwise(y, sgo.Filter(32, 4, 0, 1.0, 1).apply_f64(xh.astype(np.float64))) < TOL_F32),
+                         (sg.SAVGOL_BATCH_REFERENCE_SUMMATION, lambda y: same_bits(y, sgo.Filter(32, 4, 0, 1.0, 1).apply(xh)))):
+        y = torch.full_like(x, float("nan"))
+        f.apply_batch(x, y, ch, length, flags=flags)
+        torch.cuda.synchronize()
+        assert check(y[pick].cpu().numpy()), flags
+        assert not torch.isnan(y).any()
+        del y

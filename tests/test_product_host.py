@@ -33,6 +33,22 @@ def test_library_exports_every_declared_symbol(sg):
     assert not unbound, f"declared in include/*.h but not bound in the Python mirror: {unbound}"
 
 
+def test_optional_rccl_library_exports_its_header(sg):
+    """include/savgol_hip_rccl.h is served by lib/libsavgol_hip_rccl.so (the only object that links librccl); the main library
+    must NOT depend on RCCL."""
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "savgol_hip_rccl.h")).read(), flags=re.S)
+    names = set(re.findall(r"\b(savgol\w*)\s*\(", txt))
+    assert names == {"savgol2d_rowband_exchange_rccl"}
+    path = os.path.join(os.path.dirname(sg.LIB_PATH), "libsavgol_hip_rccl.so")
+    assert os.path.exists(path), "make builds it next to libsavgol_hip.so"
+    L = C.CDLL(path)
+    for n in names:
+        assert hasattr(L, n)
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", sg.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed and "nccl" not in needed
+
+
 def test_struct_layouts_match_reference(sg):
     # SURVEY 8b [probed on the reference]: sizes and field offsets are part of the drop-in contract
     assert C.sizeof(sg.SavgolConfig) == 12
