@@ -152,10 +152,23 @@ def timed(fn, reps=5, warm=1):
     return float(np.median(ts))
 
 
-def roofline(alg_bytes, ms, **more):
+def roofline(alg_bytes, ms, launches_ms=None, **more):
+    """`ms` = the average launch duration (what `achieved` is computed from); launches_ms = every timed launch, for the spread"""
     ach = alg_bytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), **more}
+    out = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+           "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), **more}
+    if launches_ms is not None and len(launches_ms):
+        med = float(np.median(launches_ms))
+        out.update({"median_launch_ms": round(med, 4), "min_launch_ms": round(float(np.min(launches_ms)), 4),
+                    "max_launch_ms": round(float(np.max(launches_ms)), 4), "frac_at_median": round(alg_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "launches_timed": len(launches_ms)})
+    return out
+
+
+def with_traffic(roof, pattern, files=None):
+    """roofline.traffic from the committed PMC summary of this kernel, when it was taken on the sources this run is built from"""
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["algorithmic_bytes_per_launch"], pattern, files)
+    return roof
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -267,9 +280,11 @@ def bench_stream(sg, a):
         bank.push(x[t % T], o1)
     e1.record(); torch.cuda.synchronize()
     tick_us = e0.elapsed_time(e1)
-    # (c) block push: T ticks in one launch
-    bank2 = sg.StreamBank(S, n, 2, 1, 1e-3)
-    ms = timed(lambda: bank2.push_block(x, T, out), reps=5, warm=1)
+    # (c) block push: T ticks in one launch -- the fused-multiply-add bank (SAVGOL_STREAMBANK_FMA) and the reference-order one
+    bank2 = sg.StreamBank(S, n, 2, 1, 1e-3, fma=True)
+    ms = timed(lambda: bank2.push_block(x, T, out), reps=7, warm=1)
+    bank2r = sg.StreamBank(S, n, 2, 1, 1e-3)
+    ms_ref = timed(lambda: bank2r.push_block(x, T, out), reps=7, warm=1)
     samples = S * T
     res = {
         "workload": f"BASELINE config 3: {S} streams, n=16, m=2, d=1, dt=1e-3",
@@ -278,7 +293,12 @@ def bench_stream(sg, a):
                             "Msamples_per_s": round(S / tick_us, 1)},
         "block_push": {"ticks_per_launch": T, "ms": round(ms, 3), "ns_per_sample": round(ms * 1e6 / samples, 5),
                        "Msamples_per_s": round(samples / ms / 1e3, 1),
-                       "roofline": roofline(8.0 * samples, ms, kernel="sg_bank_roll_kernel<16>", algorithmic_bytes_per_sample=8)},
+                       "summation": "SAVGOL_STREAMBANK_FMA (one v_pk_fma_f32 per tap and stream pair; <= 2e-6 of the fp64 oracle for this derivative filter)",
+                       "roofline": with_traffic(roofline(8.0 * samples, ms, kernel="sg_bank_roll_kernel<16,true>", algorithmic_bytes_per_sample=8),
+                                                "r*_stream_block_pmc_summary.json", SOURCES_STREAM)},
+        "block_push_reference_order": {"ms": round(ms_ref, 3), "Msamples_per_s": round(samples / ms_ref / 1e3, 1),
+                                       "roofline_frac": round(8.0 * samples / (ms_ref * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "note": "savgol_streambank_create: multiply and add rounded separately, bit-identical to the reference's savgol_stream_push"},
     }
     # (e) the resident tick service: a doorbell + a completion array per tick instead of a launch + synchronise
     torch.cuda.synchronize()
@@ -344,10 +364,10 @@ def bench_image(sg, a):
     f = sg.Filter2D(n, n, 3)
     res = {}
     for name, b in (("VALID", 0), ("CONSTANT", 1), ("REFLECT", 2)):
-        ms = timed(lambda: f.apply_batch(x, y, size, size, Nimg, boundary=b, method=a.method), reps=3, warm=1)
+        ms = timed(lambda: f.apply_batch(x, y, size, size, Nimg, boundary=b, method=a.method), reps=5, warm=1)
         pix = Nimg * size * size
         res[name] = {"ms": round(ms, 3), "Mpix_per_s": round(pix / ms / 1e3, 1),
-                     "roofline": roofline(8.0 * pix, ms, algorithmic_bytes_per_pixel=8)}
+                     "roofline": roofline(8.0 * pix, ms, algorithmic_bytes_per_pixel=8, kernel="sg2d_rolling_kernel<7,2,1,true>" if a.method == 2 else "sg2d_dense_roll_kernel<7>")}
         if a.method == 2:                                # the rolling kernel's committed counter passes, if taken on these sources
             traffic, src = pmc_traffic(8.0 * pix, "r*_2d_config4_pmc_summary.json", SOURCES_2D)
             res[name]["roofline"]["traffic"] = traffic
@@ -402,13 +422,14 @@ def bench_config5_slice(sg, a, rank=0, dev=None, steps=2):
         one_pass()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    ms = float(np.mean([p.elapsed_time(q) for p, q in per_launch]))
+    lms = [p.elapsed_time(q) for p, q in per_launch]
+    ms = float(np.mean(lms))
     out = {"workload": f"BASELINE config 5, one GPU's slice: {resident} of {channels} channels x {length} fp64 samples resident in HBM "
                        f"({resident * length * 8 / 1e9:.1f} GB in), half_window=32, poly_order=4 (BASELINE names no order; d=2 needs >= 2), "
                        f"derivative=2, POLYNOMIAL, processed in {chunk}-channel chunks; "
                        + ("output slice resident too" if full_out else "every chunk writes the same chunk-sized output buffer (the slice's output does not fit beside its input)"),
            "Msamples_per_s": round(resident * length * steps / el / 1e6, 1), "ms_per_pass": round(el / steps * 1e3, 3),
-           "roofline": roofline(16.0 * chunk * length, ms, kernel="sg1d_center_kernel<double,32>", launches_timed=len(per_launch))}
+           "roofline": with_traffic(roofline(16.0 * chunk * length, ms, lms, kernel="sg1d_center_kernel<double,32>"), "r*_1d_f64_n32_pmc_summary.json")}
     if not a.no_cpu:
         from oracle import sgo
         c0 = resident - chunk
@@ -433,6 +454,7 @@ def kernel_source_sha(files=None):
 
 
 SOURCES_2D = ["sg_2d_roll.hip", "sg_2d.hpp", "sg_2d.hip"]            # what profiles/r*_2d_config4_pmc_summary.json is stamped with
+SOURCES_STREAM = ["sg_stream_roll.hip", "sg_stream.hpp", "sg_pk.hpp"]   # ... r*_stream_block_pmc_summary.json
 
 
 def pmc_traffic(alg_bytes, pattern="r*_1d_f32_n32_pmc_summary.json", files=None):
@@ -556,7 +578,7 @@ def main():
         S, T = hi - lo, args.ticks
         x = torch.empty((T, S), dtype=torch.float32, device=dev); sg.synth(x, channel0=lo)
         y = torch.empty_like(x)
-        bank = sg.StreamBank(S, 16, 2, 1, 1e-3)
+        bank = sg.StreamBank(S, 16, 2, 1, 1e-3, fma=True)       # SAVGOL_STREAMBANK_FMA; the reference-order bank is timed beside it under "latency"
 
         def step(events):
             e0, e1 = ev(), ev()
@@ -565,13 +587,14 @@ def main():
                 events.append((e0, e1))
         el, events = timed_region(step)
         if rank == 0:
-            ms = float(np.mean([p.elapsed_time(q) for p, q in events]))
+            lms = [p.elapsed_time(q) for p, q in events]
+            ms = float(np.mean(lms))
             out = {"metric": "Msamples/s filtered (streaming, 65536 streams per GPU, hw=16, poly=2, derivative=1, block push)",
                    "value": round(S * T * args.steps * world / el / 1e6, 1), "unit": "Msamples/s", **common,
                    "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": "f32",
                    "config": {"workload": f"BASELINE config 3: {S} streams per GPU x {T} ticks per step, n=16, m=2, d=1, dt=1e-3", "sharding": "streams, no collective"},
-                   "roofline": roofline(8.0 * S * T, ms, kernel="sg_bank_roll_kernel<16>", launches_timed=len(events))}
-            if world == 1:
+                   "roofline": with_traffic(roofline(8.0 * S * T, ms, lms, kernel="sg_bank_roll_kernel<16,true>"), "r*_stream_block_pmc_summary.json", SOURCES_STREAM)}
+            if world == 1 and not args.no_extra:
                 out["latency"] = bench_stream(sg, args)
                 if "cpu_baseline" in out["latency"]:
                     out["cpu_baseline"] = out["latency"]["cpu_baseline"]
@@ -626,12 +649,12 @@ def main():
             cfg = {"workload": f"BASELINE config 4: {Nimg} images x {size}x{size} fp32 per GPU, n=7, order 3, one pass per boundary mode "
                                f"(VALID, CONSTANT, REFLECT) per step, method {args.method}", "sharding": "images, no collective"}
         if rank == 0:
-            ms = float(np.mean([p.elapsed_time(q) for p, q in events]))
+            lms = [p.elapsed_time(q) for p, q in events]
+            ms = float(np.mean(lms))
             per_launch_pix = pix_rank if args.rowband else pix_rank // 3
             out = {"metric": "Mpix/s filtered (2-D, hw=7, order 3)", "value": round(pix_rank * args.steps * world / el / 1e6, 1), "unit": "Mpix/s", **common,
                    "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": "f32", "config": cfg,
-                   "roofline": roofline(8.0 * per_launch_pix, ms, kernel="sg2d_rolling_kernel<7,2>" if args.method == 2 else "sg2d_dense_roll_kernel<7>",
-                                        launches_timed=len(events))}
+                   "roofline": roofline(8.0 * per_launch_pix, ms, lms, kernel="sg2d_rolling_kernel<7,2,1,true>" if args.method == 2 else "sg2d_dense_roll_kernel<7>")}
             if args.method == 2 and not args.rowband:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(8.0 * per_launch_pix, "r*_2d_config4_pmc_summary.json", SOURCES_2D)
             if world == 1 and not args.no_cpu:
@@ -657,7 +680,8 @@ def main():
                     events.append((e0, e1))
         el, events = timed_region(step)
         if rank == 0:
-            ms = float(np.mean([p.elapsed_time(q) for p, q in events]))
+            lms = [p.elapsed_time(q) for p, q in events]
+            ms = float(np.mean(lms))
             out = {"metric": "Msamples/s filtered (1D batch fp64, hw=32, poly=4, derivative=2) + % HBM roofline",
                    "value": round(resident * length * args.steps * world / el / 1e6, 1), "unit": "Msamples/s", **common,
                    "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": "f64",
@@ -665,7 +689,7 @@ def main():
                                           f"{resident * length * 8 / 1e9:.1f} GB resident input), n=32, m=4, d=2, POLYNOMIAL, {chunk}-channel chunks per launch, "
                                           + ("output slice resident" if full_out else "one chunk-sized output buffer reused"),
                               "channels_per_gpu": resident, "length": length, "sharding": "channels, no collective"},
-                   "roofline": roofline(16.0 * chunk * length, ms, kernel="sg1d_center_kernel<double,32>", launches_timed=len(events))}
+                   "roofline": with_traffic(roofline(16.0 * chunk * length, ms, lms, kernel="sg1d_center_kernel<double,32>"), "r*_1d_f64_n32_pmc_summary.json")}
             if world == 1 and not args.no_cpu:
                 from oracle import sgo
                 sample = [0, chunk - 1]
@@ -717,8 +741,10 @@ def main():
                                    f"poly_order={M}, derivative={D}, one pass per boundary mode "
                                    "(POLYNOMIAL, REFLECT, PERIODIC, CONSTANT) per step",
                        "channels_per_gpu": ch, "length": length, "sharding": "channels, no collective"},
-            "roofline": {**roofline(alg_bytes, avg_ms, kernel=kernel, launches_timed=len(launches_ms)), "traffic": traffic,
-                         "traffic_source": traffic_src},
+            "roofline": {**roofline(alg_bytes, avg_ms, launches_ms, kernel=kernel), "traffic": traffic, "traffic_source": traffic_src},
+            # where the two 16 GiB buffers landed: the same launch runs 5.2-5.75 ms depending on their physical placement
+            # (DESIGN 4.1 "Run-to-run spread"); with the addresses a 0.75 run and a 0.83 run can be told apart
+            "buffers": {"x": hex(x.data_ptr()), "y": hex(y.data_ptr()), "bytes_each": x.numel() * 4},
         }
         if world == 1 and not args.no_cpu:
             # CPU leg (rank 0, N=1 only): the reference timed on this host + parity spot checks of what was just timed

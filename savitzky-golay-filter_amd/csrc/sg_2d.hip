@@ -189,28 +189,33 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
     if (method != 1) {
         float factors[SEP_MAX_TERMS * 2 * (2 * SAVGOL2D_MAX_HALF_WINDOW + 2)];
         const int terms = sep_factors_cached(&f->config, factors);
+        const bool square = nx == ny;
+        const int nmax = nx > ny ? nx : ny;                  // rectangular windows: factors zero-padded to the square window of half width nmax
         if (terms > 0) {
-            const float *d_f = ctx_table(ctx, factors, sizeof(float) * (size_t)terms * 2 * (2 * nx + 2), 0x5e000000u + (unsigned)nx);
-            if (!d_f) return -1;
+            const float *d_f = nullptr;
             // chunks of images so that a launch indexes < 2^31 tiles
             const size_t tiles_per_image = (size_t)((cols + 63) / 64) * (size_t)(rows / 1 + 1);
             const size_t max_img = tiles_per_image ? ((size_t)1 << 30) / tiles_per_image + 1 : images;
-            for (size_t i0 = 0; i0 < images; i0 += max_img) {
+            bool all_rolled = true;
+            for (size_t i0 = 0; i0 < images && all_rolled; i0 += max_img) {
                 const size_t ni = images - i0 < max_img ? images - i0 : max_img;
                 job.in = d_in + (long long)i0 * in_pitch;
                 job.out = d_out + (long long)i0 * out_pitch;
-                if (method != 3) {                       // rolling-window kernel where it applies (n <= 8), else the tile kernel
-                    const int rc = sg2d_launch_rolling(nx, terms, job, factors, f->scale, (unsigned)ni, ctx->cu_count, st);
+                if (method != 3 || !square) {            // rolling-window kernel where it applies, else the tile kernel (square windows only)
+                    const int rc = sg2d_launch_rolling(nmax, terms, job, factors, f->scale, (unsigned)ni, ctx->cu_count, st);
                     if (rc == 0) continue;
                 }
+                if (!square) { all_rolled = false; break; }      // no rolling kernel of this rank at this half window: the dense kernel below
+                if (!d_f) d_f = ctx_table(ctx, factors, sizeof(float) * (size_t)terms * 2 * (2 * nx + 2), 0x5e000000u + (unsigned)nx);
+                if (!d_f) return -1;
                 SepPlan plan;
                 memset(&plan, 0, sizeof(plan));
                 plan.outputs = 1; plan.terms[0] = terms; plan.scale[0] = f->scale; plan.out[0] = job.out;
                 if (sg2d_launch_separable(nx, job, plan, d_f, (unsigned)ni, ctx->cu_count, st) != 0) { sg_set_error("%s: no separable kernel for n=%d", who, nx); return -1; }
             }
-            return hip_ok(hipGetLastError(), who) ? 0 : -1;
+            if (all_rolled) return hip_ok(hipGetLastError(), who) ? 0 : -1;
         }
-        if (method >= 2) { sg_set_error("%s: separable method needs a square window of rank <= %d", who, SEP_MAX_TERMS); return -1; }
+        if (method >= 2) { sg_set_error("%s: no separable kernel for this %dx%d window (rank > %d, or a rectangular window beyond the rolling kernel's ranks)", who, 2 * nx + 1, 2 * ny + 1, SEP_MAX_TERMS); return -1; }
     }
     const size_t lds = sizeof(float) * (size_t)(((f->window_area + 3) & ~3) + (T2_W + 2 * nx) * (T2_H + 2 * ny));
     for (size_t i0 = 0; i0 < images; i0 += 65535) {
@@ -373,7 +378,7 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
         } else if (rc == 0) {
             for (int i = 0; i < nspec && rc == 0; ++i)
                 rc = enqueue_2d(who, fs[i], d_in, rows, cols, in_stride, (long long)in_pitch, specs[i].out, out_stride, (long long)out_pitch,
-                                images, boundary, 1, st);
+                                images, boundary, 0, st);           // the rolling kernel on zero-padded factors where it is built for the rank, else dense
         }
         for (int i = 0; i < nspec; ++i)
             if (owned[i]) savgol2d_destroy(const_cast<Savgol2DFilter *>(fs[i]));
@@ -431,6 +436,14 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
         job.out = plan.out[0];
         if (sg2d_launch_rolling2(n, plan.terms[0], job, factors, plan.scale[0], factors + (size_t)plan.terms[0] * 2 * (ws + 1), plan.scale[1],
                                  plan.out[1], (unsigned)images, ctx->cu_count, st) == 0)
+            return hip_ok(hipGetLastError(), who) ? 0 : -1;
+    }
+    // three outputs with the same number of terms (the Hessian of order <= 3: rank 1 each): ONE rolling launch up to n = 9
+    if (plan.outputs == 3 && plan.terms[0] == plan.terms[1] && plan.terms[1] == plan.terms[2]) {
+        job.out = plan.out[0];
+        const size_t tstride = (size_t)plan.terms[0] * 2 * (ws + 1);
+        if (sg2d_launch_rolling3(n, plan.terms[0], job, factors, plan.scale[0], factors + tstride, plan.scale[1], factors + 2 * tstride, plan.scale[2],
+                                 plan.out[1], plan.out[2], (unsigned)images, ctx->cu_count, st) == 0)
             return hip_ok(hipGetLastError(), who) ? 0 : -1;
     }
     if (plan.outputs <= 2) {

@@ -395,14 +395,15 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 
 // terms per output the rolling kernel is built for: the taps live in SGPRs (2 * NT * NOUT * (N/2 + 1) pairs), which caps the
 // windows 9..12 at 3 terms and 13..16 at 2 (1 when two outputs share the walk); everything else runs the tile kernel of sg_2d_sep.hip
-constexpr int roll_max_terms(int n, int nout) { return nout == 1 ? (n <= 8 ? SEP_MAX_TERMS : (n <= 12 ? 3 : 2)) : (n <= 8 ? 3 : 1); }
+// (three outputs -- the Hessian -- share the walk up to n = 9 with one term each: every Hessian frame of order <= 3 is rank 1)
+constexpr int roll_max_terms(int n, int nout) { return nout == 1 ? (n <= 8 ? SEP_MAX_TERMS : (n <= 12 ? 3 : 2)) : nout == 2 ? (n <= 8 ? 3 : 1) : (n <= 3 ? 2 : (n <= 9 ? 1 : 0)); }
 // waves per SIMD the register allocation must allow: the row ring alone is (2N+2) x 4 VGPRs
 // (n = 7 and n = 8 with three rows in flight and the two-output form at n = 6, rank 2, spill at 4 waves per SIMD: 300 / 20-108 / 12
 // bytes of scratch; tools/roll_resources.py lists every instantiation)
 #ifdef SG_ROLL_MINWAVES
 constexpr int roll_min_waves(int, int, int) { return SG_ROLL_MINWAVES; }
 #else
-constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt >= 3 && n >= 6) || n == 7 || n == 8 || (n == 6 && nt == 2 && nout == 2) ? 3 : 4); }
+constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt >= 3 && n >= 6) || n == 7 || n == 8 || (n == 6 && nt == 2 && nout == 2) || (nout == 3 && n >= 5) ? 3 : 4); }
 #endif
 
 // waves per block: the waves of a block walk neighbouring strips row for row, so a block's loads of one row step are one
@@ -413,7 +414,7 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 constexpr int roll_wpb(int n) { (void)n; return SG_ROLL_WPB; }
 
 template <int N, int NT, int NOUT, bool BOX>
-__global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1,
+__global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1, float *const out2,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
     typedef Roll<N> R;
@@ -425,13 +426,14 @@ __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void
     // one item per wave by default (the loop runs once), or persistent waves striding over the items; blocks that share an XCD
     // (blockIdx % 8) take neighbouring items (halo columns meet in L2)
     const unsigned nblk = gridDim.x;
-    const unsigned blk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const unsigned blk = (aligned & 8) ? blockIdx.x : (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);      // bit 3: blocks in launch order (A/B: SAVGOL_HIP_ROLL_XCD=0)
     constexpr unsigned WPB = (unsigned)roll_wpb(N);
     const unsigned nwaves = nblk * WPB;
 
     const bool valid = job.boundary == SAVGOL2D_BOUNDARY_VALID;
-    const int xlo = valid ? N : 0, xhi = valid ? job.cols - N : job.cols;
-    const int ylo = valid ? N : 0, yhi = valid ? job.rows - N : job.rows;
+    // the job's own half windows: a rectangular window runs on the square kernel of its larger half width with zero-padded factors
+    const int xlo = valid ? job.nx : 0, xhi = valid ? job.cols - job.nx : job.cols;
+    const int ylo = valid ? job.ny : 0, yhi = valid ? job.rows - job.ny : job.rows;
 
     for (unsigned item = blk * WPB + (unsigned)wv; item < total_items; item += nwaves) {
         const unsigned strip = item % strips, ib = item / strips;
@@ -445,9 +447,10 @@ __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void
         float *outs[NOUT];
         outs[0] = job.out + (long long)img * job.out_pitch;
         if constexpr (NOUT > 1) outs[1] = out1 + (long long)img * job.out_pitch;
+        if constexpr (NOUT > 2) outs[2] = out2 + (long long)img * job.out_pitch;
         const int sx = (int)strip * R::SW;
         // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
-        if (aligned == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
+        if ((aligned & 3) == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
             roll_item<N, NT, NOUT, true, BOX>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
         else
             roll_item<N, NT, NOUT, false, BOX>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
@@ -544,14 +547,16 @@ static int roll_box_env()                                   // SAVGOL_HIP_ROLL_B
     return v;
 }
 template <int N, int NT, int NOUT, bool BOX>
-static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *out1, unsigned images, int cu_count, hipStream_t st)
+static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *out1, float *out2, unsigned images, int cu_count, hipStream_t st)
 {
     typedef Roll<N> R;
     int aligned = 0;
     if (job.in_stride % 4 == 0 && job.in_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.in) & 15u) == 0) aligned |= 1;
     if (job.out_stride % 4 == 0 && job.out_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.out) & 15u) == 0 &&
-        (NOUT == 1 || (reinterpret_cast<uintptr_t>(out1) & 15u) == 0) &&
+        (NOUT < 2 || (reinterpret_cast<uintptr_t>(out1) & 15u) == 0) && (NOUT < 3 || (reinterpret_cast<uintptr_t>(out2) & 15u) == 0) &&
         (long long)job.rows * job.out_stride * 4 < 0x7fffff00ll) aligned |= 2;       // the store descriptor holds a 31-bit byte count
+    static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_XCD"); return e ? atoi(e) : 1; }();
+    if (!xcd_env) aligned |= 8;
     const unsigned strips = (unsigned)((job.cols + R::SW - 1) / R::SW);
     static int per_cu = 0;                                   // resident blocks per CU of this instantiation
     constexpr unsigned WPB = (unsigned)roll_wpb(N);
@@ -598,26 +603,27 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
         part.in = job.in + (long long)i0 * job.in_pitch;
         part.out = job.out + (long long)i0 * job.out_pitch;
         hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT, BOX>), dim3(grid), dim3(64 * WPB), lds, st, part, taps,
-                           out1 ? out1 + (long long)i0 * job.out_pitch : nullptr, strips, bands, band_rows, (unsigned)total, aligned);
+                           out1 ? out1 + (long long)i0 * job.out_pitch : nullptr, out2 ? out2 + (long long)i0 * job.out_pitch : nullptr, strips, bands,
+                           band_rows, (unsigned)total, aligned);
     }
     return 0;
 }
 
 template <int N, int NT, int NOUT>
-static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], const float (&scale)[NOUT], float *out1, unsigned images,
+static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], const float (&scale)[NOUT], float *out1, float *out2, unsigned images,
                        int cu_count, hipStream_t st)
 {
     if constexpr (NT == 2 && NOUT == 1) {
         RollTaps<N, 2, 1> box;
         memset(&box, 0, sizeof(box));
         if (roll_box_env() != 0 && fill_box_taps<N>(box, factors[0], scale[0]))
-            return launch_roll_kernel<N, 2, 1, true>(job, box, out1, images, cu_count, st);
+            return launch_roll_kernel<N, 2, 1, true>(job, box, out1, out2, images, cu_count, st);
     }
     RollTaps<N, NT, NOUT> taps;
     memset(&taps, 0, sizeof(taps));
     for (int o = 0; o < NOUT; ++o)
         if (!fill_taps<N, NT, NOUT>(taps, o, factors[o], scale[o])) return 1;
-    return launch_roll_kernel<N, NT, NOUT, false>(job, taps, out1, images, cu_count, st);
+    return launch_roll_kernel<N, NT, NOUT, false>(job, taps, out1, out2, images, cu_count, st);
 }
 
 template <int N, int NT>
@@ -626,7 +632,7 @@ static int dispatch_roll(int n, int terms, const Job2D &job, const float *factor
     if (n == N && terms == NT) {
         const float *const f1[1] = {factors};
         const float s1[1] = {scale};
-        return launch_roll<N, NT, 1>(job, f1, s1, nullptr, images, cu_count, st);
+        return launch_roll<N, NT, 1>(job, f1, s1, nullptr, nullptr, images, cu_count, st);
     }
     if constexpr (NT < roll_max_terms(N, 1)) return dispatch_roll<N, NT + 1>(n, terms, job, factors, scale, images, cu_count, st);
     else if constexpr (N < SEP_ROLL_MAX_N) return dispatch_roll<N + 1, 1>(n, terms, job, factors, scale, images, cu_count, st);
@@ -641,10 +647,24 @@ static int dispatch_roll2(int n, int terms, const Job2D &job, const float *f0, f
     if (n == N && terms == NT) {
         const float *const ff[2] = {f0, f1};
         const float ss[2] = {s0, s1};
-        return launch_roll<N, NT, 2>(job, ff, ss, out1, images, cu_count, st);
+        return launch_roll<N, NT, 2>(job, ff, ss, out1, nullptr, images, cu_count, st);
     }
     if constexpr (NT < roll_max_terms(N, 2)) return dispatch_roll2<N, NT + 1>(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
     else if constexpr (N < SEP_ROLL_MAX_N) return dispatch_roll2<N + 1, 1>(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
+    else return 1;
+}
+
+// three output frames from one walk over the input, the same number of terms for all three: the Hessian (reference
+// savgol2d_hessian, src/savgol2d.c:501-558, creates, applies and destroys one filter per frame)
+template <int N, int NT>
+static int dispatch_roll3(int n, int terms, const Job2D &job, const float *const (&ff)[3], const float (&ss)[3], float *out1, float *out2, unsigned images,
+                          int cu_count, hipStream_t st)
+{
+    if constexpr (roll_max_terms(N, 3) >= NT) {
+        if (n == N && terms == NT) return launch_roll<N, NT, 3>(job, ff, ss, out1, out2, images, cu_count, st);
+    }
+    if constexpr (NT < roll_max_terms(N, 3)) return dispatch_roll3<N, NT + 1>(n, terms, job, ff, ss, out1, out2, images, cu_count, st);
+    else if constexpr (N < SEP_ROLL_MAX_N) return dispatch_roll3<N + 1, 1>(n, terms, job, ff, ss, out1, out2, images, cu_count, st);
     else return 1;
 }
 
@@ -662,6 +682,16 @@ int SEP_ROLL_FN2(int n, int terms, const Job2D &job, const float *factors0, floa
 {
     if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > roll_max_terms(n, 2)) return 1;
     return dispatch_roll2<SEP_ROLL_MIN_N, 1>(n, terms, job, factors0, scale0, factors1, scale1, out1, images, cu_count, st);
+}
+
+// the three-output form: job.out, out1 and out2 share stride and pitch; every output has `terms` terms
+int SEP_ROLL_FN3(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, const float *f2, float s2, float *out1,
+                 float *out2, unsigned images, int cu_count, hipStream_t st)
+{
+    if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > roll_max_terms(n, 3)) return 1;
+    const float *const ff[3] = {f0, f1, f2};
+    const float ss[3] = {s0, s1, s2};
+    return dispatch_roll3<SEP_ROLL_MIN_N, 1>(n, terms, job, ff, ss, out1, out2, images, cu_count, st);
 }
 
 }  // namespace sg

@@ -310,8 +310,67 @@ int sg2d_factors_from_kernel(const double *Wd, int n, int order, float *factors,
     return terms;
 }
 
+// Rectangular windows (nx != ny; reference savgol2d.h:82-90, test_savgol2d.c:508-543): the same factorisation on the
+// (2ny+1) x (2nx+1) kernel, G_t orthonormal polynomials on the y window, Q_t = G_t^T W on the x window, each embedded in the
+// middle of a vector of 2N+1 entries, N = max(nx, ny), zeros either side -- the square kernels of half window N then apply it
+// unchanged (zero taps add nothing; the stored range of VALID comes from the job's own nx, ny).  One caveat, stated in
+// savgol_hip.h: a zero tap times a non-finite sample is NaN, so NaN / Inf spread over the padded window in this method.
+static int sg2d_rect_factors(const Savgol2DConfig *cfg, float *factors, int max_terms)
+{
+    const int nx = cfg->half_window_x, ny = cfg->half_window_y, order = cfg->poly_order;
+    const int ww = 2 * nx + 1, wh = 2 * ny + 1, N = nx > ny ? nx : ny, ws = 2 * N + 1;
+    float wf[SAVGOL2D_MAX_WINDOW_AREA];
+    double coef[SAVGOL2D_MAX_TERMS];
+    if (sg2d_weights_fill(cfg, wf, coef) != 0) return 0;
+    static thread_local double Wd[33 * 33];
+    double wmax = 0.0;
+    for (int y = -ny; y <= ny; ++y)
+        for (int x = -nx; x <= nx; ++x) {
+            double s = 0.0;
+            for (int px = 0; px <= order; ++px)
+                for (int py = 0; px + py <= order; ++py) s += coef[sg2d_term(px, py)] * std::pow((double)x, px) * std::pow((double)y, py);
+            Wd[(y + ny) * ww + (x + nx)] = s;
+            if (std::fabs(s) > wmax) wmax = std::fabs(s);
+        }
+    const int nb = (order + 1 < wh) ? order + 1 : wh;
+    double G[7][33];
+    int terms = 0;
+    for (int j = 0; j < nb; ++j) {
+        double v[33];
+        for (int y = 0; y < wh; ++y) v[y] = std::pow((double)(y - ny) / (double)ny, j);
+        for (int pass = 0; pass < 2; ++pass)
+            for (int k = 0; k < j; ++k) {
+                double d = 0.0;
+                for (int y = 0; y < wh; ++y) d += G[k][y] * v[y];
+                for (int y = 0; y < wh; ++y) v[y] -= d * G[k][y];
+            }
+        double nrm = 0.0;
+        for (int y = 0; y < wh; ++y) nrm += v[y] * v[y];
+        nrm = std::sqrt(nrm);
+        for (int y = 0; y < wh; ++y) G[j][y] = v[y] / nrm;
+    }
+    for (int j = 0; j < nb; ++j) {
+        double Q[33], qmax = 0.0;
+        for (int x = 0; x < ww; ++x) {
+            double s = 0.0;
+            for (int y = 0; y < wh; ++y) s += G[j][y] * Wd[y * ww + x];
+            Q[x] = s;
+            if (std::fabs(s) > qmax) qmax = std::fabs(s);
+        }
+        if (qmax <= 1e-13 * wmax) continue;
+        if (terms >= max_terms) return 0;
+        float *f = factors + (size_t)terms * 2 * (ws + 1);
+        memset(f, 0, sizeof(float) * 2 * (ws + 1));
+        for (int x = 0; x < ww; ++x) f[(N - nx) + x] = (float)Q[x];
+        for (int y = 0; y < wh; ++y) f[(ws + 1) + (N - ny) + y] = (float)G[j][y];
+        ++terms;
+    }
+    return terms;
+}
+
 int sg2d_separable_factors(const Savgol2DConfig *cfg, float *factors, int max_terms)
 {
+    if (cfg->half_window_x != cfg->half_window_y) return sg2d_rect_factors(cfg, factors, max_terms);
     static thread_local double Wd[33 * 33];
     if (sg2d_kernel_double(cfg, Wd) != 0) return 0;
     return sg2d_factors_from_kernel(Wd, cfg->half_window_x, cfg->poly_order, factors, max_terms);

@@ -189,14 +189,14 @@ __global__ __launch_bounds__(256) void sg_bank_roll_kernel(const BankJob job, co
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // persistent waves; the 4 waves of a block take adjacent strips (2 KB contiguous per tick row)
     const unsigned nblk = gridDim.x;
-    const unsigned blk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const unsigned blk = (job.aligned & 2) ? blockIdx.x : (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);      // bit 1: launch order (A/B: SAVGOL_HIP_STREAM_XCD=0)
     const unsigned long long total = (unsigned long long)job.strips * job.bands;
     for (unsigned long long item = (unsigned long long)blk * 4u + (unsigned)wv; item < total; item += (unsigned long long)nblk * 4u) {
         const unsigned strip = (unsigned)(item % job.strips), band = (unsigned)(item / job.strips);
         const size_t s0 = (size_t)strip * 128 + 2 * (size_t)lane;
         const size_t t0 = (size_t)band * (size_t)job.band_ticks;
         const int nt = job.ticks - t0 < (size_t)job.band_ticks ? (int)(job.ticks - t0) : job.band_ticks;
-        const bool vec = job.aligned && (size_t)strip * 128 + 128 <= job.streams;
+        const bool vec = (job.aligned & 1) && (size_t)strip * 128 + 128 <= job.streams;
         if constexpr (N <= STREAM_RING_MAX_N) {
             if (vec) bank_roll_item<N, true, FMA>(job, taps, s0, t0, nt); else bank_roll_item<N, false, FMA>(job, taps, s0, t0, nt);
         } else {
@@ -234,6 +234,17 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
     grid = (grid + 7u) & ~7u;
     job.aligned = (job.streams % 2 == 0 && ((reinterpret_cast<uintptr_t>(job.samples) | reinterpret_cast<uintptr_t>(job.out) |
                                               reinterpret_cast<uintptr_t>(job.ring)) & 7u) == 0) ? 1 : 0;
+    static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_XCD"); return e ? atoi(e) : 1; }();
+    if (!xcd_env) job.aligned |= 2;
+    static const int one_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_ONEWAVE"); return e ? atoi(e) : 0; }();     // A/B: one item per wave, blocks in order
+    if (one_env) {
+        size_t b2 = job.ticks / (size_t)(one_env > 1 ? one_env : 256);
+        if (b2 < 1) b2 = 1;
+        job.band_ticks = (int)((job.ticks + b2 - 1) / b2);
+        job.bands = (unsigned)((job.ticks + (size_t)job.band_ticks - 1) / (size_t)job.band_ticks);
+        grid = (unsigned)(((unsigned long long)job.strips * job.bands + 3) / 4);
+        grid = (grid + 7u) & ~7u;
+    }
     hipLaunchKernelGGL((sg_bank_roll_kernel<N, FMA>), dim3(grid), dim3(256), 0, st, job, taps);
     return 0;
 }

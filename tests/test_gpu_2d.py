@@ -267,11 +267,50 @@ def test_separable_rank4_and_rectangular_fallback(sg, sgo, torch_gpu):
     f.apply_batch(d, out, 90, 100, 1, boundary=2, method=2)
     hi = sgo.Filter2D(16, 16, 6).apply_f64acc(x, 100, 2)
     assert normwise(out.cpu().numpy(), hi) < 2e-6
-    with pytest.raises(RuntimeError):                        # rectangular window: no separable kernel
-        sg.Filter2D(4, 6, 3).apply_batch(d, out, 90, 100, 1, boundary=1, method=2)
-    sg.Filter2D(4, 6, 3).apply_batch(d, out, 90, 100, 1, boundary=1, method=0)        # auto: falls back to the dense kernel
+    # rectangular windows: method 1 is the reference order bit for bit; methods 0 / 2 run the rolling kernel on zero-padded factors
+    sg.Filter2D(4, 6, 3).apply_batch(d, out, 90, 100, 1, boundary=1, method=1)
     want = sgo.Filter2D(4, 6, 3).apply(x, 100, 1)
-    assert np.array_equal(out.cpu().numpy(), want)           # ... which is bit-identical to the reference order
+    assert np.array_equal(out.cpu().numpy(), want)
+    with pytest.raises(RuntimeError):                        # rank 4 at half window 16 x 9: beyond the rolling kernel's ranks, and the tile kernel is square only
+        sg.Filter2D(9, 16, 6).apply_batch(d, out, 90, 100, 1, boundary=1, method=2)
+    sg.Filter2D(9, 16, 6).apply_batch(d, out, 90, 100, 1, boundary=1, method=0)        # auto: falls back to the dense kernel
+    assert np.array_equal(out.cpu().numpy(), sgo.Filter2D(9, 16, 6).apply(x, 100, 1))
+
+
+@pytest.mark.parametrize("nx,ny,order,dx,dy", [(4, 7, 3, 0, 0), (7, 4, 3, 0, 0), (2, 1, 2, 0, 0), (5, 3, 2, 0, 0), (3, 5, 4, 0, 0), (1, 16, 2, 0, 0), (12, 2, 3, 0, 0),
+                                               (4, 7, 3, 1, 0), (6, 3, 3, 0, 1), (3, 8, 4, 2, 0), (5, 2, 3, 1, 1), (2, 6, 2, 0, 2)])
+def test_rectangular_windows_on_the_rolling_kernel(sg, sgo, torch_gpu, nx, ny, order, dx, dy):
+    """nx != ny (reference savgol2d.h:82-90; its test: test_savgol2d.c:508-543) on method 2: the exact low-rank factors of the
+    (2ny+1) x (2nx+1) kernel, zero-padded to the square window of the larger half width.  Against the double-accumulation
+    oracle (1e-6 smoothing / 4e-6 derivatives), all three boundary modes, VALID's stored range from the window's OWN nx, ny
+    (untouched border checked), odd strides and frame widths that take the scalar strips, and the reference's own rectangular
+    test: a constant frame stays constant."""
+    torch = torch_gpu
+    rng = np.random.default_rng(nx * 100 + ny)
+    tol = TOL_SEP if dx + dy == 0 else TOL_SEP_DERIV
+    f = sg.Filter2D(nx, ny, order, dx, dy, 0.5 if dx else 1.0, 2.0 if dy else 1.0)
+    o = sgo.Filter2D(nx, ny, order, dx, dy, 0.5 if dx else 1.0, 2.0 if dy else 1.0)
+    for rows, cols, stride, images in ((300, 1000, 1000, 3), (97, 301, 303, 2), (2 * ny + 9, 2 * nx + 12, 2 * nx + 12, 1), (700, 520, 520, 1)):
+        x = rng.normal(0, 1, (images, rows, stride)).astype(np.float32)
+        d = torch.from_numpy(x).cuda()
+        for b in (0, 1, 2):
+            out = torch.full_like(d, -7.0)
+            f.apply_batch(d, out, rows, cols, images, in_stride=stride, out_stride=stride, boundary=b, method=2)
+            got = out.cpu().numpy()
+            sel = np.zeros((rows, stride), bool)
+            if b == 0:
+                sel[ny:rows - ny, nx:cols - nx] = True
+            else:
+                sel[:, :cols] = True
+            for k in range(images):
+                hi = o.apply_f64acc(x[k], cols, b)
+                assert np.all(got[k][~sel] == -7.0), (rows, cols, b)
+                assert normwise(got[k][sel], hi[sel]) < tol, (rows, cols, b, normwise(got[k][sel], hi[sel]))
+    if dx + dy == 0:
+        c = torch.full((1, 64, 300), 3.25, device="cuda")
+        out = torch.zeros_like(c)
+        f.apply_batch(c, out, 64, 300, 1, boundary=1, method=2)
+        assert (out - 3.25).abs().max().item() < 1e-5
 
 
 def test_row_bands_on_gpu_equal_whole_frame(sg, torch_gpu):

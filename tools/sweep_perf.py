@@ -38,6 +38,10 @@ if "2d" in which:
             ms = timed(lambda: f.apply_batch(x, y, size, size, images, boundary=1, method=method), reps=2)
             line += f"  method {method}: {ms:8.3f} ms {images * size * size / ms / 1e6:7.1f} Gpix/s"
         print(line, flush=True)
-    f = sg.Filter2D(4, 7, 3)
-    ms = timed(lambda: f.apply_batch(x, y, size, size, images, boundary=1, method=1), reps=2)
-    print(f"2-D 9x15 window, method 1: {ms:8.3f} ms {images * size * size / ms / 1e6:7.1f} Gpix/s")
+    for (nx, ny) in ((4, 7), (7, 4), (2, 12)):
+        f = sg.Filter2D(nx, ny, 3)
+        line = f"2-D {2 * nx + 1}x{2 * ny + 1} window:"
+        for method in (2, 1):
+            ms = timed(lambda: f.apply_batch(x, y, size, size, images, boundary=1, method=method), reps=2)
+            line += f"  method {method}: {ms:8.3f} ms {images * size * size / ms / 1e6:7.1f} Gpix/s"
+        print(line, flush=True)
