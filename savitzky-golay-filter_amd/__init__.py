@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsavgol_hip.so")
+# SAVGOL_HIP_LIB: another build of the same library (tools/ A/B runs); the product is lib/libsavgol_hip.so
+LIB_PATH = os.environ.get("SAVGOL_HIP_LIB") or os.path.join(_HERE, "lib", "libsavgol_hip.so")
 
 SAVGOL_MAX_HALF_WINDOW = 32
 SAVGOL_MAX_WINDOW = 65

@@ -520,6 +520,19 @@ int savgol_hip_moment_table(const SavgolFilter *filter, float *table)
     return sg1d_moment_prepare(filter->config.half_window, filter->center_weights, table);
 }
 
+// Medium host signals: two hipMemcpy calls cost more than the filter.  Between these lengths the CPU copies the signal into
+// pinned, device-visible host memory, the kernel reads it and writes its result across the link itself, and one stream
+// synchronise ends the call: launch + synchronise instead of H2D + launch + D2H.  Same kernel, same bits.  Measured
+// (tools/time_host_small.py, profiles/r03_host_small.txt): 4096 samples 30 -> 23 us, 65 536: 66 -> 53 us, 262 144: 139 -> 129 us;
+// BELOW ~2000 samples it loses (360 samples, the reference's demo: 20 -> 26 us -- the kernel's dependent loads then each pay a
+// PCIe round trip), so short signals keep the copies.  SAVGOL_HIP_ZERO_COPY_MIN / _MAX override the range (tuning).
+static bool zero_copy_length(size_t n)
+{
+    static const size_t lo = [] { const char *e = getenv("SAVGOL_HIP_ZERO_COPY_MIN"); return e ? (size_t)atoll(e) : (size_t)2048; }();
+    static const size_t hi = [] { const char *e = getenv("SAVGOL_HIP_ZERO_COPY_MAX"); return e ? (size_t)atoll(e) : (size_t)262144; }();
+    return n >= lo && n <= hi;
+}
+
 // the host-pointer drop-in calls: always the reference's summation order; the two semantic switches follow the process defaults
 static unsigned host_call_flags()
 {
@@ -722,6 +735,15 @@ int savgol_apply(const SavgolFilter *filter, const float *input, float *output, 
         return -1;
     }
     const size_t ld = (length + 3) & ~(size_t)3;
+    if (zero_copy_length(length)) {
+        float *pin = static_cast<float *>(sg::ctx_pinned(ctx, 2 * ld * sizeof(float)));
+        if (!pin) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
+        memcpy(pin, input, length * sizeof(float));
+        if (enqueue_batch<float>("savgol_apply", filter, pin, pin + ld, 1, length, ld, ld, FULL, nullptr, host_call_flags()) != 0 ||
+            !sg::hip_ok(hipStreamSynchronize(nullptr), "savgol_apply")) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
+        memcpy(output, pin + ld, length * sizeof(float));
+        return 0;
+    }
     float *d_in = static_cast<float *>(sg::ctx_arena(ctx, 2 * ld * sizeof(float)));
     if (!d_in) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
     float *d_out = d_in + ld;
@@ -748,6 +770,15 @@ size_t savgol_apply_valid(const SavgolFilter *filter, const float *input, size_t
         return 0;
     }
     const size_t ld = (input_length + 3) & ~(size_t)3;
+    if (zero_copy_length(input_length)) {
+        float *pin = static_cast<float *>(sg::ctx_pinned(ctx, 2 * ld * sizeof(float)));
+        if (!pin) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
+        memcpy(pin, input, input_length * sizeof(float));
+        if (enqueue_batch<float>("savgol_apply_valid", filter, pin, pin + ld, 1, input_length, ld, ld, VALID, nullptr, host_call_flags()) != 0 ||
+            !sg::hip_ok(hipStreamSynchronize(nullptr), "savgol_apply_valid")) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
+        memcpy(output, pin + ld, out_len * sizeof(float));
+        return out_len;
+    }
     float *d_in = static_cast<float *>(sg::ctx_arena(ctx, 2 * ld * sizeof(float)));
     if (!d_in) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
     float *d_out = d_in + ld;
@@ -768,12 +799,21 @@ int savgol_apply_strided(const SavgolFilter *filter, const void *input, size_t i
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     // the float fields are picked on the host (pure data movement), the arithmetic runs on the GPU
     const size_t ld = (count + 3) & ~(size_t)3;
-    float *stage = static_cast<float *>(sg::ctx_pinned(ctx, ld * sizeof(float)));
+    float *stage = static_cast<float *>(sg::ctx_pinned(ctx, 2 * ld * sizeof(float)));      // gathered field, then (short signals) the result
     float *d_in = static_cast<float *>(sg::ctx_arena(ctx, 2 * ld * sizeof(float)));
     if (!stage || !d_in) { fprintf(stderr, "savgol_apply_strided: %s\n", savgol_hip_last_error()); return -1; }
     float *d_out = d_in + ld;
     const char *ib = static_cast<const char *>(input) + in_offset;
     for (size_t i = 0; i < count; ++i) memcpy(&stage[i], ib + i * in_stride, sizeof(float));
+    if (zero_copy_length(count)) {                               // short signals: the kernel works on the pinned staging buffer itself
+        float *pin = stage;
+        if (enqueue_batch<float>("savgol_apply_strided", filter, pin, pin + ld, 1, count, ld, ld, (host_call_flags() & SAVGOL_BATCH_BOUNDARY_AWARE) ? FULL : FULL_POLY_EDGES,
+                                 nullptr, host_call_flags()) != 0 ||
+            !sg::hip_ok(hipStreamSynchronize(nullptr), "savgol_apply_strided")) { fprintf(stderr, "savgol_apply_strided: %s\n", savgol_hip_last_error()); return -1; }
+        char *ob2 = static_cast<char *>(output) + out_offset;
+        for (size_t i = 0; i < count; ++i) memcpy(ob2 + i * out_stride, &pin[ld + i], sizeof(float));
+        return 0;
+    }
     bool ok = sg::hip_ok(hipMemcpy(d_in, stage, count * sizeof(float), hipMemcpyHostToDevice), "H2D copy");
     ok = ok && enqueue_batch<float>("savgol_apply_strided", filter, d_in, d_out, 1, count, ld, ld, (host_call_flags() & SAVGOL_BATCH_BOUNDARY_AWARE) ? FULL : FULL_POLY_EDGES, nullptr, host_call_flags()) == 0;
     ok = ok && sg::hip_ok(hipMemcpy(stage, d_out, count * sizeof(float), hipMemcpyDeviceToHost), "D2H copy");

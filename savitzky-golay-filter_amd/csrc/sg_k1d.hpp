@@ -217,7 +217,11 @@ struct Conv<double, N, V> {
         if constexpr (Rr < K::R) {
             constexpr int k = I - Rr - K::OFF;
             if constexpr (k >= 0 && k <= N) acc[Rr] = __builtin_fma(taps.wd[k], x, acc[Rr]);
+#ifdef SG_F64_HALF_ADDS    // timing experiment only (wrong results): the instruction mix of the symmetric-tap fold, 32 adds + 33 multiply-adds
+            else if constexpr (k > N && k <= 2 * N) acc[Rr] = acc[Rr] + xs;
+#else
             else if constexpr (k > N && k <= 2 * N) acc[Rr] = __builtin_fma(taps.wd[2 * N - k], xs, acc[Rr]);
+#endif
             feed<I, Rr + 1>(acc, taps, x, xs);
         }
     }

@@ -28,7 +28,10 @@ namespace sg {
 template <int N>
 struct SRoll {
     static constexpr int WS = 2 * N + 1;
-    static constexpr int P = 3;                              // rows loaded ahead of the arithmetic
+#ifndef SG_SROLL_P
+#define SG_SROLL_P 3
+#endif
+    static constexpr int P = SG_SROLL_P;                     // rows loaded ahead of the arithmetic (A/B builds override)
     static constexpr int U = WS + P;                         // ring slots = unroll factor of the tick loop
     static constexpr int NP = N + 1;                         // SGPR pairs holding taps 0..2N
 };
@@ -234,7 +237,7 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
     grid = (grid + 7u) & ~7u;
     job.aligned = (job.streams % 2 == 0 && ((reinterpret_cast<uintptr_t>(job.samples) | reinterpret_cast<uintptr_t>(job.out) |
                                               reinterpret_cast<uintptr_t>(job.ring)) & 7u) == 0) ? 1 : 0;
-    static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_XCD"); return e ? atoi(e) : 1; }();
+    static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_XCD"); return e ? atoi(e) : 0; }();
     if (!xcd_env) job.aligned |= 2;
     static const int one_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_ONEWAVE"); return e ? atoi(e) : 0; }();     // A/B: one item per wave, blocks in order
     if (one_env) {
