@@ -29,3 +29,14 @@ def test_plain_c_program_against_the_c_abi():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "c_api_demo: OK" in r.stdout
     print(r.stdout)
+
+
+def test_row_bands_from_plain_c():
+    """examples/rowband_demo.c: a frame stack filtered whole and as 2..4 row bands through savgol2d_rowband_plan /
+    savgol2d_apply_rowband_f32 (halos copied device to device, where a multi-GPU host runs the RCCL exchange): stitched bands ==
+    whole frames, bit for bit in method 1, for VALID / CONSTANT / REFLECT, square and rectangular windows."""
+    exe = os.path.join(ROOT, "savitzky-golay-filter_amd", "lib", "rowband_demo")
+    assert os.path.exists(exe), "build it with `make -C savitzky-golay-filter_amd`"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rowband_demo: OK (63 band-split / whole-frame comparisons)" in r.stdout

@@ -76,6 +76,20 @@ def test_row_band_halo_exchange_matches_whole_frame(tmp_path, sgo, world):
         assert np.array_equal(got2, whole), f"overlapped, boundary {b}: max diff {np.max(np.abs(got2 - whole))}"
 
 
+def test_thin_bands_take_the_simple_form_instead_of_truncating(tmp_path, sgo):
+    """apply_overlapped rebuilds an artificial edge from the band's own 2*ny rows; with bands of ny .. 2*ny - 1 rows the
+    slice used to truncate silently and the strip's middle rows were computed with boundary handling instead of real neighbour data.
+    Such bands (here 3 ranks x 6-7 rows at ny = 4) now take exchange() + apply(); the stitched result is still the whole frame's."""
+    images, rows, cols, n, world = 2, 20, 33, 4, 3
+    mp.spawn(_worker, args=(world, _free_port(), images, rows, cols, n, str(tmp_path)), nprocs=world, join=True)
+    x = _frames(images, rows, cols)
+    for b in range(3):
+        whole = _oracle_apply(sgo, n, b)(torch.from_numpy(x)).numpy()
+        for tag in ("b", "o"):
+            got = np.concatenate([np.load(tmp_path / f"{tag}{b}_r{r}.npy") for r in range(world)], axis=1)
+            assert np.array_equal(got, whole), (tag, b)
+
+
 def test_row_band_refuses_bands_thinner_than_the_window(sg):
     import importlib
     rowband = importlib.import_module("savgol_amd.rowband")
@@ -83,3 +97,14 @@ def test_row_band_refuses_bands_thinner_than_the_window(sg):
         rowband.RowBand(20, 7, rank=0, world_size=4)
     b = rowband.RowBand(100, 7, rank=0, world_size=1)
     assert (b.lo, b.hi, b.top, b.bottom) == (0, 100, 0, 0)
+    assert rowband.RowBand(40, 7, rank=1, world_size=4).thin and not rowband.RowBand(56, 7, rank=1, world_size=4).thin
+    # the C ABI's plan agrees with the Python split and refuses bands below 2 x ny rows (no GPU needed: host arithmetic)
+    import ctypes as C
+    L = sg.lib()
+    lo, hi, up, dn = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    for world in (1, 2, 3, 5):
+        for rank in range(world):
+            assert L.savgol2d_rowband_plan(173, 7, rank, world, C.byref(lo), C.byref(hi), C.byref(up), C.byref(dn)) == 0
+            rb = rowband.RowBand(173, 7, rank=rank, world_size=world)
+            assert (lo.value, hi.value, up.value, dn.value) == (rb.lo, rb.hi, rb.top, rb.bottom)
+    assert L.savgol2d_rowband_plan(27, 7, 0, 2, C.byref(lo), C.byref(hi), None, None) == -1
