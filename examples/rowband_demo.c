@@ -83,16 +83,15 @@ int main(void)
                             return 1;
                         }
                     } else {
-                        double worst = 0.0, vmax = 0.0;
+                        double worst = 0.0, vmax = 1.0;              /* the rolling column sums scale with the INPUT, here uniform in [-1, 1] */
                         for (size_t i = 0; i < frame * images; ++i) {
                             unsigned a, b;
                             memcpy(&a, &whole[i], 4); memcpy(&b, &parts[i], 4);
                             if ((a == 0x7f7f7f7fu) != (b == 0x7f7f7f7fu)) { fprintf(stderr, "FAILED: written regions differ (config %u)\n", c); return 1; }
                             if (a == 0x7f7f7f7fu) continue;
-                            if (fabs((double)whole[i]) > vmax) vmax = fabs((double)whole[i]);
                             if (fabs((double)whole[i] - parts[i]) > worst) worst = fabs((double)whole[i] - parts[i]);
                         }
-                        if (!(worst <= 4e-7 * vmax)) { fprintf(stderr, "FAILED: config %u world %d boundary %d: %g of %g\n", c, world, boundary, worst, vmax); return 1; }
+                        if (!(worst <= 2.5e-7 * vmax)) { fprintf(stderr, "FAILED: config %u world %d boundary %d: %g of %g\n", c, world, boundary, worst, vmax); return 1; }
                     }
                     ++checks;
                 }

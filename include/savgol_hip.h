@@ -257,7 +257,7 @@ int savgol2d_laplacian_batch_f32(int half_win_x, int half_win_y, int poly_order,
  *   exactly as in savgol2d_apply_batch_f32.  All band_rows output rows are written (VALID: not the frame's own first / last
  *   half_window_y rows, not the half_window_x border columns).  Enqueue-only plus a stream-ordered scratch allocation; the
  *   FIRST launch (the band itself) does not read the halos.  Method 1 gives the whole-frame call's bits; method 2 its bits for
- *   kernels of order > 3 or derivative kernels, and fp32 rounding (<= 4e-7 of the frame's maximum) for the additive smoothing
+ *   kernels of order > 3 or derivative kernels, and fp32 rounding (<= 2.5e-7 of the input's maximum) for the additive smoothing
  *   kernels, whose rolling column sums are re-seeded on a phase tied to the frame's row 0.
  * The halo buffers are the caller's to fill: a device-to-device copy on one GPU, ncclSend / ncclRecv across GPUs --
  * savgol2d_rowband_exchange_rccl in the optional lib/libsavgol_hip_rccl.so (csrc/sg_rowband_rccl.cpp; comm = an ncclComm_t,

@@ -258,8 +258,11 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     // pass's 14 + 16 NT independent multiply-adds.  (Issued after it, as the first version did, every row had the wave stall
     // on lgkmcnt three to four times with nothing to do.)
     constexpr int UNITS = NOUT * NT;
-    // (n = 15, 16: one buffer and the reads right before their use -- a second 36-register window does not fit beside the row ring)
-    constexpr int NB = N >= 15 ? 1 : 2;
+    // (n = 15, 16: one buffer and the reads right before their use -- a second 36-register window does not fit beside the row ring;
+    //  the additive form at n = 6, 7, 9, 10: its box unit consumes a window in ~16 instructions, too few to hide a second buffer's
+    //  reads behind -- one buffer is 10-14 % faster at n = 6, 9, 10 and 0.5-3 % at n = 7, 2-4 % slower at n = 3, 5, 12, 14, level
+    //  elsewhere: previous build vs this one in one process, profiles/r03_2d_experiments.txt exp12 / exp13)
+    constexpr int NB = (N >= 15 || (BOX && (N == 6 || N == 7 || N == 9 || N == 10))) ? 1 : 2;
     f32x4 hq[NB][R::NQ];
     auto fetch = [&](auto uc, int par) {
         constexpr int u = decltype(uc)::value, o = u / NT, t = u % NT;

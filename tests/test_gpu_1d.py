@@ -839,3 +839,64 @@ def test_many_short_channels_split_below_the_launch_limit(sg, sgo, torch_gpu):
         assert check(y[pick].cpu().numpy()), flags
         assert not torch.isnan(y).any()
         del y
+
+
+def test_randomized_strided_calls(sg, sgo, torch_gpu):
+    """60 random array-of-structs calls: record size 4..80 bytes, random field offsets (aligned and not), separate arrays / the same
+    array with another field / the same field in place, counts from one window to a few tiles, channel pitches with slack, any (n,
+    m, d, dt), with and without SAVGOL_BATCH_BOUNDARY_AWARE, default and reference summation.  Every draw: the filtered field within
+    the dot-product error bound of the double oracle (bit-identical to the oracle's fp32 restatement in the reference order), every
+    other byte of the destination untouched.  Covers the fused kernel, its channel-end tiles and the staged fallback alike."""
+    torch = torch_gpu
+    L = sg.lib()
+    seed, iters = fuzz(20261004, 60)
+    rng = np.random.default_rng(seed)
+    for it in range(iters):
+        n = int(rng.integers(1, 33)); m = int(rng.integers(0, min(2 * n, 8) + 1)); d = int(rng.integers(0, min(m, 3) + 1))
+        dt = float(rng.choice([1.0, 0.5, 2.0])); mode = int(rng.integers(0, 4))
+        rec = int(rng.integers(1, 21)) * 4                                     # record bytes
+        aligned = rng.random() < 0.8
+        off_in = int(rng.integers(0, rec // 4)) * 4 if aligned or rec < 8 else int(rng.integers(0, rec - 3))
+        count = int(rng.integers(2 * n + 1, 5000)); ch = int(rng.integers(1, 4))
+        pitch = count * rec + int(rng.integers(0, 3)) * 4
+        layout = int(rng.integers(0, 3))                                       # 0 separate arrays, 1 same array other field, 2 same field in place
+        if rec < 8 and layout == 1:
+            layout = 0
+        flags = int(rng.choice([0, 0, sg.SAVGOL_BATCH_BOUNDARY_AWARE, sg.SAVGOL_BATCH_REFERENCE_SUMMATION,
+                                sg.SAVGOL_BATCH_REFERENCE_SUMMATION | sg.SAVGOL_BATCH_BOUNDARY_AWARE]))
+        src_h = rng.integers(0, 256, (ch * pitch + 8,), dtype=np.uint8)
+        field = signal(rng, (ch, count)).astype(np.float32)
+        for c in range(ch):                                                    # plant the field into the byte image
+            for_bytes = field[c].view(np.uint8).reshape(count, 4)
+            idx = c * pitch + off_in + np.arange(count)[:, None] * rec + np.arange(4)[None, :]
+            src_h[idx] = for_bytes
+        if layout == 0:
+            dst_h = rng.integers(0, 256, (ch * pitch + 8,), dtype=np.uint8)
+            off_out = int(rng.integers(0, rec // 4)) * 4
+        elif layout == 1:
+            dst_h = src_h
+            off_out = (off_in // 4 * 4 + 4 * int(rng.integers(1, rec // 4))) % rec
+            if abs(off_out - off_in) < 4 or rec - abs(off_out - off_in) < 4:
+                layout, dst_h, off_out = 0, rng.integers(0, 256, (ch * pitch + 8,), dtype=np.uint8), 0
+        else:
+            dst_h, off_out = src_h, off_in
+        src = torch.from_numpy(src_h.copy()).cuda()
+        dst = src if layout != 0 else torch.from_numpy(dst_h.copy()).cuda()
+        before = dst.cpu().numpy().copy()
+        f = sg.Filter(n, m, d, dt, mode)
+        rc = L.savgol_apply_strided_batch_f32_ex(f.ptr, src.data_ptr(), rec, off_in, pitch, dst.data_ptr(), rec, off_out, pitch, ch, count, flags, None)
+        assert rc == 0, (it, sg.last_error())
+        after = dst.cpu().numpy()
+        eff_mode = mode if flags & sg.SAVGOL_BATCH_BOUNDARY_AWARE else 0
+        o = sgo.Filter(n, m, d, dt, eff_mode)
+        idx = (np.arange(ch)[:, None, None] * pitch + off_out + np.arange(count)[None, :, None] * rec + np.arange(4)[None, None, :]).reshape(-1)
+        got = after[idx].view(np.float32).reshape(ch, count)
+        if flags & sg.SAVGOL_BATCH_REFERENCE_SUMMATION:
+            assert same_bits(got, o.apply(field)), (it, n, m, d, mode, rec, off_in, off_out, layout, flags)
+        else:
+            ref = o.apply_f64(field.astype(np.float64))
+            rows = np.vstack([f.center_weights[None, :], f.edge_weights]).astype(np.float64)
+            bound = (2 * n + 2) * 2.0 ** -24 * np.abs(rows).sum(axis=1).max() * np.abs(field).max() / (np.float32(dt) ** d)
+            assert np.abs(got - ref).max() <= bound, (it, n, m, d, mode, rec, off_in, off_out, layout, flags)
+        mask = np.ones(after.shape, bool); mask[idx] = False
+        assert np.array_equal(after[mask], before[mask]), (it, "bytes outside the output field changed")
