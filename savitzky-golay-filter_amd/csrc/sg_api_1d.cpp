@@ -533,6 +533,27 @@ static bool zero_copy_length(size_t n)
     return n >= lo && n <= hi;
 }
 
+// Short host signals (<= 4096 samples; the reference's demo filters 360): the resident small-call service of sg_k1d_misc.hip -- no
+// launch, no copies through the runtime: 0 = `output` holds the result, 1 = not taken (longer signal, service disabled or
+// unavailable: the caller goes on to the launched paths), -1 = error.  Caller holds ctx->mu.
+extern "C" int sg_small_call(void *ctx, const float *d_table, const float *input, float *output, int L, int n, int mode, int store_lo,
+                             int store_hi, int out_shift, int negate, float dt_inv);
+static unsigned host_call_flags();
+static int small_host_call(const char *who, DeviceCtx *ctx, const SavgolFilter *f, const float *input, float *output, size_t length, Variant variant)
+{
+    if (length > 4096) return 1;
+    if (!filter_sane(f, who)) return -1;
+    const int n = f->config.half_window;
+    const FilterPlan *plan = plan_get(ctx, f, NEED_REF);
+    if (!plan) return -1;
+    const unsigned flags = host_call_flags();
+    const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
+    const bool inner = variant == VALID;
+    const int negate = (mode == SAVGOL_BOUNDARY_POLYNOMIAL && (flags & SAVGOL_BATCH_CORRECT_LEADING_EDGE) && (f->config.derivative & 1)) ? 1 : 0;
+    return sg_small_call(ctx, plan->d_ref, input, output, (int)length, n, mode, inner ? n : 0, inner ? (int)length - n : (int)length, inner ? n : 0, negate,
+                         dt_inverse(f));
+}
+
 // the host-pointer drop-in calls: always the reference's summation order; the two semantic switches follow the process defaults
 static unsigned host_call_flags()
 {
@@ -726,6 +747,11 @@ int savgol_apply(const SavgolFilter *filter, const float *input, float *output, 
     DeviceCtx *ctx = sg::ctx_get();
     if (!ctx) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    {
+        const int rc = small_host_call("savgol_apply", ctx, filter, input, output, length, FULL);
+        if (rc == 0) return 0;
+        if (rc < 0) { fprintf(stderr, "savgol_apply: %s\n", savgol_hip_last_error()); return -1; }
+    }
     // pipelined unless the two host buffers overlap without being the same (in place is fine: a chunk is downloaded only
     // after the samples it overwrites went up; a shifted overlap is not, so that case keeps the upload-everything-first path)
     const bool partial_overlap = input != output && (uintptr_t)input < (uintptr_t)(output + length) && (uintptr_t)output < (uintptr_t)(input + length);
@@ -762,6 +788,11 @@ size_t savgol_apply_valid(const SavgolFilter *filter, const float *input, size_t
     if (!ctx) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     const size_t out_len = input_length - 2 * (size_t)filter->config.half_window;
+    {
+        const int rc = small_host_call("savgol_apply_valid", ctx, filter, input, output, input_length, VALID);
+        if (rc == 0) return out_len;
+        if (rc < 0) { fprintf(stderr, "savgol_apply_valid: %s\n", savgol_hip_last_error()); return 0; }
+    }
     // VALID writes output[j - n]: even output == input is a shifted overlap, so only disjoint buffers are pipelined
     const bool overlap = (uintptr_t)input < (uintptr_t)(output + out_len) && (uintptr_t)output < (uintptr_t)(input + input_length);
     if (input_length >= PIPE_MIN_LENGTH && input_length <= ((size_t)1 << 30) && !overlap) {
@@ -805,6 +836,15 @@ int savgol_apply_strided(const SavgolFilter *filter, const void *input, size_t i
     float *d_out = d_in + ld;
     const char *ib = static_cast<const char *>(input) + in_offset;
     for (size_t i = 0; i < count; ++i) memcpy(&stage[i], ib + i * in_stride, sizeof(float));
+    {
+        const int rc = small_host_call("savgol_apply_strided", ctx, filter, stage, stage + ld, count, (host_call_flags() & SAVGOL_BATCH_BOUNDARY_AWARE) ? FULL : FULL_POLY_EDGES);
+        if (rc < 0) { fprintf(stderr, "savgol_apply_strided: %s\n", savgol_hip_last_error()); return -1; }
+        if (rc == 0) {
+            char *ob0 = static_cast<char *>(output) + out_offset;
+            for (size_t i = 0; i < count; ++i) memcpy(ob0 + i * out_stride, &stage[ld + i], sizeof(float));
+            return 0;
+        }
+    }
     if (zero_copy_length(count)) {                               // short signals: the kernel works on the pinned staging buffer itself
         float *pin = stage;
         if (enqueue_batch<float>("savgol_apply_strided", filter, pin, pin + ld, 1, count, ld, ld, (host_call_flags() & SAVGOL_BATCH_BOUNDARY_AWARE) ? FULL : FULL_POLY_EDGES,

@@ -31,6 +31,7 @@ struct DeviceCtx {
     void                   *pinned = nullptr; // small pinned buffer for scalar results
     size_t                  pinned_bytes = 0;
     std::unordered_multimap<uint64_t, TableEntry> tables;    // by content hash
+    void                   *small = nullptr;  // sg::SmallService (sg_k1d_misc.hip): the resident kernel behind short host-pointer calls
 };
 
 // 64-bit content hash, eight bytes at a time on four independent lanes (a table is hashed on every call that uses it: the

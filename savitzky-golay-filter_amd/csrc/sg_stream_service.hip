@@ -226,7 +226,7 @@ static void probe_fault(int sig)
     if (tl_probing) siglongjmp(g_probe_jmp, 1);
     sigaction(sig, sig == SIGSEGV ? &g_probe_old_segv : &g_probe_old_bus, nullptr);
 }
-static bool host_can_write_device_memory(void *p)
+bool host_can_write_device_memory(void *p)          // also used by the small-call service (sg_k1d_misc.hip)
 {
     static std::mutex mu;
     static int verdict = -1;                                 // -1 unknown, 0 no, 1 yes

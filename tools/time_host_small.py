@@ -6,7 +6,7 @@ sg = load_package()
 import ctypes as C
 L = sg.lib()
 f = sg.Filter(5, 3, 0, 1.0, 0)
-for n in (360, 4096, 1 << 16, 1 << 18, 1000000, 1 << 22, (1 << 23) - 8, 1 << 23, 1 << 24):
+for n in (360, 1024, 4096, 1 << 16, 1 << 18, 1000000, 1 << 22, (1 << 23) - 8, 1 << 23, 1 << 24):
     x = np.random.default_rng(0).normal(0, 1, n).astype(np.float32)
     y = np.zeros_like(x)
     px = x.ctypes.data_as(C.POINTER(C.c_float)); py = y.ctypes.data_as(C.POINTER(C.c_float))
