@@ -79,7 +79,11 @@ int main(void)
                     const int additive = method == 2 && cfg.poly_order <= 3 && cfg.deriv_x == 0 && cfg.deriv_y == 0;
                     if (!additive) {
                         if (memcmp(whole, parts, sizeof(float) * frame * images) != 0) {
-                            fprintf(stderr, "FAILED: config %u world %d boundary %d method %d: stitched bands differ from the whole frame\n", c, world, boundary, method);
+                            size_t bad = 0, first = (size_t)-1;
+                            for (size_t i = 0; i < frame * images; ++i)
+                                if (memcmp(&whole[i], &parts[i], 4) != 0) { if (first == (size_t)-1) first = i; ++bad; }
+                            fprintf(stderr, "FAILED: config %u world %d boundary %d method %d: stitched bands differ from the whole frame in %zu values; first at image %zu row %zu column %zu: %.9g vs %.9g\n",
+                                    c, world, boundary, method, bad, first / frame, (first % frame) / stride, first % stride, whole[first], parts[first]);
                             return 1;
                         }
                     } else {

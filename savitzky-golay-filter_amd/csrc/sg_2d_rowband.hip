@@ -105,7 +105,10 @@ int savgol2d_apply_rowband_f32(const Savgol2DFilter *filter, const float *d_band
     const size_t simg = (size_t)srows * sstride;
     const int nstrips = (d_halo_up ? 1 : 0) + (d_halo_down ? 1 : 0);
     float *scratch = nullptr;
-    if (!sg::hip_ok(hipMallocAsync(reinterpret_cast<void **>(&scratch), sizeof(float) * 2 * simg * images * nstrips, st), "hipMallocAsync(row-band strips)")) return -1;
+    sg::DeviceCtx *ctx = sg::ctx_get();
+    if (!ctx) return -1;
+    scratch = static_cast<float *>(sg::scratch_alloc(ctx, sizeof(float) * 2 * simg * images * nstrips, st, "scratch (row-band strips)"));
+    if (!scratch) return -1;
     int rc = 0;
     int k = 0;
     for (int side = 0; side < 2 && rc == 0; ++side) {
@@ -128,7 +131,7 @@ int savgol2d_apply_rowband_f32(const Savgol2DFilter *filter, const float *d_band
         float *dst = (side == 0 ? d_out : d_out + (size_t)(band_rows - ny) * out_stride) + c0;
         if (!sg::copy_rows(dst, out_stride, (long long)out_image_pitch, sout + (size_t)ny * sstride + c0, sstride, (long long)simg, ny, nc, images, st)) rc = -1;
     }
-    if (!sg::hip_ok(hipFreeAsync(scratch, st), "hipFreeAsync(row-band strips)")) rc = -1;
+    if (!sg::scratch_free(scratch, st, "scratch free (row-band strips)")) rc = -1;
     return rc;
 }
 

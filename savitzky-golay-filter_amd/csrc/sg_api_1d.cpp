@@ -355,7 +355,10 @@ int enqueue_long(const char *who, const SavgolFilter *f, const T *d_in, T *d_out
     constexpr size_t E = 256;                                    // samples of a channel end that are copied out (>= 4 half windows, vector aligned)
     const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
     T *scratch = nullptr;
-    if (!sg::hip_ok(hipMallocAsync(reinterpret_cast<void **>(&scratch), 4 * channels * E * sizeof(T), st), "hipMallocAsync(channel ends)")) return -1;
+    DeviceCtx *ctx_long = sg::ctx_get();
+    if (!ctx_long) return -1;
+    scratch = static_cast<T *>(sg::scratch_alloc(ctx_long, 4 * channels * E * sizeof(T), st, "scratch (channel ends)"));
+    if (!scratch) return -1;
     T *in_a = scratch, *in_b = scratch + channels * E, *out_a = scratch + 2 * channels * E, *out_b = scratch + 3 * channels * E;
     auto copy2d = [&](T *dst, size_t dst_ld, const T *src, size_t src_ld, size_t width) {
         return sg::hip_ok(hipMemcpy2DAsync(dst, dst_ld * sizeof(T), src, src_ld * sizeof(T), width * sizeof(T), channels, hipMemcpyDeviceToDevice, st),
@@ -372,7 +375,7 @@ int enqueue_long(const char *who, const SavgolFilter *f, const T *d_in, T *d_out
              enqueue_batch<T>(who, f, in_a, out_a, 2 * channels, E, E, E, variant, st, flags) == 0 &&      // in_b / out_b follow in_a / out_a
              copy2d(d_out, out_ld, out_a, E, n) && copy2d(d_out + (length - n), out_ld, out_b + (E - n), E, n);
     }
-    if (!sg::hip_ok(hipFreeAsync(scratch, st), "hipFreeAsync(channel ends)")) ok = false;
+    if (!sg::scratch_free(scratch, st, "scratch free (channel ends)")) ok = false;
     return ok ? 0 : -1;
 }
 
@@ -710,10 +713,11 @@ int savgol_apply_strided_batch_f32_ex(const SavgolFilter *filter, const void *d_
 
     // ---- staged path (the reference's summation order, unaligned or overlapping fields, channels beyond 2^30 samples): gather the
     //      field into dense rows, filter, scatter back.  The two dense frames are this call's own, allocated and freed in stream
-    //      order (hipMallocAsync / hipFreeAsync): no shared arena, no lock, no synchronise -- the call only enqueues. ----
+    //      order (sg::scratch_alloc: the library's own retained pool): no shared arena, no lock, no synchronise -- the call only enqueues. ----
     const size_t ld = (count + 3) & ~(size_t)3;
     float *dense = nullptr;
-    if (!sg::hip_ok(hipMallocAsync(reinterpret_cast<void **>(&dense), 2 * channels * ld * sizeof(float), st), "hipMallocAsync(strided scratch)")) return -1;
+    dense = static_cast<float *>(sg::scratch_alloc(ctx, 2 * channels * ld * sizeof(float), st, "scratch (strided staging)"));
+    if (!dense) return -1;
     float *result = dense + channels * ld;
     int rc = 0;
     if (sg_launch_gather_f32(d_in, in_stride, in_offset, in_channel_pitch, dense, ld, channels, count, st) != 0) {
@@ -725,7 +729,7 @@ int savgol_apply_strided_batch_f32_ex(const SavgolFilter *filter, const void *d_
         sg_set_error("%s: scatter launch failed", who);
         rc = -1;
     }
-    if (!sg::hip_ok(hipFreeAsync(dense, st), "hipFreeAsync(strided scratch)")) rc = -1;
+    if (!sg::scratch_free(dense, st, "scratch free (strided staging)")) rc = -1;
     return rc;
 }
 

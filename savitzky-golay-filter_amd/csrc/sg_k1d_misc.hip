@@ -214,7 +214,7 @@ struct alignas(64) SmallMailbox {
     const float *table;                                      // [n+1][2n+1] device table of the filter (FilterPlan::d_ref)
     int L, n, mode, store_lo, store_hi, out_shift, negate;
     float dt_inv;
-    int cmd;                                                 // 0 = filter, 1 = leave
+    int cmd;                                                 // 0 = filter a signal, 1 = leave, 2 = ring rows of one SavgolStream
     int pad;
     unsigned long long seq_b;
 };
@@ -224,6 +224,7 @@ struct SmallArgs { const SmallMailbox *bell; const float *in; float *out; unsign
 __global__ __launch_bounds__(256) void sg_small_service_kernel(const SmallArgs a)
 {
     __shared__ float xs[SMALL_MAX_SAMPLES];
+    __shared__ float centre[SAVGOL_MAX_WINDOW + 3];         // the filter's centre row: every interior output reads all of it
     __shared__ SmallMailbox cmd;
     __shared__ int leave;
     unsigned long long seq = 1;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void sg_small_service_kernel(const SmallArgs a
                     if (threadIdx.x == 0) {
                         unsigned w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
                         __builtin_memcpy(&cmd, w, 64);
-                        leave = cmd.cmd != 0;
+                        leave = cmd.cmd == 1;
                     }
                     break;
                 }
@@ -266,10 +267,34 @@ __global__ __launch_bounds__(256) void sg_small_service_kernel(const SmallArgs a
                 const int i = (int)threadIdx.x + 256 * k;
                 if (i < L) xs[i] = v[k];
             }
+            if (cmd.cmd == 0 && (int)threadIdx.x <= 2 * n) centre[threadIdx.x] = cmd.table[threadIdx.x];
         }
         __syncthreads();
+        if (cmd.cmd == 2) {
+            // one SavgolStream (savgol_stream_push / _push_full / _flush*, reference src/savgol_stream.c:25-74): the staged floats are the
+            // ring [0, 65), then as integers {count, row[count], backward[count]}; cmd.n = window size, cmd.mode = write position.  Output r
+            // = one ring dot product with table row row[r]: ONE accumulator, taps ascending, multiply and add rounded separately.
+            const int ws = cmd.n, wp = cmd.mode;
+            const int *meta = reinterpret_cast<const int *>(xs + SAVGOL_MAX_WINDOW);
+            const int count = meta[0];
+            if ((int)threadIdx.x < count) {
+                const int r = threadIdx.x;
+                const float *w = cmd.table + (size_t)meta[1 + r] * ws;
+                const int backward = meta[1 + count + r];
+                float acc = 0.0f;
+                for (int i = 0; i < ws; ++i) {
+                    int slot = backward ? (wp + ws - 1 - i) : (wp + i);
+                    if (slot >= ws) slot -= ws;
+                    acc = __fadd_rn(acc, __fmul_rn(w[i], xs[slot]));
+                }
+                __hip_atomic_store(a.out + r, __fmul_rn(acc, cmd.dt_inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        } else
         for (int j = cmd.store_lo + (int)threadIdx.x; j < cmd.store_hi; j += 256) {
-            const float y = __fmul_rn(reference_order_output(xs, L, n, cmd.table, cmd.mode, j, cmd.negate), cmd.dt_inv);
+            // interior outputs take the centre taps from LDS (same values, same order); the 2n edge outputs their rows from the table
+            const float v = (j >= n && j < L - n) ? dot_reference_order(centre, 2 * n + 1, [&](int k) { return xs[j - n + k]; })
+                                                   : reference_order_output(xs, L, n, cmd.table, cmd.mode, j, cmd.negate);
+            const float y = __fmul_rn(v, cmd.dt_inv);
             __hip_atomic_store(a.out + (j - cmd.out_shift), y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's outputs have left for host memory ...
@@ -382,25 +407,17 @@ static bool small_launch(SmallService *s)
 }
 }  // namespace sg
 
-// 0 = output holds the result; 1 = not taken (disabled, too long, service unavailable): the caller runs its usual path; the
-// caller holds ctx->mu.  `out_count` floats are copied to `output` from result index 0.
-extern "C" int sg_small_call(void *ctx_v, const float *d_table, const float *input, float *output, int L, int n, int mode, int store_lo,
-                             int store_hi, int out_shift, int negate, float dt_inv)
+// post one command and wait for its answer.  0 = `output` holds out_floats results (from result index out_off); 1 = service
+// unavailable (the caller runs its usual launched path).  The caller holds ctx->mu.
+static int small_roundtrip(sg::SmallService *s, const void *in_bytes, size_t in_size, sg::SmallMailbox m, float *output, size_t out_floats, size_t out_off)
 {
     using namespace sg;
-    DeviceCtx *ctx = static_cast<DeviceCtx *>(ctx_v);
-    if (L > SMALL_MAX_SAMPLES || L < 2 * n + 1) return 1;
-    SmallService *s = small_service(ctx);
-    if (!s || s->broken) return 1;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (!s->running && !small_launch(s)) { s->broken = true; return 1; }
-        memcpy(s->in_host, input, sizeof(float) * (size_t)L);
+        memcpy(s->in_host, in_bytes, in_size);
         _mm_sfence();                                                 // the samples are on their way before the doorbell
-        SmallMailbox m;
-        memset(&m, 0, sizeof(m));
         const unsigned long long seq = ++s->seq;
-        m.seq_a = seq; m.seq_b = seq; m.table = d_table; m.L = L; m.n = n; m.mode = mode; m.store_lo = store_lo; m.store_hi = store_hi;
-        m.out_shift = out_shift; m.negate = negate; m.dt_inv = dt_inv; m.cmd = 0;
+        m.seq_a = seq; m.seq_b = seq;
         memcpy(s->bell_host, &m, sizeof(m));
         _mm_sfence();
         const auto t0 = std::chrono::steady_clock::now();
@@ -422,7 +439,7 @@ extern "C" int sg_small_call(void *ctx_v, const float *d_table, const float *inp
             }
         }
         if (!exited) {
-            memcpy(output, s->out_host + (store_lo - out_shift), sizeof(float) * (size_t)(store_hi - store_lo));
+            memcpy(output, s->out_host + out_off, sizeof(float) * out_floats);
             return 0;
         }
         // the kernel left on its idle time-out before it saw this call: wait for it, start a fresh one, post again
@@ -433,6 +450,45 @@ extern "C" int sg_small_call(void *ctx_v, const float *d_table, const float *inp
     return 1;
 }
 
+// savgol_apply / _valid / _strided on a short host signal.  0 = done, 1 = not taken (disabled, too long, unavailable).
+extern "C" int sg_small_call(void *ctx_v, const float *d_table, const float *input, float *output, int L, int n, int mode, int store_lo,
+                             int store_hi, int out_shift, int negate, float dt_inv)
+{
+    using namespace sg;
+    DeviceCtx *ctx = static_cast<DeviceCtx *>(ctx_v);
+    // one workgroup does the arithmetic: beyond ~64 K multiply-adds the launched kernel (every CU) is as fast (4096 samples at
+    // n = 5: 20 vs 23 us; tools/time_host_small.py)
+    if (L > SMALL_MAX_SAMPLES || L < 2 * n + 1 || (long long)L * (2 * n + 1) > 65536) return 1;
+    SmallService *s = small_service(ctx);
+    if (!s || s->broken) return 1;
+    SmallMailbox m;
+    memset(&m, 0, sizeof(m));
+    m.table = d_table; m.L = L; m.n = n; m.mode = mode; m.store_lo = store_lo; m.store_hi = store_hi;
+    m.out_shift = out_shift; m.negate = negate; m.dt_inv = dt_inv; m.cmd = 0;
+    return small_roundtrip(s, input, sizeof(float) * (size_t)L, m, output, (size_t)(store_hi - store_lo), (size_t)(store_lo - out_shift));
+}
+
+// `count` ring dot products of one SavgolStream (table row row[r], walked backward where backward[r]): 0 = done, 1 = not taken
+extern "C" int sg_small_stream_rows(void *ctx_v, const float *d_table, const float *ring, int ws, int wp, float dt_inv, int count, const int *row,
+                                    const int *backward, float *output)
+{
+    using namespace sg;
+    DeviceCtx *ctx = static_cast<DeviceCtx *>(ctx_v);
+    if (count < 1 || count > SAVGOL_MAX_HALF_WINDOW + 1 || ws > SAVGOL_MAX_WINDOW) return 1;
+    SmallService *s = small_service(ctx);
+    if (!s || s->broken) return 1;
+    float staged[SAVGOL_MAX_WINDOW + 1 + 2 * (SAVGOL_MAX_HALF_WINDOW + 1)];
+    memcpy(staged, ring, sizeof(float) * SAVGOL_MAX_WINDOW);
+    int *meta = reinterpret_cast<int *>(staged + SAVGOL_MAX_WINDOW);
+    meta[0] = count;
+    memcpy(meta + 1, row, sizeof(int) * (size_t)count);
+    memcpy(meta + 1 + count, backward, sizeof(int) * (size_t)count);
+    const int total = SAVGOL_MAX_WINDOW + 1 + 2 * count;
+    SmallMailbox m;
+    memset(&m, 0, sizeof(m));
+    m.table = d_table; m.L = total; m.n = ws; m.mode = wp; m.dt_inv = dt_inv; m.cmd = 2;
+    return small_roundtrip(s, staged, sizeof(float) * (size_t)total, m, output, (size_t)count, 0);
+}
 
 extern "C" {
 

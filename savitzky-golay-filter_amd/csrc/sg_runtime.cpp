@@ -74,6 +74,30 @@ const float *ctx_table(DeviceCtx *ctx, const void *host, size_t bytes, uint64_t 
     return dev;
 }
 
+void *scratch_alloc(DeviceCtx *ctx, size_t bytes, hipStream_t st, const char *what)
+{
+    {
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        if (!ctx->pool) {
+            hipMemPoolProps props;
+            memset(&props, 0, sizeof(props));
+            props.allocType = hipMemAllocationTypePinned;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = ctx->ordinal;
+            hipMemPool_t pool = nullptr;
+            if (!hip_ok(hipMemPoolCreate(&pool, &props), "hipMemPoolCreate")) return nullptr;
+            uint64_t keep = ~0ull;                            // never hand freed blocks back while the process lives
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            ctx->pool = pool;
+        }
+    }
+    void *p = nullptr;
+    if (!hip_ok(hipMallocFromPoolAsync(&p, bytes, ctx->pool, st), what)) return nullptr;
+    return p;
+}
+
+bool scratch_free(void *p, hipStream_t st, const char *what) { return hip_ok(hipFreeAsync(p, st), what); }
+
 void *ctx_arena(DeviceCtx *ctx, size_t bytes)
 {
     if (bytes <= ctx->arena_bytes) return ctx->arena;

@@ -31,6 +31,7 @@ struct DeviceCtx {
     void                   *pinned = nullptr; // small pinned buffer for scalar results
     size_t                  pinned_bytes = 0;
     std::unordered_multimap<uint64_t, TableEntry> tables;    // by content hash
+    hipMemPool_t            pool = nullptr;  // the library's own stream-ordered pool (scratch_alloc)
     void                   *small = nullptr;  // sg::SmallService (sg_k1d_misc.hip): the resident kernel behind short host-pointer calls
 };
 
@@ -67,6 +68,14 @@ const float *ctx_table(DeviceCtx *ctx, const void *host, size_t bytes, uint64_t 
 // Scratch of at least `bytes`; caller holds ctx->mu for as long as it uses the memory.
 void *ctx_arena(DeviceCtx *ctx, size_t bytes);
 void *ctx_pinned(DeviceCtx *ctx, size_t bytes);
+
+// Stream-ordered scratch for the calls that need a temporary frame (strided staging, channel ends of very long channels, row-band
+// strips): allocated and freed in the order of `st`, so such a call only enqueues.  From the library's OWN memory pool with the
+// release threshold at its maximum: the default pool hands freed blocks back to the driver at the next opportunity, and on the
+// legacy NULL stream that was observed (examples/rowband_demo.c, round 3) to pull the memory from under kernels that were still
+// queued -- garbage in the row-band strips unless the caller synchronised around the call.  A retained pool never unmaps.
+void *scratch_alloc(DeviceCtx *ctx, size_t bytes, hipStream_t st, const char *what);   // nullptr + error text on failure
+bool scratch_free(void *p, hipStream_t st, const char *what);
 
 bool hip_ok(hipError_t e, const char *what);      // false + error text on failure
 

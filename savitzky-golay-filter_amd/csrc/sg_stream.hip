@@ -27,6 +27,9 @@
 #include "sg_runtime.hpp"
 #include "sg_stream.hpp"
 
+extern "C" int sg_small_stream_rows(void *ctx, const float *d_table, const float *ring, int ws, int wp, float dt_inv, int count, const int *row,
+                                    const int *backward, float *output);
+
 namespace sg {
 
 // one ring dot product, reference order: taps ascending, ring walked forward from the oldest sample
@@ -346,8 +349,11 @@ static int single_stream_rows(const SavgolStream *st, const RowList &rows, float
     if (!ctx) return -1;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     const float *table = filter_table(ctx, f);
+    if (!table) return -1;
+    // the resident small-call service (sg_k1d_misc.hip): a doorbell instead of a launch + synchronise per sample -- same arithmetic
+    if (sg_small_stream_rows(ctx, table, st->buffer, f->window_size, st->write_pos, st->dt_inv, rows.count, rows.row, rows.backward, dst) == 0) return 0;
     float *pinned = static_cast<float *>(ctx_pinned(ctx, sizeof(float) * 256));
-    if (!table || !pinned) return -1;
+    if (!pinned) return -1;
     float *ring = pinned + 64;
     memcpy(ring, st->buffer, sizeof(float) * SAVGOL_MAX_WINDOW);
     hipLaunchKernelGGL(sg_stream_rows_kernel, dim3(1), dim3(64), 0, nullptr, ring, pinned, table, f->window_size,
