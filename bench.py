@@ -229,8 +229,10 @@ def bench_config1(sg, no_cpu):
             el2 = time.perf_counter() - t0
             out["reference_demo_360pt"] = {"cpu_reference_Msamples_per_s": round(360 * iters / el / 1e6, 2),
                                            "gpu_host_pointer_Msamples_per_s": round(360 * it2 / el2 / 1e6, 4),
-                                           "note": "test_savgol_main.c:136-155 (360 points, n=6, m=3, called back to back through ctypes); a 1.4 KB "
-                                                   "signal per call is pure launch + PCIe latency on a GPU: the CPU wins this case by design"}
+                                           "note": "test_savgol_main.c:136-155 (360 points, n=6, m=3, called back to back through ctypes); short host signals "
+                                                   "run on the resident small-call service (a doorbell and a completion word instead of H2D + launch + D2H: "
+                                                   "~7 us per call; rounds 1-2: ~22 us, 16 Msamples/s); the reference's own demo binary linked against this "
+                                                   "library prints 55-58 Msamples/s (profiles/r03_small_service.txt)"}
     return out
 
 
@@ -346,8 +348,9 @@ def bench_stream(sg, a):
     for v in xs[64:64 + 500]:
         s1.push(float(v))
     res["single_stream_push"] = {"us_per_sample": round((time.perf_counter() - t0) / 500 * 1e6, 2),
-                                 "note": "savgol_stream_push on one SavgolStream: a kernel launch and a synchronise per sample; the reference's CPU "
-                                         "push costs ~50 ns (cpu_baseline below) -- one stream at a time is the CPU's case, the bank API is the GPU's"}
+                                 "note": "savgol_stream_push on one SavgolStream: one doorbell round trip to the resident small-call service per sample "
+                                         "(rounds 1-2: a launch and a synchronise, ~18 us); the reference's CPU push costs ~50 ns (cpu_baseline below) -- "
+                                         "one stream at a time is the CPU's case, the bank API is the GPU's"}
     if not a.no_cpu:
         res["cpu_baseline"] = cpu_reference("stream")
     return res
