@@ -21,6 +21,11 @@
  *     frames (no shared scratch, no lock, no synchronise);
  *   - savgol_streambank_save/_load, savgol_hip_synchronize and every host-pointer drop-in call of savgolFilter.h /
  *     savgol_stream.h / savgol2d.h: synchronous by nature (they return host data).
+ * Short host-pointer calls (savgol_apply / _valid / _strided on <= 4096 samples and <= 64 K multiply-adds, every savgol_stream_* call
+ * on one SavgolStream) do not launch: one workgroup stays resident behind a doorbell (csrc/sg_k1d_misc.hip) and answers in 6-8 us
+ * with the reference's bits.  It leaves by itself after 2 ms without a call -- a device-wide synchronise issued by the caller
+ * waits at most that long for it -- and is restarted by the next short call.  Environment: SAVGOL_HIP_SMALL_SERVICE=0 disables
+ * it (every call then launches), SAVGOL_HIP_SMALL_SERVICE_IDLE_US sets the idle time (50 ... 5 000 000).
  * Accuracy of the default fp32 device kernels against the double-accumulation oracle (normwise, max|err| / max|ref|):
  * <= 1e-6 for smoothing filters (derivative 0), <= 2e-6 for derivative filters on the 1-D path (the reference's own fp32
  * paths -- batch vs stream -- disagree by 1.3e-6 there), <= 4e-6 for 2-D derivative frames.  Bit-identical-to-the-reference

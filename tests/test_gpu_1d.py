@@ -900,3 +900,55 @@ def test_randomized_strided_calls(sg, sgo, torch_gpu):
             assert np.abs(got - ref).max() <= bound, (it, n, m, d, mode, rec, off_in, off_out, layout, flags)
         mask = np.ones(after.shape, bool); mask[idx] = False
         assert np.array_equal(after[mask], before[mask]), (it, "bytes outside the output field changed")
+
+
+def test_small_call_service_is_bit_identical_and_survives_idling(sg, sgo, torch_gpu):
+    """Short host-pointer signals (<= 4096 samples and <= 64 K multiply-adds) do not launch: a resident workgroup behind a doorbell
+    computes them in the reference's order (csrc/sg_k1d_misc.hip, sg_small_service_kernel).  Bit-identical to the oracle's fp32
+    restatement for every entry point, boundary mode and a spread of lengths around the service's limits; across the kernel's idle
+    exit (2 ms without a call) and a device-wide synchronise; from several threads at once; in place."""
+    import threading
+    import time
+    torch = torch_gpu
+    rng = np.random.default_rng(31)
+    cases = [(6, 3, 0, 1.0), (5, 3, 1, 0.5), (32, 4, 2, 1.0), (1, 1, 0, 1.0), (16, 2, 1, 1e-3), (32, 10, 4, 1.0)]
+    for (n, m, d, dt) in cases:
+        ws = 2 * n + 1
+        for length in (ws, ws + 1, 360, 1000, 65536 // ws, 65536 // ws + 1, 4096, 4097):
+            if length < ws:
+                continue
+            x = signal(rng, (length,)).astype(np.float32)
+            for mode in range(4):
+                f = sg.Filter(n, m, d, dt, mode)
+                o = sgo.Filter(n, m, d, dt, mode)
+                assert same_bits(f.apply(x), o.apply(x)), (n, m, d, mode, length)
+                if mode == 0:
+                    assert same_bits(f.apply_valid(x), o.apply_valid(x)), (n, length)
+                    y = x.copy()
+                    f.apply(y, out=y)                                   # in place: the out-of-place answer
+                    assert same_bits(y, o.apply(x))
+        time.sleep(0.01)                                                # the kernel leaves after 2 ms without a call; the next call restarts it
+        torch.cuda.synchronize()                                        # ... and a device-wide synchronise must not hang on it
+    # strided through the service
+    src = rng.normal(0, 1, (500, 3)).astype(np.float32); dst = src.copy()
+    f = sg.Filter(3, 2, 0, 1.0, 0)
+    assert f.apply_strided(src, 12, 4, dst, 12, 4, 500) == 0
+    want = src.copy(); want[:, 1] = sgo.Filter(3, 2, 0, 1.0, 0).apply(np.ascontiguousarray(src[:, 1]))
+    assert same_bits(dst, want)
+    # several threads, one filter
+    f = sg.Filter(6, 3, 0, 1.0, 1)
+    xs = [signal(rng, (360 + 7 * k,)).astype(np.float32) for k in range(6)]
+    want = [sgo.Filter(6, 3, 0, 1.0, 1).apply(x) for x in xs]
+    errors = []
+
+    def worker(k):
+        for _ in range(200):
+            if not same_bits(f.apply(xs[k]), want[k]):
+                errors.append(k)
+                return
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
