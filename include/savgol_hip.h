@@ -17,8 +17,10 @@
  *     uploads its tables (hipMalloc + a synchronous hipMemcpy, then cached for the life of the process; tables are never
  *     freed or moved, so captured graphs and queued launches stay valid) and, for the derivative frames, solves the
  *     least-squares problem on the host (cached per configuration);
- *   - savgol_apply_strided_batch_f32: launches plus a stream-ordered hipMallocAsync/hipFreeAsync pair for its two dense
- *     frames (no shared scratch, no lock, no synchronise);
+ *   - savgol_apply_strided_batch_f32[_ex]: launches only when the fields are 4-byte aligned and disjoint (the fused kernel);
+ *     otherwise (reference summation order, unaligned or overlapping fields) launches plus a stream-ordered allocation /
+ *     free pair for its two dense frames, from the library's own retained memory pool (no shared scratch, no lock, no
+ *     synchronise); savgol2d_apply_rowband_f32 and channels longer than 2^30 samples use the same pool for their scratch;
  *   - savgol_streambank_save/_load, savgol_hip_synchronize and every host-pointer drop-in call of savgolFilter.h /
  *     savgol_stream.h / savgol2d.h: synchronous by nature (they return host data).
  * Short host-pointer calls (savgol_apply / _valid / _strided on <= 4096 samples and <= 64 K multiply-adds, every savgol_stream_* call

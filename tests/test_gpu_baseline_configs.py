@@ -124,6 +124,56 @@ def test_batch_call_is_graph_capturable(sg, sgo, torch_gpu):
     assert torch.equal(y, want)
 
 
+def test_round3_entry_points_are_graph_capturable(sg, torch_gpu):
+    """The entry points added in round 3 that promise "launches only": per-call flags (_ex), the fused strided call, the FMA stream
+    bank's block push, and the three-output Hessian / rectangular-window launches.  Captured once, replayed, compared with the
+    eager results."""
+    torch = torch_gpu
+    L = sg.lib()
+    x = torch.empty((32, 9000), dtype=torch.float32, device="cuda")
+    sg.synth(x)
+    y_ex, y_ref = torch.zeros_like(x), torch.zeros_like(x)
+    aos = torch.randn((4, 5000, 4), device="cuda")
+    aos_out = torch.zeros_like(aos)
+    f = sg.Filter(32, 4, 1, 1.0, 0)
+    T, S = 200, 4096
+    xs = torch.randn((T, S), device="cuda")
+    ys = torch.zeros_like(xs)
+    bank = sg.StreamBank(S, 16, 2, 1, 1e-3, fma=True)
+    img = torch.randn((2, 160, 520), device="cuda")
+    rect_out, hess = torch.zeros_like(img), [torch.zeros_like(img) for _ in range(3)]
+    f2 = sg.Filter2D(4, 7, 3)
+
+    def enqueue(stream):
+        h = stream.cuda_stream if stream is not None else None
+        f.apply_batch(x, y_ex, 32, 9000, stream=stream, flags=sg.SAVGOL_BATCH_PLAIN_SUMMATION | sg.SAVGOL_BATCH_CORRECT_LEADING_EDGE)
+        f.apply_batch(x, y_ref, 32, 9000, stream=stream, flags=sg.SAVGOL_BATCH_REFERENCE_SUMMATION)
+        assert L.savgol_apply_strided_batch_f32(f.ptr, aos.data_ptr(), 16, 4, 5000 * 16, aos_out.data_ptr(), 16, 8, 5000 * 16, 4, 5000, h) == 0
+        f2.apply_batch(img, rect_out, 160, 520, 2, boundary=2, method=2, stream=stream)
+        assert L.savgol2d_hessian_batch_f32(7, 7, 3, img.data_ptr(), 160, 520, 520, 160 * 520, hess[0].data_ptr(), hess[1].data_ptr(), hess[2].data_ptr(),
+                                            520, 160 * 520, 2, 1.0, 1.0, 1, h) == 0
+
+    enqueue(None)                                              # warm-up: tables, plans
+    bank.push_block(xs, T, ys)
+    torch.cuda.synchronize()
+    want = [t.clone() for t in (y_ex, y_ref, aos_out, rect_out, *hess)]
+    want_stream = ys.clone()
+    bank2 = sg.StreamBank(S, 16, 2, 1, 1e-3, fma=True)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            enqueue(s)
+            bank2.push_block(xs, T, ys, stream=s)
+    for t in (y_ex, y_ref, aos_out, rect_out, *hess, ys):
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for t, w in zip((y_ex, y_ref, aos_out, rect_out, *hess), want):
+        assert torch.equal(t, w)
+    assert torch.equal(ys[32:], want_stream[32:])
+
+
 def test_2d_batch_and_derivative_calls_are_graph_capturable(sg, torch_gpu):
     """Same promise for the 2-D device entry points (rolling-window kernel, fused tile kernel, dense kernel)."""
     torch = torch_gpu
