@@ -276,7 +276,15 @@ int savgol2d_apply_rowband_f32(const Savgol2DFilter *filter,
                                const float *d_halo_up, const float *d_halo_down, int halo_stride, size_t halo_image_pitch,
                                float *d_out, int out_stride, size_t out_image_pitch,
                                size_t images, Savgol2DBoundary boundary, int method, void *stream);
-/* (declared in savgol_hip_rccl.h -- that library is the only part that links librccl) */
+/* Step (2) of the call above on its own -- the half_window_y output rows next to each artificial edge -- for callers that overlap
+ * the halo exchange with the band: enqueue savgol2d_apply_batch_f32 on the band (it reads no halo) while the exchange runs on
+ * another stream, make the compute stream wait for the exchange, then call this.  Same arguments, same result as the one call. */
+int savgol2d_apply_rowband_edges_f32(const Savgol2DFilter *filter,
+                                     const float *d_band, int band_rows, int cols, int in_stride, size_t in_image_pitch,
+                                     const float *d_halo_up, const float *d_halo_down, int halo_stride, size_t halo_image_pitch,
+                                     float *d_out, int out_stride, size_t out_image_pitch,
+                                     size_t images, Savgol2DBoundary boundary, int method, void *stream);
+/* (savgol2d_rowband_exchange_rccl is declared in savgol_hip_rccl.h -- that library is the only part that links librccl) */
 
 /* ---------------------------------------------------------------- bench utilities ----- *
  * Synthetic workload of SURVEY.md section 8(d), generated in HBM (never crosses PCIe):

@@ -75,12 +75,9 @@ int savgol2d_rowband_plan(int rows, int half_win_y, int rank, int world_size, in
     return 0;
 }
 
-int savgol2d_apply_rowband_f32(const Savgol2DFilter *filter, const float *d_band, int band_rows, int cols, int in_stride,
-                               size_t in_image_pitch, const float *d_halo_up, const float *d_halo_down, int halo_stride,
-                               size_t halo_image_pitch, float *d_out, int out_stride, size_t out_image_pitch, size_t images,
-                               Savgol2DBoundary boundary, int method, void *stream)
+static int rowband_check(const char *who, const Savgol2DFilter *filter, const float *d_band, float *d_out, int band_rows, int cols, const float *d_halo_up,
+                         const float *d_halo_down, int halo_stride, size_t halo_image_pitch, size_t images)
 {
-    const char *who = "savgol2d_apply_rowband_f32";
     if (!filter || !d_band || !d_out) { sg_set_error("%s: NULL pointer", who); return -1; }
     const int nx = filter->config.half_window_x, ny = filter->config.half_window_y;
     if (nx < 1 || ny < 1 || nx > SAVGOL2D_MAX_HALF_WINDOW || ny > SAVGOL2D_MAX_HALF_WINDOW) { sg_set_error("%s: filter struct is not a valid Savgol2DFilter", who); return -1; }
@@ -91,16 +88,23 @@ int savgol2d_apply_rowband_f32(const Savgol2DFilter *filter, const float *d_band
         return -1;
     }
     if (any_halo && (halo_stride < cols || (images > 1 && halo_image_pitch < (size_t)ny * (size_t)halo_stride))) { sg_set_error("%s: bad halo geometry", who); return -1; }
+    return 0;
+}
+
+// step (2) alone: the ny output rows next to each artificial edge, from the halo rows and the band's own 2 ny rows next to that edge
+int savgol2d_apply_rowband_edges_f32(const Savgol2DFilter *filter, const float *d_band, int band_rows, int cols, int in_stride,
+                                     size_t in_image_pitch, const float *d_halo_up, const float *d_halo_down, int halo_stride,
+                                     size_t halo_image_pitch, float *d_out, int out_stride, size_t out_image_pitch, size_t images,
+                                     Savgol2DBoundary boundary, int method, void *stream)
+{
+    const char *who = "savgol2d_apply_rowband_edges_f32";
+    if (rowband_check(who, filter, d_band, d_out, band_rows, cols, d_halo_up, d_halo_down, halo_stride, halo_image_pitch, images) != 0) return -1;
+    if ((!d_halo_up && !d_halo_down) || images == 0) return 0;
+    const int nx = filter->config.half_window_x, ny = filter->config.half_window_y;
+    if (cols - 2 * nx <= 0 && boundary == SAVGOL2D_BOUNDARY_VALID) { sg_set_error("%s: image smaller than the window", who); return -1; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool valid = boundary == SAVGOL2D_BOUNDARY_VALID;
-    // (1) the band as a frame.  VALID on a band thinner than the window writes nothing here; its rows all come from the strips.
-    if (!(valid && (band_rows - 2 * ny <= 0))) {
-        if (savgol2d_apply_batch_f32(filter, d_band, band_rows, cols, in_stride, in_image_pitch, d_out, out_stride, out_image_pitch, images,
-                                     boundary, method, stream) != 0) return -1;
-    } else if (cols - 2 * nx <= 0) { sg_set_error("%s: image smaller than the window", who); return -1; }
-    if (!any_halo || images == 0) return 0;
-
-    // (2) the artificial edges: [halo | first 2 ny rows] and [last 2 ny rows | halo], each 3 ny rows, filtered as frames
+    // [halo | first 2 ny rows] and [last 2 ny rows | halo], each 3 ny rows, filtered as frames
     const int srows = 3 * ny, sstride = (cols + 3) & ~3;
     const size_t simg = (size_t)srows * sstride;
     const int nstrips = (d_halo_up ? 1 : 0) + (d_halo_down ? 1 : 0);
@@ -133,6 +137,25 @@ int savgol2d_apply_rowband_f32(const Savgol2DFilter *filter, const float *d_band
     }
     if (!sg::scratch_free(scratch, st, "scratch free (row-band strips)")) rc = -1;
     return rc;
+}
+
+int savgol2d_apply_rowband_f32(const Savgol2DFilter *filter, const float *d_band, int band_rows, int cols, int in_stride,
+                               size_t in_image_pitch, const float *d_halo_up, const float *d_halo_down, int halo_stride,
+                               size_t halo_image_pitch, float *d_out, int out_stride, size_t out_image_pitch, size_t images,
+                               Savgol2DBoundary boundary, int method, void *stream)
+{
+    const char *who = "savgol2d_apply_rowband_f32";
+    if (rowband_check(who, filter, d_band, d_out, band_rows, cols, d_halo_up, d_halo_down, halo_stride, halo_image_pitch, images) != 0) return -1;
+    const int nx = filter->config.half_window_x, ny = filter->config.half_window_y;
+    const bool valid = boundary == SAVGOL2D_BOUNDARY_VALID;
+    // (1) the band as a frame.  VALID on a band thinner than the window writes nothing here; its rows all come from the strips.
+    if (!(valid && (band_rows - 2 * ny <= 0))) {
+        if (savgol2d_apply_batch_f32(filter, d_band, band_rows, cols, in_stride, in_image_pitch, d_out, out_stride, out_image_pitch, images,
+                                     boundary, method, stream) != 0) return -1;
+    } else if (cols - 2 * nx <= 0) { sg_set_error("%s: image smaller than the window", who); return -1; }
+    // (2) the artificial edges
+    return savgol2d_apply_rowband_edges_f32(filter, d_band, band_rows, cols, in_stride, in_image_pitch, d_halo_up, d_halo_down, halo_stride,
+                                            halo_image_pitch, d_out, out_stride, out_image_pitch, images, boundary, method, stream);
 }
 
 }  // extern "C"

@@ -96,18 +96,25 @@ class RowBand:
         return bufs.get("up"), bufs.get("dn")
 
     def apply_c(self, filter2d, local, boundary=1, method=0, stream=None):
-        """The same through the C ABI (savgol2d_apply_rowband_f32, csrc/sg_2d_rowband.hip): post the exchange, enqueue the
-        band + its edge strips in ONE call given the received halo rows.  `local`: [images, own, cols] fp32 on the GPU."""
+        """The same through the C ABI (csrc/sg_2d_rowband.hip), exchange overlapped with the band: post the halo sends / receives,
+        enqueue the band itself (savgol2d_apply_batch_f32: it reads no halo), wait for the halos, then the edge strips
+        (savgol2d_apply_rowband_edges_f32).  `local`: [images, own, cols] fp32 on the GPU."""
         from . import lib, last_error, _addr, _stream
         images, own, cols = local.shape
         if self.thin:
             raise ValueError(f"row bands thinner than 2 x half window ({2 * self.ny}): use fewer ranks")
         local = local.contiguous()
-        up, dn = self.finish_exchange(self.start_exchange(local))
+        handle = self.start_exchange(local)
         out = torch.empty_like(local)
-        rc = lib().savgol2d_apply_rowband_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols,
-                                              _addr(up) if up is not None else None, _addr(dn) if dn is not None else None,
-                                              cols, self.ny * cols, _addr(out), cols, own * cols, images, boundary, method, _stream(stream))
+        L = lib()
+        if not (boundary == 0 and own - 2 * self.ny <= 0):
+            if L.savgol2d_apply_batch_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols, _addr(out), cols, own * cols, images, boundary, method,
+                                          _stream(stream)) != 0:
+                raise RuntimeError(last_error())
+        up, dn = self.finish_exchange(handle)
+        rc = L.savgol2d_apply_rowband_edges_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols,
+                                                _addr(up) if up is not None else None, _addr(dn) if dn is not None else None,
+                                                cols, self.ny * cols, _addr(out), cols, own * cols, images, boundary, method, _stream(stream))
         if rc != 0:
             raise RuntimeError(last_error())
         return out

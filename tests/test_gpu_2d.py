@@ -603,3 +603,57 @@ def test_randomized_row_bands_and_rectangular_windows(sg, sgo, torch_gpu):
         else:
             assert np.array_equal(ph, wh), (nx, ny, order, dx, dy, rows, cols, b, method, world, np.abs(ph - wh).max())
         done += 1
+
+
+def _apply_c_worker(rank, world, port, rows, cols, images, n, out_dir):
+    import os as _os
+    import sys as _sys
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch as _torch
+    import torch.distributed as _dist
+    _dist.init_process_group("gloo", rank=rank, world_size=world)
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    from __graft_entry__ import load_package
+    import importlib
+    sgm = load_package()
+    rowband = importlib.import_module("savgol_amd.rowband")
+    _torch.cuda.set_device(0)
+    rng = np.random.default_rng(77)
+    x = rng.normal(0, 1, (images, rows, cols)).astype(np.float32)
+    band = rowband.RowBand(rows, n)
+    local = _torch.from_numpy(x[:, band.lo:band.hi].copy()).cuda()
+    f = sgm.Filter2D(n, n, 4, 1, 0)                      # order 4 derivative: rank 2, not the additive form -> bit-exact in both methods
+    for b in range(3):
+        for method in (1, 2):
+            out = band.apply_c(f, local, boundary=b, method=method)
+            _torch.cuda.synchronize()
+            np.save(_os.path.join(out_dir, f"c{b}_{method}_r{rank}.npy"), out.cpu().numpy())
+    _dist.barrier()
+    _dist.destroy_process_group()
+
+
+def test_row_bands_apply_c_two_ranks_sharing_the_gpu(sg, torch_gpu, tmp_path):
+    """RowBand.apply_c -- halo exchange posted, savgol2d_apply_batch_f32 on the band meanwhile, then savgol2d_apply_rowband_edges_f32 --
+    with two real ranks (gloo carries the halos; both ranks use this box's one GPU): the stitched bands equal the whole-frame result
+    bit for bit, all three boundary modes, methods 1 and 2."""
+    import socket
+    import torch.multiprocessing as mp
+    torch = torch_gpu
+    rows, cols, images, n, world = 150, 300, 2, 5, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_apply_c_worker, args=(world, port, rows, cols, images, n, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(77)
+    x = torch.from_numpy(rng.normal(0, 1, (images, rows, cols)).astype(np.float32)).cuda()
+    f = sg.Filter2D(n, n, 4, 1, 0)
+    for b in range(3):
+        for method in (1, 2):
+            whole = torch.zeros_like(x)
+            f.apply_batch(x, whole, rows, cols, images, boundary=b, method=method)
+            got = np.concatenate([np.load(tmp_path / f"c{b}_{method}_r{r}.npy") for r in range(world)], axis=1)
+            wh = whole.cpu().numpy()
+            if b == 0:                                    # VALID: the untouched border is whatever the buffers held (empty vs zeros): compare the written region
+                assert np.array_equal(got[:, n:rows - n, n:cols - n], wh[:, n:rows - n, n:cols - n]), (b, method)
+            else:
+                assert np.array_equal(got, wh), (b, method)
