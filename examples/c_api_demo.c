@@ -86,10 +86,9 @@ int main(void)
     double apart = 0.0;
     for (size_t i = 0; i < L; ++i) { double d = fabs((double)yb[5 * L + i] - (double)y[i]); if (d > apart) apart = d; }
     CHECK(apart < 2e-6);
-    /* ... and bit for bit when the batch call is asked for the reference's order too */
-    CHECK(savgol_hip_set_option(SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 1) == 0);
-    CHECK(savgol_apply_batch_f32(f, d_in, d_out, CH, L, L, L, NULL) == 0);
-    CHECK(savgol_hip_set_option(SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 0) == 0);
+    /* ... and bit for bit when the batch call is asked for the reference's order too: a per-call flag, so another thread's
+     * calls keep their own summation order (the process-wide savgol_hip_set_option only sets the default of the non-_ex calls) */
+    CHECK(savgol_apply_batch_f32_ex(f, d_in, d_out, CH, L, L, L, SAVGOL_BATCH_REFERENCE_SUMMATION, NULL) == 0);
     CHECK(hipMemcpy(yb, d_out, sizeof(float) * L * CH, hipMemcpyDeviceToHost) == hipSuccess);
     CHECK(memcmp(yb + 5 * L, y, sizeof(float) * L) == 0);
     double worst = 0.0;                                          /* smoothing a smooth signal: stays close to it */
@@ -160,6 +159,48 @@ int main(void)
         CHECK(savgol_streambank_samples_received(bank) == 100 + TICKS);
         savgol_streambank_destroy(twin);
         hipFree(d_rows); hipFree(d_o2); free(h_rows); free(h_a); free(h_b);
+    }
+
+    /* ---- 3c. many ticks per launch: 1024 ticks of all the streams in one call.  The bank created above keeps the reference's
+     *          summation order (bit-identical to savgol_stream_push); a bank created with SAVGOL_STREAMBANK_FMA runs fused
+     *          multiply-adds instead -- faster, and within fp32 rounding of the first ---- */
+    {
+        enum { BT = 1024 };
+        SavgolStreamBank *fast = savgol_streambank_create_ex(&scfg, S, SAVGOL_STREAMBANK_FMA);
+        CHECK(fast != NULL);
+        float *h_blk = (float *)malloc(sizeof(float) * S * BT), *h_y1 = (float *)malloc(sizeof(float) * S), *h_y2 = (float *)malloc(sizeof(float) * S);
+        float *d_blk, *d_y1, *d_y2;
+        unsigned rs = 777u;
+        for (size_t i = 0; i < S * BT; ++i) { rs = rs * 1664525u + 1013904223u; h_blk[i] = (float)(rs >> 8) * (1.0f / 8388608.0f) - 1.0f; }
+        CHECK(hipMalloc((void **)&d_blk, sizeof(float) * S * BT) == hipSuccess);
+        CHECK(hipMalloc((void **)&d_y1, sizeof(float) * S * BT) == hipSuccess);
+        CHECK(hipMalloc((void **)&d_y2, sizeof(float) * S * BT) == hipSuccess);
+        CHECK(hipMemcpy(d_blk, h_blk, sizeof(float) * S * BT, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(savgol_streambank_reset(bank, NULL) == 0);
+        double ms[2] = {0.0, 0.0};
+        for (int rep = 0; rep < 3; ++rep) {                      /* windows fill during the first call; time the last */
+            SavgolStreamBank *banks[2] = {bank, fast};
+            float *outs[2] = {d_y1, d_y2};
+            for (int b = 0; b < 2; ++b) {
+                CHECK(savgol_hip_synchronize(NULL) == 0);
+                const double t0 = now_us();
+                CHECK(savgol_streambank_push_block(banks[b], d_blk, BT, outs[b], NULL) == (rep == 0 ? BT - 32 : BT));
+                CHECK(savgol_hip_synchronize(NULL) == 0);
+                ms[b] = (now_us() - t0) * 1e-3;
+            }
+        }
+        CHECK(hipMemcpy(h_y1, d_y1 + (size_t)(BT - 1) * S, sizeof(float) * S, hipMemcpyDeviceToHost) == hipSuccess);
+        CHECK(hipMemcpy(h_y2, d_y2 + (size_t)(BT - 1) * S, sizeof(float) * S, hipMemcpyDeviceToHost) == hipSuccess);
+        double top = 0.0, gap = 0.0;
+        for (size_t i = 0; i < S; ++i) {
+            if (fabs(h_y1[i]) > top) top = fabs(h_y1[i]);
+            if (fabs((double)h_y1[i] - (double)h_y2[i]) > gap) gap = fabs((double)h_y1[i] - (double)h_y2[i]);
+        }
+        CHECK(gap <= 4e-6 * top);
+        printf("stream bank: %d ticks x %zu streams per call: %.3f ms in the reference's order, %.3f ms with fused multiply-adds (%.0f / %.0f Gsamples/s), last tick %.1e apart (relative)\n",
+               BT, S, ms[0], ms[1], 1e-6 * S * BT / ms[0], 1e-6 * S * BT / ms[1], gap / top);
+        savgol_streambank_destroy(fast);
+        hipFree(d_blk); hipFree(d_y1); hipFree(d_y2); free(h_blk); free(h_y1); free(h_y2);
     }
 
     savgol_streambank_destroy(bank);
