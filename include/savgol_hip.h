@@ -219,12 +219,11 @@ int    savgol_streambank_load(SavgolStreamBank *bank, const void *host_blob, voi
  * `images` frames, image k at base + k*image_pitch (elements), row pitch in elements.
  * Arithmetic of savgol2d_apply / savgol2d_apply_valid (src/savgol2d.c:356-456).
  * method: 0 = auto, 1 = direct dense window (bit-identical to the reference), 2 = exact low-rank
- * separable passes (rolling-window kernel for every half window up to the rank it is built for -- 4 terms
- * to n = 8, 3 to n = 12, 2 to n = 16 -- the tile kernel otherwise), 3 = the
- * separable tile kernel for any half window (diagnostic).
+ * separable passes (rolling-window kernel for every half window: one launch holds 4 terms to n = 8, 3 to n = 12, 2 to
+ * n = 16; kernels with more -- orders 4 to 6 on wide windows -- take two launches, the second adding to the output frame,
+ * which therefore must not overlap the input), 3 = the separable tile kernel for any half window (diagnostic).
  * Rectangular windows (half_window_x != half_window_y): methods 0 / 2 run the rolling kernel of the LARGER half window on
- * factors zero-padded to it (same results to fp32 rounding; -1 from method 2, the dense kernel from method 0, where that
- * kernel is not built for the window's rank).  Caveat of the padding: a zero tap times a non-finite sample is NaN, so in
+ * factors zero-padded to it (same results to fp32 rounding).  Caveat of the padding: a zero tap times a non-finite sample is NaN, so in
  * this method NaN / Inf input spreads over the padded (square) window instead of the rectangular one; method 1 does not.  */
 int savgol2d_apply_batch_f32(const Savgol2DFilter *filter,
                              const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,

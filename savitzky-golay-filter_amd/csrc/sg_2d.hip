@@ -154,6 +154,27 @@ static int dense_kernel_env()
     return v;
 }
 
+// The rolling kernel on one output, in one launch where its taps fit the scalar registers (4 terms up to n = 8, 3 up to n = 12, 2
+// beyond), else in TWO: the first half of the terms, then the rest with job.accumulate (out += ...).  The second pass re-reads the
+// input and read-modify-writes the output -- 20 B per pixel instead of 8 -- which these arithmetic-bound shapes can afford: order 6
+// at n = 9 / 12 / 16: 1.83 / 2.25 / 3.15 ms per 16 frames on the tile kernel, two rolling passes 1.5-2 x faster (profiles/
+// r03_sweep_2d_orders.txt).  0 = launched, 1 = not covered.  `n` = the (larger) half window the factors are laid out for.
+static int roll_passes(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
+{
+    static const int split_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_SPLIT"); return e ? atoi(e) : 1; }();     // 0: A/B against the tile kernel
+    int rc = sg2d_launch_rolling(n, terms, job, factors, scale, images, cu_count, st);
+    if (rc == 0 || n < 9 || terms < 3 || terms > 4 || !split_env) return rc;
+    // 2 + 2 (or 2 + 1) rather than 3 + 1 where three terms fit: the accumulating pass moves 12 B per pixel and takes ~0.9 ms per 16
+    // frames at n = 9 whether it carries one term or two, so it may as well carry two (3 + 1: 1.05 + 0.89 ms, 2 + 2: 0.75 + 0.93)
+    const int first = 2;
+    Job2D rest = job;
+    rest.accumulate = 1;
+    // try the second pass's instantiation first?  Both exist for every n >= 9 (NT <= 2), so the first failing means neither ran.
+    rc = sg2d_launch_rolling(n, first, job, factors, scale, images, cu_count, st);
+    if (rc != 0) return rc;
+    return sg2d_launch_rolling(n, terms - first, rest, factors + (size_t)first * 2 * (2 * n + 2), scale, images, cu_count, st);
+}
+
 static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_in, int rows, int cols, int in_stride,
                       long long in_pitch, float *d_out, int out_stride, long long out_pitch, size_t images, int boundary,
                       int method, hipStream_t st)
@@ -202,7 +223,7 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
                 job.in = d_in + (long long)i0 * in_pitch;
                 job.out = d_out + (long long)i0 * out_pitch;
                 if (method != 3 || !square) {            // rolling-window kernel where it applies, else the tile kernel (square windows only)
-                    const int rc = sg2d_launch_rolling(nmax, terms, job, factors, f->scale, (unsigned)ni, ctx->cu_count, st);
+                    const int rc = roll_passes(nmax, terms, job, factors, f->scale, (unsigned)ni, ctx->cu_count, st);
                     if (rc == 0) continue;
                 }
                 if (!square) { all_rolled = false; break; }      // no rolling kernel of this rank at this half window: the dense kernel below
@@ -446,13 +467,16 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
                                  plan.out[1], plan.out[2], (unsigned)images, ctx->cu_count, st) == 0)
             return hip_ok(hipGetLastError(), who) ? 0 : -1;
     }
-    if (plan.outputs <= 2) {
+    // (three frames that could not share one rolling launch -- Hessians of order >= 4: two or three terms each -- also go one
+    //  rolling launch per frame from n = 6 up: n = 8, order 4: 2.21 ms fused on the tile kernel, 1.52 as three launches; n = 16,
+    //  order 3: 2.72 vs 1.72; at n = 4 the fused tile kernel is level or ahead, 1.41 vs 1.56)
+    if (plan.outputs <= 2 || n >= 6) {
         bool rolled = true;
         int tbase = 0;
         for (int o = 0; o < plan.outputs && rolled; ++o) {
             job.out = plan.out[o];
-            rolled = sg2d_launch_rolling(n, plan.terms[o], job, factors + (size_t)tbase * 2 * (ws + 1), plan.scale[o], (unsigned)images,
-                                         ctx->cu_count, st) == 0;
+            rolled = roll_passes(n, plan.terms[o], job, factors + (size_t)tbase * 2 * (ws + 1), plan.scale[o], (unsigned)images,
+                                 ctx->cu_count, st) == 0;
             tbase += plan.terms[o];
         }
         if (rolled) return hip_ok(hipGetLastError(), who) ? 0 : -1;

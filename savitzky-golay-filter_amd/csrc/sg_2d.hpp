@@ -16,6 +16,7 @@ struct Job2D {
     int boundary;                       // Savgol2DBoundary (anything else was mapped to CONSTANT by the host)
     float scale;
     int tiles_x, tiles_y;
+    int accumulate;                     // rolling kernel only: out += result (the second pass of a kernel split over two launches)
 };
 
 // frame coordinate fix-up of the padded modes (reference src/savgol2d.c:428-445); VALID only clamps

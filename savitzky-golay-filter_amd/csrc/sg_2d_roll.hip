@@ -32,7 +32,7 @@
 
 namespace sg {
 
-template <int N>
+template <int N, bool ACC = false>
 struct Roll {
     // halo lanes on each side of a strip: ceil(N/4) are needed; more where that buys whole memory lines.  A strip stores
     // 1024 - 32*HL bytes per row starting 16*HL bytes into its loaded KiB: with HL = 1 (3) the stores of neighbouring strips meet
@@ -52,10 +52,12 @@ struct Roll {
     // rows loaded ahead of the arithmetic (odd: U must be even).  PMC on config 4 (n=7) showed the waves parked on s_waitcnt 47 %
     // of their cycles with one row ahead; three rows ahead cost 8 VGPRs and buy 5-10 % from n = 6 up (n = 8: 2.21 -> 2.00 ms per
     // 64 frames, n = 9: 2.41 -> 2.29), nothing or a loss below (tools/ab_2d.py, all builds in one process)
+    // (accumulating passes, n >= 9: the output rows they add to are prefetched through a ring of four slots, which wants U to be a
+    //  multiple of four: P = 5 at odd half windows)
 #ifdef SG_ROLL_P
     static constexpr int P = SG_ROLL_P;
 #else
-    static constexpr int P = N >= 6 ? 3 : 1;
+    static constexpr int P = (ACC && (N & 1) && N < 15) ? 5 : (N >= 6 ? 3 : 1);
 #endif
     static constexpr int U = 2 * N + 1 + P;                 // ring slots = unroll factor of the row loop
     // branch-free row loop (buffer stores whose range check replaces the `if`, whole groups of U rows without an exit test).
@@ -133,12 +135,16 @@ __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
 // the row that leaves; re-seeded from the ring every U rows, so the drift is bounded by U steps), box_x over a lane's four
 // outputs is one sum of the aligned pairs they share plus a sliding correction.  89 instead of 125 VALU instructions per row
 // of 256 columns at n = 7.
-template <int N, int NT, int NOUT, bool VEC, bool BOX>
+//
+// ACC (NOUT = 1): the result is ADDED to what the output frame holds -- the second launch of a kernel whose terms do not fit one
+// (taps live in SGPRs: 4 terms at n >= 9, 3 at n >= 13).  The stored row's previous content is loaded one row step ahead.
+template <int N, int NT, int NOUT, bool VEC, bool BOX, bool ACC>
 __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *mine, const float *in, float *const (&outs)[NOUT],
                                           int xload, int yb, int nout, int lane, int xlo, int xhi, int ylo, int yhi)
 {
-    typedef Roll<N> R;
+    typedef Roll<N, ACC> R;
     static_assert(!BOX || (NT == 2 && NOUT == 1), "the additive form is one output of two terms");
+    static_assert(!ACC || (NOUT == 1 && !BOX && !R::STRAIGHT), "accumulating passes are single-output launches of the general form");
     static_assert(R::U % 2 == 0, "the LDS row alternates with the ring slot: U must be even");
     const int c0 = xload + 4 * lane;                         // this lane's first column (frame coordinates)
     int ix0 = 0, ix1 = 0, ix2 = 0, ix3 = 0;
@@ -324,6 +330,23 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             return true;
         });
     };
+    // ACC: what the output frame holds in this lane's columns of frame row yo (rows past the frame: clamped, never stored)
+    // Loaded as far ahead as the input rows (P row steps): the wait counter is in order, so a load consumed one step after its issue
+    // would make every input row issued before it arrive within that step too -- the input prefetch would be worth one row, not P
+    // (first version: the accumulating pass took 0.91 ms where the plain one takes 0.53).  Ring of P+1 slots indexed by literals.
+    // (n = 15, 16: no room for four slots beside the 34-row ring -- two, loaded one step ahead)
+    constexpr int PR = N >= 15 ? 2 : 4, LEAD = PR - 1;
+    static_assert(!ACC || (R::U % PR == 0 && R::P >= LEAD), "slot = row % PR must carry over from one group of U rows to the next");
+    f32x4 prevq[PR];
+    auto load_prev = [&](int yo) -> f32x4 {
+        const float *orow = outs[0] + (long long)(yo < job.rows ? yo : job.rows - 1) * job.out_stride;
+        if constexpr (VEC) return *reinterpret_cast<const f32x4 *>(orow + c0);
+        else {
+            const bool row_ok = yo >= ylo && yo < yhi;
+            auto at = [&](int c) -> float { return (row_ok && out_lane && c >= xlo && c < xhi) ? orow[c] : 0.0f; };
+            return f32x4{at(c0), at(c0 + 1), at(c0 + 2), at(c0 + 3)};
+        }
+    };
     // the store of frame row yo of output `o`
     auto store_row = [&](auto oc, const f32x2 (&r)[2], int yo) {
         constexpr int o = decltype(oc)::value;
@@ -353,7 +376,7 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
         }
     };
     // units 0 .. UNITS-1 of the row in LDS row `par` (unit 0 already fetched): fetch the next unit, compute this one
-    auto finish_row = [&](int par, int yo) {
+    auto finish_row = [&](int par, int yo, const f32x4 prev) {
         f32x2 r[2];
         static_for<UNITS>([&](auto uc) -> bool {
             constexpr int u = decltype(uc)::value;
@@ -367,6 +390,7 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             // scheduler pulls the first consumers of a read (the pair shuffles) up to right behind it and waits there
             __builtin_amdgcn_sched_barrier(0);
             hterm(uc, r);
+            if constexpr (ACC && u == UNITS - 1) { r[0] = r[0] + f32x2{prev.x, prev.y}; r[1] = r[1] + f32x2{prev.z, prev.w}; }
             if constexpr (u % NT == NT - 1) store_row(std::integral_constant<int, u / NT>{}, r, yo);
             __builtin_amdgcn_sched_barrier(0);
             return true;
@@ -376,6 +400,10 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 #pragma unroll
     for (int r = 0; r < R::U; ++r) win[r] = load_row(r);         // rows 0..2N for the first output row, P more in flight
     vertical(std::integral_constant<int, 0>{}, 0);
+    if constexpr (ACC) {
+#pragma unroll
+        for (int j = 0; j < LEAD; ++j) prevq[j] = load_prev(yb + j);
+    }
     // Iteration m runs the vertical pass of row m and the horizontal pass + store of row m-1.  Whole groups of U iterations, no
     // early exit: the iterations past the band (at most U-1, their loads clamped to real rows) compute rows nobody stores.  An
     // exit test per row would be a branch per row, with the same cost to the wait counts as a branch around the store.
@@ -385,12 +413,14 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             const int m = base + uu;                         // base = 1 mod U: row m starts in slot (uu+1) % U
             if constexpr (!R::STRAIGHT) { if (m > nout) return false; }     // uniform; iteration m = nout still stores row nout-1
             win[uu] = load_row(m + R::U - 1);                // slot of row m-1, which no later row needs
+            if constexpr (ACC) prevq[(uu + LEAD) % PR] = load_prev(yb + m - 1 + LEAD);       // for the store LEAD iterations on
             wave_lds_sync();                                 // row m-1's vertical results (previous iteration) are written ...
             if constexpr (NB == 2) fetch(std::integral_constant<int, 0>{}, uu & 1);     // ... and its first window is on its way while row m's vertical pass runs
             __builtin_amdgcn_sched_barrier(0);
             vertical(std::integral_constant<int, (uu + 1) % R::U>{}, (uu + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            finish_row(uu & 1, yb + m - 1);
+            if constexpr (ACC) finish_row(uu & 1, yb + m - 1, prevq[uu % PR]);
+            else finish_row(uu & 1, yb + m - 1, f32x4{0.0f, 0.0f, 0.0f, 0.0f});
             return true;
         });
     }
@@ -416,7 +446,7 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #endif
 constexpr int roll_wpb(int n) { (void)n; return SG_ROLL_WPB; }
 
-template <int N, int NT, int NOUT, bool BOX>
+template <int N, int NT, int NOUT, bool BOX, bool ACC>
 __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1, float *const out2,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
@@ -454,9 +484,9 @@ __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void
         const int sx = (int)strip * R::SW;
         // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
         if ((aligned & 3) == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
-            roll_item<N, NT, NOUT, true, BOX>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+            roll_item<N, NT, NOUT, true, BOX, ACC>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
         else
-            roll_item<N, NT, NOUT, false, BOX>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+            roll_item<N, NT, NOUT, false, BOX, ACC>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
     }
 }
 
@@ -549,7 +579,7 @@ static int roll_box_env()                                   // SAVGOL_HIP_ROLL_B
     static const int v = [] { const char *e = getenv("SAVGOL_HIP_ROLL_BOX"); return e ? atoi(e) : 1; }();
     return v;
 }
-template <int N, int NT, int NOUT, bool BOX>
+template <int N, int NT, int NOUT, bool BOX, bool ACC = false>
 static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *out1, float *out2, unsigned images, int cu_count, hipStream_t st)
 {
     typedef Roll<N> R;
@@ -566,7 +596,7 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
     const size_t lds = sizeof(float) * WPB * 2 * NOUT * NT * R::BUFW;
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT, BOX>, 64 * WPB, lds) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC>, 64 * WPB, lds) != hipSuccess || nb < 1)
             nb = WPB <= 8 ? 2 : 1;
         per_cu = nb > (int)(16 / WPB) ? (int)(16 / WPB) : nb;
     }
@@ -605,7 +635,7 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
         Job2D part = job;
         part.in = job.in + (long long)i0 * job.in_pitch;
         part.out = job.out + (long long)i0 * job.out_pitch;
-        hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT, BOX>), dim3(grid), dim3(64 * WPB), lds, st, part, taps,
+        hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC>), dim3(grid), dim3(64 * WPB), lds, st, part, taps,
                            out1 ? out1 + (long long)i0 * job.out_pitch : nullptr, out2 ? out2 + (long long)i0 * job.out_pitch : nullptr, strips, bands,
                            band_rows, (unsigned)total, aligned);
     }
@@ -616,6 +646,15 @@ template <int N, int NT, int NOUT>
 static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], const float (&scale)[NOUT], float *out1, float *out2, unsigned images,
                        int cu_count, hipStream_t st)
 {
+    if (job.accumulate) {
+        // the second pass of a kernel split over two launches (sg_2d.hip, roll_passes): built where a split can be asked for
+        if constexpr (NOUT == 1 && N >= 9 && NT <= 2) {
+            RollTaps<N, NT, 1> taps;
+            memset(&taps, 0, sizeof(taps));
+            if (!fill_taps<N, NT, 1>(taps, 0, factors[0], scale[0])) return 1;
+            return launch_roll_kernel<N, NT, 1, false, true>(job, taps, out1, out2, images, cu_count, st);
+        } else return 1;
+    }
     if constexpr (NT == 2 && NOUT == 1) {
         RollTaps<N, 2, 1> box;
         memset(&box, 0, sizeof(box));

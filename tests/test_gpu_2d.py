@@ -271,14 +271,22 @@ def test_separable_rank4_and_rectangular_fallback(sg, sgo, torch_gpu):
     sg.Filter2D(4, 6, 3).apply_batch(d, out, 90, 100, 1, boundary=1, method=1)
     want = sgo.Filter2D(4, 6, 3).apply(x, 100, 1)
     assert np.array_equal(out.cpu().numpy(), want)
-    with pytest.raises(RuntimeError):                        # rank 4 at half window 16 x 9: beyond the rolling kernel's ranks, and the tile kernel is square only
-        sg.Filter2D(9, 16, 6).apply_batch(d, out, 90, 100, 1, boundary=1, method=2)
-    sg.Filter2D(9, 16, 6).apply_batch(d, out, 90, 100, 1, boundary=1, method=0)        # auto: falls back to the dense kernel
-    assert np.array_equal(out.cpu().numpy(), sgo.Filter2D(9, 16, 6).apply(x, 100, 1))
+    # rank 4 at half window 16 x 9: more terms than one launch of the wide rolling kernel holds (and the tile kernel is square only);
+    # since round 3 two rolling passes, the second accumulating -- methods 2 and 0 alike, no fall-back to the dense kernel
+    o = sgo.Filter2D(9, 16, 6)
+    hi, ref32 = o.apply_f64acc(x, 100, 1), o.apply(x, 100, 1)
+    for method in (2, 0):
+        out.fill_(-1.0)
+        sg.Filter2D(9, 16, 6).apply_batch(d, out, 90, 100, 1, boundary=1, method=method)
+        assert normwise(out.cpu().numpy(), hi) < max(2e-6, 0.75 * normwise(ref32, hi)), (method, normwise(out.cpu().numpy(), hi), normwise(ref32, hi))
+    sg.Filter2D(9, 16, 6).apply_batch(d, out, 90, 100, 1, boundary=1, method=1)
+    assert np.array_equal(out.cpu().numpy(), ref32)
 
 
 @pytest.mark.parametrize("nx,ny,order,dx,dy", [(4, 7, 3, 0, 0), (7, 4, 3, 0, 0), (2, 1, 2, 0, 0), (5, 3, 2, 0, 0), (3, 5, 4, 0, 0), (1, 16, 2, 0, 0), (12, 2, 3, 0, 0),
-                                               (4, 7, 3, 1, 0), (6, 3, 3, 0, 1), (3, 8, 4, 2, 0), (5, 2, 3, 1, 1), (2, 6, 2, 0, 2)])
+                                               (4, 7, 3, 1, 0), (6, 3, 3, 0, 1), (3, 8, 4, 2, 0), (5, 2, 3, 1, 1), (2, 6, 2, 0, 2),
+                                               # more terms than one launch of the wide windows holds: two passes, the second accumulating
+                                               (14, 3, 4, 0, 0), (4, 16, 6, 0, 0), (10, 5, 6, 0, 0), (9, 9, 6, 0, 0), (13, 13, 4, 0, 0), (3, 15, 5, 1, 0)])
 def test_rectangular_windows_on_the_rolling_kernel(sg, sgo, torch_gpu, nx, ny, order, dx, dy):
     """nx != ny (reference savgol2d.h:82-90; its test: test_savgol2d.c:508-543) on method 2: the exact low-rank factors of the
     (2ny+1) x (2nx+1) kernel, zero-padded to the square window of the larger half width.  Against the double-accumulation
@@ -305,7 +313,13 @@ def test_rectangular_windows_on_the_rolling_kernel(sg, sgo, torch_gpu, nx, ny, o
             for k in range(images):
                 hi = o.apply_f64acc(x[k], cols, b)
                 assert np.all(got[k][~sel] == -7.0), (rows, cols, b)
-                assert normwise(got[k][sel], hi[sel]) < tol, (rows, cols, b, normwise(got[k][sel], hi[sel]))
+                err, bar = normwise(got[k][sel], hi[sel]), tol
+                if err >= tol and order >= 5:
+                    # high orders on wide windows cancel: there the bar is the reference's own fp32 error on the same frame (as in
+                    # test_rolling_window_kernel_all_half_windows)
+                    ref32 = o.apply(x[k], cols, b if b else 1)
+                    bar = max(tol, 0.75 * normwise(ref32[sel], hi[sel]))
+                assert err < bar, (rows, cols, b, err, bar)
     if dx + dy == 0:
         c = torch.full((1, 64, 300), 3.25, device="cuda")
         out = torch.zeros_like(c)
