@@ -370,7 +370,7 @@ def bench_image(sg, a):
         ms = timed(lambda: f.apply_batch(x, y, size, size, Nimg, boundary=b, method=a.method), reps=5, warm=1)
         pix = Nimg * size * size
         res[name] = {"ms": round(ms, 3), "Mpix_per_s": round(pix / ms / 1e3, 1),
-                     "roofline": roofline(8.0 * pix, ms, algorithmic_bytes_per_pixel=8, kernel="sg2d_rolling_kernel<7,2,1,true>" if a.method == 2 else "sg2d_dense_roll_kernel<7>")}
+                     "roofline": roofline(8.0 * pix, ms, algorithmic_bytes_per_pixel=8, kernel="sg2d_rolling_kernel<7,2,1,true,false>" if a.method == 2 else "sg2d_dense_roll_kernel<7>")}
         if a.method == 2:                                # the rolling kernel's committed counter passes, if taken on these sources
             traffic, src = pmc_traffic(8.0 * pix, "r*_2d_config4_pmc_summary.json", SOURCES_2D)
             res[name]["roofline"]["traffic"] = traffic
@@ -664,7 +664,7 @@ def main():
             per_launch_pix = pix_rank if args.rowband else pix_rank // 3
             out = {"metric": "Mpix/s filtered (2-D, hw=7, order 3)", "value": round(pix_rank * args.steps * world / el / 1e6, 1), "unit": "Mpix/s", **common,
                    "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": "f32", "config": cfg,
-                   "roofline": roofline(8.0 * per_launch_pix, ms, lms, kernel="sg2d_rolling_kernel<7,2,1,true>" if args.method == 2 else "sg2d_dense_roll_kernel<7>")}
+                   "roofline": roofline(8.0 * per_launch_pix, ms, lms, kernel="sg2d_rolling_kernel<7,2,1,true,false>" if args.method == 2 else "sg2d_dense_roll_kernel<7>")}
             if args.method == 2 and not args.rowband:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(8.0 * per_launch_pix, "r*_2d_config4_pmc_summary.json", SOURCES_2D)
             if world == 1 and not args.no_cpu:

@@ -56,7 +56,7 @@ SRC_STREAM = ["sg_stream_roll.hip", "sg_stream.hpp", "sg_pk.hpp"]
 jobs = [("f32", "sg1d_center_moment_kernel<32, 5>", 8.0 * 4096 * (1 << 20), None, "r03_1d_f32_n32_pmc_summary.json", "bench.py --no-cpu --no-extra --steps 2 --warmup 1", "BASELINE config 2: 4096 x 2^20 fp32, n=32, m=4"),
         ("f64", "sg1d_center_kernel<double, 32", 16.0 * 1024 * (1 << 22), None, "r03_1d_f64_n32_pmc_summary.json", "bench.py --workload batch1d_f64 --c5-channels 1024 --no-cpu --steps 2 --warmup 1", "BASELINE config 5 chunk: 1024 x 2^22 fp64, n=32, m=4, d=2"),
         ("stream", "sg_bank_roll_kernel<16, true>", 8.0 * 65536 * 4096, SRC_STREAM, "r03_stream_block_pmc_summary.json", "bench.py --workload stream --no-cpu --no-extra --steps 3 --warmup 1", "BASELINE config 3 block push: 65536 streams x 4096 ticks, n=16, m=2, d=1, SAVGOL_STREAMBANK_FMA"),
-        ("image", "sg2d_rolling_kernel<7, 2, 1, true>", 8.0 * 512 * 4096 * 4096, SRC_2D, "r03_2d_config4_pmc_summary.json", "bench.py --workload image --no-cpu --steps 1 --warmup 1", "BASELINE config 4: 512 x 4096^2 fp32, n=7, order 3 (additive rolling form)")]
+        ("image", "sg2d_rolling_kernel<7, 2, 1, true, false>", 8.0 * 512 * 4096 * 4096, SRC_2D, "r03_2d_config4_pmc_summary.json", "bench.py --workload image --no-cpu --steps 1 --warmup 1", "BASELINE config 4: 512 x 4096^2 fp32, n=7, order 3 (additive rolling form)")]
 for name, kernel, algb, src, out, cmd, wl in jobs:
     if not os.path.isdir(os.path.join(O, name + "_fetch")):
         continue
