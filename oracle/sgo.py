@@ -112,7 +112,7 @@ class Filter:
         else:
             y = np.empty_like(x)
             rc = lib().sgo_apply_batch_f32(_f(self.center), _f(self.edges), self.n, float(self.dt_inv), mode,
-                                           _f(x), _f(y), x.shape[0], x.shape[1], x.shape[1], os.cpu_count() or 1)
+                                           _f(x), _f(y), x.shape[0], x.shape[1], x.shape[1], _threads(x.shape[0]))
         if rc != 0:
             raise ValueError("oracle apply failed (length < window?)")
         return y
@@ -138,10 +138,15 @@ class Filter:
         else:
             rc = lib().sgo_apply_batch_f64(_f(self.center), _f(self.edges), self.n, float(self.dt_inv), mode,
                                            _d(x), _d(y), x.shape[0], x.shape[1], x.shape[1],
-                                           threads or os.cpu_count() or 1)
+                                           threads or _threads(x.shape[0]))
         if rc != 0:
             raise ValueError("oracle apply failed (length < window?)")
         return y
+
+
+def _threads(channels):
+    """one OpenMP thread per channel at most: a 256-thread team for a 5-channel batch costs ~120 ms per call on the GPU box's host"""
+    return max(1, min(os.cpu_count() or 1, int(channels)))
 
 
 class Stream:

@@ -299,15 +299,21 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     const float *d_moment = (want_moment && plan->moment_terms > 0) ? plan->d_moment : nullptr;
     const int moment_terms = d_moment ? plan->moment_terms : 0;
 
+    // the POLYNOMIAL edge rows ride in the same launch: two more items per channel behind the tiles (sg1d_edge_item)
+    if (d_edges) {
+        job.edges = d_edges;
+        if (correct_edge && (f->config.derivative & 1)) job.flags |= sg::JOB_EDGE_NEGATE;
+    }
     // split so that a launch stays below 2^24 blocks of four tiles (sg::MAX_TILES_PER_LAUNCH)
-    const size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / job.tiles_per_channel;
+    const size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / ((size_t)job.tiles_per_channel + 2);
     for (size_t c0 = 0; c0 < channels; c0 += max_ch) {
         const size_t nc = (channels - c0 < max_ch) ? channels - c0 : max_ch;
         job.in = d_in + c0 * in_ld;
         job.out = d_out + c0 * out_ld;
         job.total_tiles = (unsigned)(nc * job.tiles_per_channel);
+        job.edge_items = d_edges ? (unsigned)(2 * nc) : 0u;
         // one tile per wave, four waves per block, blocks dispatched in order (see sg1d_center_kernel)
-        unsigned blocks = (job.total_tiles + 3u) / 4u;
+        unsigned blocks = (job.total_tiles + job.edge_items + 3u) / 4u;
         blocks = (blocks + 7u) & ~7u;                                    // the XCD remap wants a multiple of 8
         if (d_moment) {
             const int rc = moment_terms == 3 ? sg1d_launch_f32_moment_t3(n, &job, d_moment, blocks, st)
@@ -315,13 +321,6 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
                                              : sg1d_launch_f32_moment_t7(n, &job, d_moment, blocks, st);
             if (rc != 0) return -1;
         } else if (sg::launch_center<T>(n, wide, job, taps, blocks, st) != 0) return -1;
-    }
-    if (d_edges) {
-        // bit 0: multiply by dt_inv; bit 1: negate the leading-edge outputs (SAVGOL_HIP_OPT_CORRECT_LEADING_EDGE, odd d only)
-        const int eflags = (job.dt_inv != 1.0f ? 1 : 0) | ((correct_edge && (f->config.derivative & 1)) ? 2 : 0);
-        const int rc = sg::launch_edges<T>(d_in, d_out, (long long)in_ld, (long long)out_ld, (long long)length, n, d_edges,
-                                           job.dt_inv, eflags, channels, st);
-        if (rc != 0) { sg_set_error("%s: edge kernel launch failed", who); return -1; }
     }
     return 0;
 }

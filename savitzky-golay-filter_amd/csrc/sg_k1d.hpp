@@ -245,6 +245,51 @@ struct Conv<double, N, V> {
     }
 };
 
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// POLYNOMIAL edge rows as items of the tile kernels (reference savgolFilter.c:773-784; the arithmetic of sg1d_edges_kernel below,
+// bit for bit: lanes hold taps l and l + 64, one butterfly sum per output).  As a kernel of its own the n outputs of a channel end
+// were n dependent round trips to the edge table -- 14 us at n = 32, a third of a single-signal call (POLYNOMIAL 33.9 us against
+// REFLECT 20.2 for 10^6 samples, profiles/r03_host_time_per_call.txt) -- and a second launch.  Here the half window is a template
+// parameter: all 2n table loads are issued up front, and the item runs beside the channel's tiles.
+template <typename T, int N>
+__device__ __forceinline__ void sg1d_edge_item(const Job1D &job, unsigned item, int lane)
+{
+    constexpr int WS = 2 * N + 1;
+    const long long c = item >> 1;
+    const bool trailing = (item & 1u) != 0;
+    const long long L = job.length;
+    const T *__restrict__ row = static_cast<const T *>(job.in) + c * job.in_ld;
+    T *__restrict__ orow = static_cast<T *>(job.out) + c * job.out_ld;
+    const float *__restrict__ ew = job.edges;
+    const int k0 = lane, k1 = lane + 64;
+    T x0 = T(0), x1 = T(0);
+    if (k0 < WS) x0 = row[trailing ? (L - WS + k0) : (long long)(2 * N - k0)];
+    if (WS > 64 && k1 < WS) x1 = row[trailing ? (L - WS + k1) : (long long)(2 * N - k1)];
+    float w0[N], w1[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        w0[e] = k0 < WS ? ew[e * WS + k0] : 0.0f;
+        w1[e] = (WS > 64 && k1 < WS) ? ew[e * WS + k1] : 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        T p = T(0);
+        if (k0 < WS) p = (T)w0[e] * x0;
+        if (WS > 64 && k1 < WS) p = fma_t((T)w1[e], x1, p);
+        p = wave_sum(p);
+        if (job.flags & JOB_SCALE) p *= (T)job.dt_inv;
+        if ((job.flags & JOB_EDGE_NEGATE) && !trailing) p = -p;
+        if (lane == 0) orow[trailing ? (L - 1 - e) : (long long)e] = p;
+    }
+}
+
 // Work distribution: ONE TILE PER WAVE, blocks dispatched in order (grid = total_tiles / 4).  Round 1 ran a persistent
 // grid (resident waves striding over the tiles, next tile prefetched into registers); measured on MI355X that shape caps a
 // read+write stream at 5.2-5.5 TB/s, while the same tiles handed out by the hardware dispatcher in block order stream at
@@ -269,7 +314,10 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
     unsigned blk = blockIdx.x;
     if (blk < nb8 * 8u) blk = (blk & 7u) * nb8 + (blk >> 3);
     const unsigned tile = blk * K::WAVES + wave;
-    if (tile >= job.total_tiles) return;                                  // wave-uniform
+    if (tile >= job.total_tiles) {                                        // wave-uniform: past the tiles come the edge items, if any
+        if (tile - job.total_tiles < job.edge_items) sg1d_edge_item<T, N>(job, tile - job.total_tiles, lane);
+        return;
+    }
 
     const T *__restrict__ gin  = static_cast<const T *>(job.in);
     T *__restrict__       gout = static_cast<T *>(job.out);
@@ -499,14 +547,6 @@ __global__ __launch_bounds__(256, (K1D<float, N, SG_VPL_NARROW>::MIN_WAVES)) voi
 //                                                                    odd-derivative sign quirk included)
 //   trailing: out[L-1-e]   = s * sum_k ew[e][k] * in[L - ws + k]
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
 template <typename T>
 __global__ __launch_bounds__(64) void sg1d_edges_kernel(const T *__restrict__ in, T *__restrict__ out,
                                                         long long in_ld, long long out_ld, long long L,

@@ -73,6 +73,10 @@ struct Job1D {
     unsigned    out_shift;              // ... at out[c*out_ld + g - out_shift]
     float       dt_inv;
     unsigned    flags;                  // FLAG_* below; boundary mode in the low byte
+    // POLYNOMIAL edge rows ride along as extra items behind the tiles (sg1d_edge_item): item 2c = leading end of channel c,
+    // 2c + 1 = trailing end; edges = the filter's [n][2n+1] edge table on the device, NULL = none
+    unsigned    edge_items;
+    const float *edges;
 };
 // The fused strided (array-of-structs) kernel, sg1d_strided_kernel<N> (reference savgol_apply_strided, src/savgolFilter.c:877-934):
 // sample i of channel c is the float at in + c * in_pitch + i * in_stride (bytes; the field offset is folded into `in`), all
@@ -129,6 +133,7 @@ enum : unsigned {
     JOB_VEC_IN     = 1u << 9,           // input rows are 16-B aligned
     JOB_VEC_OUT    = 1u << 10,          // output rows (after out_shift) are 16-B aligned
     JOB_ODD_TAPS   = 1u << 11,          // fp64: taps.wd holds taps 0..n, tap 2n-k = -tap k (odd derivative) instead of +tap k
+    JOB_EDGE_NEGATE = 1u << 12,         // edge items: negate the leading-edge outputs (SAVGOL_BATCH_CORRECT_LEADING_EDGE, odd derivatives)
 };
 
 }  // namespace sg

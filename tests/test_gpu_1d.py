@@ -662,7 +662,7 @@ def test_fp32_kernels_against_the_reference_s_own_fp32_error(sg, sgo, torch_gpu,
         (test_randomized_configurations_within_the_dot_product_error_bound).
     So: <= max(1e-6, 4 x the reference's own error) everywhere, 1e-6 outright for well-conditioned smoothing, <= 2.5e-6 always."""
     torch = torch_gpu
-    x = torch.empty((3, 30000 + 17 * n), dtype=torch.float32, device="cuda")         # (the sweep behind the docstring's numbers: 5 x 40 000)
+    x = torch.empty((5, 40000 + 17 * n), dtype=torch.float32, device="cuda")
     sg.synth(x, channel0=3 * n)
     xh = x.cpu().numpy()
     xmax = float(np.max(np.abs(xh)))
