@@ -689,23 +689,20 @@ int savgol_apply_strided_batch_f32_ex(const SavgolFilter *filter, const void *d_
         job.flags = ((unsigned)mode & sg::JOB_MODE_MASK);
         if (mode < 0 || mode > 255) job.flags = 255u;
         if (job.dt_inv != 1.0f) job.flags |= sg::JOB_SCALE;
-        const size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / job.tiles_per_channel;
+        if (poly) {                                                      // the edge rows ride in the same launch (sg1d_edge_item)
+            job.edges = plan->d_edges;
+            if ((flags & SAVGOL_BATCH_CORRECT_LEADING_EDGE) && (filter->config.derivative & 1)) job.flags |= sg::JOB_EDGE_NEGATE;
+        }
+        const size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / ((size_t)job.tiles_per_channel + 2);
         for (size_t c0 = 0; c0 < channels; c0 += max_ch) {
             const size_t nc = (channels - c0 < max_ch) ? channels - c0 : max_ch;
             job.in = reinterpret_cast<const char *>(ia) + c0 * in_channel_pitch;
             job.out = reinterpret_cast<char *>(oa) + c0 * out_channel_pitch;
             job.total_tiles = (unsigned)(nc * job.tiles_per_channel);
-            unsigned blocks = (job.total_tiles + 3u) / 4u;
+            job.edge_items = poly ? (unsigned)(2 * nc) : 0u;
+            unsigned blocks = (job.total_tiles + job.edge_items + 3u) / 4u;
             blocks = (blocks + 7u) & ~7u;
             if (sg::launch_strided(n, job, plan->taps32, blocks, st) != 0) return -1;
-        }
-        if (poly) {
-            const int eflags = (job.dt_inv != 1.0f ? 1 : 0) | (((flags & SAVGOL_BATCH_CORRECT_LEADING_EDGE) && (filter->config.derivative & 1)) ? 2 : 0);
-            if (sg1d_launch_edges_strided_f32(reinterpret_cast<const void *>(ia), reinterpret_cast<void *>(oa), (long long)in_channel_pitch, (long long)out_channel_pitch,
-                                              (long long)in_stride, (long long)out_stride, (long long)count, n, plan->d_edges, job.dt_inv, eflags, channels, st) != 0) {
-                sg_set_error("%s: edge kernel launch failed", who);
-                return -1;
-            }
         }
         return 0;
     }

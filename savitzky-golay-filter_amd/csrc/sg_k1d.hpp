@@ -4,7 +4,7 @@
 // Reference loop replaced: savgol_apply centre loop, src/savgolFilter.c:763-766 (+ the index
 // remaps of get_padded_sample :442-482 for the non-polynomial boundary modes, + savgol_apply_valid
 // :843-847 through the store window).  The POLYNOMIAL edge rows are a separate tiny kernel
-// (sg1d_edges_kernel below; reference :773-784).
+// (sg1d_edge_item below, extra items of the same launch; reference :773-784).
 //
 // Mapping (one 64-lane wave = one tile, waves never talk to each other, no s_barrier):
 //   * a tile is 64*R consecutive outputs of one channel, R = 128 B / sizeof(T) (32 fp32, 16 fp64);
@@ -253,25 +253,25 @@ __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
-// POLYNOMIAL edge rows as items of the tile kernels (reference savgolFilter.c:773-784; the arithmetic of sg1d_edges_kernel below,
-// bit for bit: lanes hold taps l and l + 64, one butterfly sum per output).  As a kernel of its own the n outputs of a channel end
-// were n dependent round trips to the edge table -- 14 us at n = 32, a third of a single-signal call (POLYNOMIAL 33.9 us against
-// REFLECT 20.2 for 10^6 samples, profiles/r03_host_time_per_call.txt) -- and a second launch.  Here the half window is a template
-// parameter: all 2n table loads are issued up front, and the item runs beside the channel's tiles.
-template <typename T, int N>
-__device__ __forceinline__ void sg1d_edge_item(const Job1D &job, unsigned item, int lane)
+// POLYNOMIAL edge rows (reference savgolFilter.c:773-784) as items of the tile kernels: for each channel end n outputs, each its
+// own 2n+1-tap row of edge_weights.  One wave per (channel, end); lanes hold the taps (lane l: taps l and l + 64), the dot
+// product is a wavefront butterfly sum.
+//   leading : out[e]       = s * sum_k ew[e][k] * in[2n - k]        (reversed data: the reference's odd-derivative sign quirk
+//                                                                    included; JOB_EDGE_NEGATE is the opt-in fix)
+//   trailing: out[L-1-e]   = s * sum_k ew[e][k] * in[L - ws + k]
+// Rounds 1-2 ran this as a kernel of its own (same arithmetic, bit for bit): the n outputs of a channel end were n dependent
+// round trips to the edge table -- 14 us at n = 32, a third of a single-signal call (POLYNOMIAL 33.9 us against REFLECT 20.2 for
+// 10^6 samples, profiles/r03_host_time_per_call.txt) -- and a second launch.  Here the half window is a template parameter: all
+// 2n table loads are issued up front, and the item runs beside the channel's tiles.
+template <typename T, int N, typename Load, typename Store>
+__device__ __forceinline__ void sg1d_edge_rows(const float *__restrict__ ew, unsigned flags, float dt_inv, bool trailing, long long L, int lane,
+                                               Load sample, Store put)
 {
     constexpr int WS = 2 * N + 1;
-    const long long c = item >> 1;
-    const bool trailing = (item & 1u) != 0;
-    const long long L = job.length;
-    const T *__restrict__ row = static_cast<const T *>(job.in) + c * job.in_ld;
-    T *__restrict__ orow = static_cast<T *>(job.out) + c * job.out_ld;
-    const float *__restrict__ ew = job.edges;
     const int k0 = lane, k1 = lane + 64;
     T x0 = T(0), x1 = T(0);
-    if (k0 < WS) x0 = row[trailing ? (L - WS + k0) : (long long)(2 * N - k0)];
-    if (WS > 64 && k1 < WS) x1 = row[trailing ? (L - WS + k1) : (long long)(2 * N - k1)];
+    if (k0 < WS) x0 = sample(trailing ? (L - WS + k0) : (long long)(2 * N - k0));
+    if (WS > 64 && k1 < WS) x1 = sample(trailing ? (L - WS + k1) : (long long)(2 * N - k1));
     float w0[N], w1[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) {
@@ -284,10 +284,32 @@ __device__ __forceinline__ void sg1d_edge_item(const Job1D &job, unsigned item, 
         if (k0 < WS) p = (T)w0[e] * x0;
         if (WS > 64 && k1 < WS) p = fma_t((T)w1[e], x1, p);
         p = wave_sum(p);
-        if (job.flags & JOB_SCALE) p *= (T)job.dt_inv;
-        if ((job.flags & JOB_EDGE_NEGATE) && !trailing) p = -p;
-        if (lane == 0) orow[trailing ? (L - 1 - e) : (long long)e] = p;
+        if (flags & JOB_SCALE) p *= (T)dt_inv;
+        if ((flags & JOB_EDGE_NEGATE) && !trailing) p = -p;
+        if (lane == 0) put(trailing ? (L - 1 - e) : (long long)e, p);
     }
+}
+
+// item 2c = leading end of channel c, 2c + 1 = its trailing end
+template <typename T, int N>
+__device__ __forceinline__ void sg1d_edge_item(const Job1D &job, unsigned item, int lane)
+{
+    const long long c = item >> 1;
+    const T *__restrict__ row = static_cast<const T *>(job.in) + c * job.in_ld;
+    T *__restrict__ orow = static_cast<T *>(job.out) + c * job.out_ld;
+    sg1d_edge_rows<T, N>(job.edges, job.flags, job.dt_inv, (item & 1u) != 0, (long long)job.length, lane,
+                         [&](long long i) { return row[i]; }, [&](long long i, T v) { orow[i] = v; });
+}
+// the same on array-of-structs data (always the edges of a strided call: the reference's savgol_apply_strided ignores config.boundary, :902-928)
+template <int N>
+__device__ __forceinline__ void sg1d_edge_item(const JobStrided &job, unsigned item, int lane)
+{
+    const long long c = item >> 1;
+    const char *__restrict__ row = job.in + c * job.in_pitch;
+    char *__restrict__ orow = job.out + c * job.out_pitch;
+    sg1d_edge_rows<float, N>(job.edges, job.flags, job.dt_inv, (item & 1u) != 0, (long long)job.length, lane,
+                             [&](long long i) { return *reinterpret_cast<const float *>(row + i * job.in_stride); },
+                             [&](long long i, float v) { *reinterpret_cast<float *>(orow + i * job.out_stride) = v; });
 }
 
 // Work distribution: ONE TILE PER WAVE, blocks dispatched in order (grid = total_tiles / 4).  Round 1 ran a persistent
@@ -470,7 +492,10 @@ __global__ __launch_bounds__(256, (K1D<float, N, SG_VPL_NARROW>::MIN_WAVES)) voi
     unsigned blk = blockIdx.x;
     if (blk < nb8 * 8u) blk = (blk & 7u) * nb8 + (blk >> 3);
     const unsigned tile = blk * K::WAVES + wave;
-    if (tile >= job.total_tiles) return;                                  // wave-uniform
+    if (tile >= job.total_tiles) {                                        // wave-uniform: past the tiles come the edge items
+        if (tile - job.total_tiles < job.edge_items) sg1d_edge_item<N>(job, tile - job.total_tiles, lane);
+        return;
+    }
     const int L = (int)job.length;
     const int mode = (int)(job.flags & JOB_MODE_MASK);
     const unsigned c = job.tpc_shift >= 32 ? tile : (__umulhi(tile, job.tpc_magic) >> job.tpc_shift);
@@ -536,44 +561,6 @@ __global__ __launch_bounds__(256, (K1D<float, N, SG_VPL_NARROW>::MIN_WAVES)) voi
             const int g = ts + lane + 64 * k;
             if (g >= lo && g < hi) *reinterpret_cast<float *>(q + (long long)(64 * k) * job.out_stride) = *reinterpret_cast<const float *>(mine + k * KSTEP);
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// POLYNOMIAL edge rows (reference savgolFilter.c:773-784): for each channel end, n outputs, each
-// its own 2n+1-tap row of edge_weights.  One wave per (channel, end); lanes hold the taps
-// (lane l: taps l and l+64), the dot product is a wavefront butterfly reduction.
-//   leading : out[e]       = s * sum_k ew[e][k] * in[2n - k]        (reversed data: the reference's
-//                                                                    odd-derivative sign quirk included)
-//   trailing: out[L-1-e]   = s * sum_k ew[e][k] * in[L - ws + k]
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(64) void sg1d_edges_kernel(const T *__restrict__ in, T *__restrict__ out,
-                                                        long long in_ld, long long out_ld, long long L,
-                                                        int n, const float *__restrict__ ew,
-                                                        float dt_inv, int flags)
-{
-    const int lane = threadIdx.x;
-    const long long c = blockIdx.x;
-    const bool trailing = blockIdx.y != 0;
-    const int ws = 2 * n + 1;
-    const T *row = in + c * in_ld;
-    T *orow = out + c * out_ld;
-
-    const int k0 = lane, k1 = lane + 64;
-    T x0 = T(0), x1 = T(0);
-    if (k0 < ws) x0 = row[trailing ? (L - ws + k0) : (long long)(2 * n - k0)];
-    if (k1 < ws) x1 = row[trailing ? (L - ws + k1) : (long long)(2 * n - k1)];
-
-    for (int e = 0; e < n; ++e) {
-        const float *w = ew + e * ws;
-        T p = T(0);
-        if (k0 < ws) p = (T)w[k0] * x0;
-        if (k1 < ws) p = fma_t((T)w[k1], x1, p);
-        p = wave_sum(p);
-        if (flags & 1) p *= (T)dt_inv;
-        if ((flags & 2) && !trailing) p = -p;           // opt-in sign fix of the reference's reversed leading edge (odd derivatives)
-        if (lane == 0) orow[trailing ? (L - 1 - e) : (long long)e] = p;
     }
 }
 

@@ -91,7 +91,9 @@ struct JobStrided {
     unsigned    tiles_per_channel, total_tiles, tpc_magic, tpc_shift;
     unsigned    store_lo, store_hi;     // sample indices whose result is stored
     float       dt_inv;
-    unsigned    flags;                  // boundary mode in the low byte, JOB_SCALE
+    unsigned    flags;                  // boundary mode in the low byte, JOB_SCALE, JOB_EDGE_NEGATE
+    unsigned    edge_items;             // as in Job1D
+    const float *edges;
 };
 // Division by an invariant on the scalar unit (gfx950 has s_mul_hi_u32 but no scalar divide; left as `/` the compiler
 // runs the float-reciprocal sequence on the VECTOR unit, ~25 instructions per tile in a kernel that is VALU-issue bound).
@@ -149,8 +151,6 @@ int sg1d_launch_strided_f32_g0(int n, const sg::JobStrided *job, const sg::Taps 
 int sg1d_launch_strided_f32_g1(int n, const sg::JobStrided *job, const sg::Taps *taps, unsigned grid, void *stream);
 int sg1d_launch_strided_f32_g2(int n, const sg::JobStrided *job, const sg::Taps *taps, unsigned grid, void *stream);
 int sg1d_launch_strided_f32_g3(int n, const sg::JobStrided *job, const sg::Taps *taps, unsigned grid, void *stream);
-int sg1d_launch_edges_strided_f32(const void *in, void *out, long long in_pitch, long long out_pitch, long long in_stride, long long out_stride,
-                                  long long L, int n, const float *d_edges, float dt_inv, int flags, size_t channels, void *st);
 int sg1d_launch_f64_g0(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
 int sg1d_launch_f64_g1(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
 int sg1d_launch_f64_g2(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
@@ -165,10 +165,6 @@ int sg1d_launch_f32_moment_t7(int n, const sg::Job1D *job, const float *d_table,
 // (sg_k1d_moment_fit.cpp)
 int sg1d_moment_prepare(int n, const float *center_weights, float *table);
 
-int sg1d_launch_edges_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
-                          const float *d_edges, float dt_inv, int apply_scale, size_t channels, void *st);
-int sg1d_launch_edges_f64(const double *in, double *out, long long in_ld, long long out_ld, long long L, int n,
-                          const float *d_edges, float dt_inv, int apply_scale, size_t channels, void *st);
 int sg1d_launch_reference_order_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
                                     const float *d_table, float dt_inv, int mode, int store_lo, int store_hi, int out_shift,
                                     int negate_leading, size_t channels, void *stream);
@@ -213,18 +209,5 @@ inline int launch_strided(int n, const JobStrided &job, const Taps &taps, unsign
     return 0;
 }
 
-template <typename T>
-int launch_edges(const T *in, T *out, long long in_ld, long long out_ld, long long L, int n, const float *d_edges,
-                 float dt_inv, int apply_scale, size_t channels, hipStream_t st);
-template <> inline int launch_edges<float>(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
-                                           const float *d_edges, float dt_inv, int apply_scale, size_t channels, hipStream_t st)
-{
-    return sg1d_launch_edges_f32(in, out, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale, channels, st);
-}
-template <> inline int launch_edges<double>(const double *in, double *out, long long in_ld, long long out_ld, long long L, int n,
-                                            const float *d_edges, float dt_inv, int apply_scale, size_t channels, hipStream_t st)
-{
-    return sg1d_launch_edges_f64(in, out, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale, channels, st);
-}
 
 }  // namespace sg

@@ -24,36 +24,6 @@ __global__ __launch_bounds__(256) void sg_gather_f32_kernel(const char *__restri
     }
 }
 
-// the POLYNOMIAL edge rows of sg1d_edges_kernel (sg_k1d.hpp) on strided data (always the edges of a strided call: the reference's
-// savgol_apply_strided ignores config.boundary, :902-928)
-__global__ __launch_bounds__(64) void sg1d_edges_strided_kernel(const char *__restrict__ in, char *__restrict__ out, long long in_pitch,
-                                                                long long out_pitch, long long in_stride, long long out_stride,
-                                                                long long L, int n, const float *__restrict__ ew, float dt_inv, int flags)
-{
-    const int lane = threadIdx.x;
-    const long long c = blockIdx.x;
-    const bool trailing = blockIdx.y != 0;
-    const int ws = 2 * n + 1;
-    const char *row = in + c * in_pitch;
-    char *orow = out + c * out_pitch;
-    auto sample = [&](long long i) { return *reinterpret_cast<const float *>(row + i * in_stride); };
-    const int k0 = lane, k1 = lane + 64;
-    float x0 = 0.0f, x1 = 0.0f;
-    if (k0 < ws) x0 = sample(trailing ? (L - ws + k0) : (long long)(2 * n - k0));
-    if (k1 < ws) x1 = sample(trailing ? (L - ws + k1) : (long long)(2 * n - k1));
-    for (int e = 0; e < n; ++e) {
-        const float *w = ew + e * ws;
-        float p = 0.0f;
-        if (k0 < ws) p = w[k0] * x0;
-        if (k1 < ws) p = __builtin_fmaf(w[k1], x1, p);
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) p += __shfl_xor(p, m, 64);
-        if (flags & 1) p *= dt_inv;
-        if ((flags & 2) && !trailing) p = -p;
-        if (lane == 0) *reinterpret_cast<float *>(orow + (trailing ? (L - 1 - e) : (long long)e) * out_stride) = p;
-    }
-}
-
 __global__ __launch_bounds__(256) void sg_scatter_f32_kernel(const float *__restrict__ src, size_t src_ld,
                                                              char *__restrict__ base, size_t stride, size_t offset,
                                                              size_t pitch, size_t count)
@@ -320,20 +290,6 @@ struct SmallService {
 };
 
 template <typename T>
-static int enqueue_edges(const T *in, T *out, long long in_ld, long long out_ld, long long L, int n,
-                        const float *d_edges, float dt_inv, int apply_scale, size_t channels, hipStream_t st)
-{
-    size_t done = 0;
-    while (done < channels) {                       // gridDim.x limit
-        const size_t chunk = (channels - done) < 1048576 ? (channels - done) : 1048576;
-        hipLaunchKernelGGL((sg1d_edges_kernel<T>), dim3((unsigned)chunk, 2), dim3(64), 0, st,
-                           in + done * in_ld, out + done * out_ld, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale);
-        done += chunk;
-    }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
-template <typename T>
 static int enqueue_synth(T *dst, size_t channel0, size_t channels, size_t length, size_t ld, uint64_t seed, hipStream_t st)
 {
     unsigned gx = (unsigned)((length + 255) / 256);
@@ -492,20 +448,6 @@ extern "C" int sg_small_stream_rows(void *ctx_v, const float *d_table, const flo
 
 extern "C" {
 
-int sg1d_launch_edges_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
-                          const float *d_edges, float dt_inv, int apply_scale, size_t channels, void *st)
-{
-    return sg::enqueue_edges<float>(in, out, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale, channels,
-                                   static_cast<hipStream_t>(st));
-}
-
-int sg1d_launch_edges_f64(const double *in, double *out, long long in_ld, long long out_ld, long long L, int n,
-                          const float *d_edges, float dt_inv, int apply_scale, size_t channels, void *st)
-{
-    return sg::enqueue_edges<double>(in, out, in_ld, out_ld, L, n, d_edges, dt_inv, apply_scale, channels,
-                                    static_cast<hipStream_t>(st));
-}
-
 int sg1d_launch_reference_order_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
                                     const float *d_table, float dt_inv, int mode, int store_lo, int store_hi, int out_shift,
                                     int negate_leading, size_t channels, void *stream)
@@ -523,18 +465,6 @@ int sg1d_launch_reference_order_f32(const float *in, float *out, long long in_ld
                            in + done * in_ld, out + done * out_ld, in_ld, out_ld, (int)L, n, d_table, dt_inv, mode, store_lo, store_hi,
                            out_shift, negate_leading, wide);
         done += chunk;
-    }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
-int sg1d_launch_edges_strided_f32(const void *in, void *out, long long in_pitch, long long out_pitch, long long in_stride, long long out_stride,
-                                  long long L, int n, const float *d_edges, float dt_inv, int flags, size_t channels, void *st)
-{
-    for (size_t done = 0; done < channels; done += 1048576) {
-        const size_t chunk = (channels - done) < 1048576 ? (channels - done) : 1048576;
-        hipLaunchKernelGGL(sg::sg1d_edges_strided_kernel, dim3((unsigned)chunk, 2), dim3(64), 0, static_cast<hipStream_t>(st),
-                           static_cast<const char *>(in) + (long long)done * in_pitch, static_cast<char *>(out) + (long long)done * out_pitch, in_pitch, out_pitch,
-                           in_stride, out_stride, L, n, d_edges, dt_inv, flags);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
