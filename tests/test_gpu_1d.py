@@ -952,3 +952,62 @@ def test_small_call_service_is_bit_identical_and_survives_idling(sg, sgo, torch_
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def _length_split_signal(channels, length):
+    t = np.arange(length)
+    return (np.sin(0.02 * t)[None, :] * (1 + np.arange(channels))[:, None] + np.random.default_rng(91).normal(0, 0.1, (channels, length))).astype(np.float32)
+
+
+def _length_split_worker(rank, world, port, channels, length, n, out_dir):
+    import os as _os
+    import sys as _sys
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch as _torch
+    import torch.distributed as _dist
+    _dist.init_process_group("gloo", rank=rank, world_size=world)
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    from __graft_entry__ import load_package
+    import importlib
+    sgm = load_package()
+    lengthsplit = importlib.import_module("savgol_amd.lengthsplit")
+    _torch.cuda.set_device(0)
+    x = _length_split_signal(channels, length)
+    seg = lengthsplit.LengthSplit(length, n)
+    local = _torch.from_numpy(x[:, seg.lo:seg.hi].copy()).cuda()
+    for mode in range(4):
+        f = sgm.Filter(n, 4, 1, 0.5, mode)
+        for tag, flags in (("ref", sgm.SAVGOL_BATCH_REFERENCE_SUMMATION), ("fma", 0)):
+            ext = seg.exchange(local.cpu(), periodic=(mode == 2)).cuda()          # gloo carries host tensors
+            own = seg.apply(ext, lambda t: f.apply_tensor(t.contiguous(), flags=flags), lambda t: f.apply_tensor(t.contiguous(), valid=True, flags=flags),
+                            periodic=(mode == 2))
+            _torch.cuda.synchronize()
+            np.save(_os.path.join(out_dir, f"{tag}{mode}_r{rank}.npy"), own.cpu().numpy())
+    _dist.barrier()
+    _dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [5, 32])
+def test_length_split_two_ranks_sharing_the_gpu(sg, sgo, torch_gpu, tmp_path, n):
+    """lengthsplit.LengthSplit with the real kernels as the per-segment filter and two real ranks (gloo carries the n-sample halos; both
+    ranks use this box's one GPU): the stitched segments equal the unsplit call bit for bit in the reference's summation order -- all
+    four boundary modes, PERIODIC through the ring wrap -- and the fp64 oracle to 2e-6 on the default (FMA / block-moment) kernels."""
+    import socket
+    import torch.multiprocessing as mp
+    torch = torch_gpu
+    channels, length, world = 3, 20011, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_length_split_worker, args=(world, port, channels, length, n, str(tmp_path)), nprocs=world, join=True)
+    xh = _length_split_signal(channels, length)
+    x = torch.from_numpy(xh).cuda()
+    for mode in range(4):
+        f = sg.Filter(n, 4, 1, 0.5, mode)
+        whole = f.apply_tensor(x, flags=sg.SAVGOL_BATCH_REFERENCE_SUMMATION).cpu().numpy()
+        got = np.concatenate([np.load(tmp_path / f"ref{mode}_r{r}.npy") for r in range(world)], axis=1)
+        assert np.array_equal(got.view(np.uint32), whole.view(np.uint32)), mode
+        assert np.array_equal(whole.view(np.uint32), sgo.Filter(n, 4, 1, 0.5, mode).apply(xh).view(np.uint32)), mode
+        ref64 = sgo.Filter(n, 4, 1, 0.5, mode).apply_f64(xh.astype(np.float64))
+        fma = np.concatenate([np.load(tmp_path / f"fma{mode}_r{r}.npy") for r in range(world)], axis=1)
+        assert normwise(fma, ref64) < TOL_F32_DERIV, (mode, normwise(fma, ref64))
