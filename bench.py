@@ -8,7 +8,7 @@ with the HBM-roofline fraction of the dominant kernel and the reference's CPU pa
     python bench.py --workload batch1d_f64 | stream | image [--rowband]      the other BASELINE configs as the main line
 
 A step = one pass of savgol_apply_batch_f32 over the whole resident batch in EACH of the four boundary
-modes (4 launches of the centre kernel + the tiny polynomial edge kernel).  Inputs are generated in HBM
+modes (4 launches of the centre kernel; the POLYNOMIAL one carries its edge rows as extra items).  Inputs are generated in HBM
 before the timed region.  Channels are independent: with N GPUs every rank owns its own 4096 channels
 (weak scaling, no data-path collective); rank 0 prints one JSON line.  At N = 1 that line also carries, under
 "extra", BASELINE configs 1, 3, 4 and the per-GPU slice of config 5, each with its own roofline and CPU baseline
