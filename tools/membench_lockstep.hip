@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -32,12 +33,14 @@ __global__ __launch_bounds__(256) void k_flat(const v4f *__restrict__ in, v4f *_
     if (i < nvec) __builtin_nontemporal_store(__builtin_bit_cast(u4, in[i]), (u4 *)(out + i));
 }
 
+__device__ int g_pitch_dev;                                          // 0 = the frame width; set by main() for the pitch experiment
 // WPB waves per block, side by side: the block covers 256*WPB columns.  An item = (frame, column group, band of rows).  P rows in
 // flight per wave.  BAR > 0: __syncthreads() every BAR rows.  XCD: 1 = blocks that share an XCD take neighbouring items.
 template <int P, int WPB, int BAR>
-__global__ __launch_bounds__(64 * WPB) void k_rows(const float *__restrict__ in, float *__restrict__ out, int cols, int rows, int band_rows,
+__global__ __launch_bounds__(64 * WPB) void k_rows(const float *__restrict__ in, float *__restrict__ out, int cols_, int rows, int band_rows,
                                                     unsigned groups, unsigned bands, unsigned total, int xcd)
 {
+    const int cols = g_pitch_dev ? g_pitch_dev : cols_;              // row pitch in floats (frames are rows x pitch)
     extern __shared__ float occupancy_pad[];                        // dynamic LDS only limits how many blocks a CU holds
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned nblk = gridDim.x;
@@ -104,9 +107,28 @@ static void run(unsigned bands, int blocks_per_cu, int xcd)
     fflush(stdout);
 }
 
-int main()
+int main(int argc, char **argv)
 {
     CK(hipEventCreate(&ev_a)); CK(hipEventCreate(&ev_b));
+    if (argc > 1 && !strcmp(argv[1], "pitch")) {
+        // Is it the power-of-two row pitch?  A wave's rows in flight are 16 KiB apart: the same L1 / L2 sets.  Same walk, same 4096 columns
+        // copied, frames laid out with a longer pitch.
+        const int pitches[] = {4096, 4128, 4160, 4224, 4352, 4608, 5120};
+        const size_t big = (size_t)kFrames * 5120 * kRows * 4;
+        CK(hipMalloc(&g_in, big)); CK(hipMalloc(&g_out, big));
+        hipLaunchKernelGGL(k_init, dim3(8192), dim3(256), 0, 0, (v4f *)g_in, big / 16);
+        hipLaunchKernelGGL(k_init, dim3(8192), dim3(256), 0, 0, (v4f *)g_out, big / 16);
+        CK(hipDeviceSynchronize());
+        for (int p : pitches) {
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pitch_dev), &p, sizeof(int)));
+            printf("-- row pitch %d floats (%d bytes)\n", p, p * 4);
+            run<4, 4, 0>(16, 3, 0);
+            run<4, 4, 0>(16, 0, 0);
+            run<8, 4, 0>(16, 1, 0);
+            run<8, 16, 8>(16, 1, 0);
+        }
+        return 0;
+    }
     const size_t bytes = (size_t)kFrames * kCols * kRows * 4;
     CK(hipMalloc(&g_in, bytes)); CK(hipMalloc(&g_out, bytes));
     hipLaunchKernelGGL(k_init, dim3(8192), dim3(256), 0, 0, (v4f *)g_in, bytes / 16);
