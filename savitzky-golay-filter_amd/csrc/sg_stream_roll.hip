@@ -28,10 +28,17 @@ namespace sg {
 template <int N>
 struct SRoll {
     static constexpr int WS = 2 * N + 1;
-#ifndef SG_SROLL_P
-#define SG_SROLL_P 3
+    // rows loaded ahead of the arithmetic (A/B builds override).  Round 3, after the counters had said that a walk is short of
+    // requests in flight rather than of memory (profiles/r03_strip_walk_counters.txt): the sample-ring kernels (n <= 16) with 7 rows
+    // ahead -- and, for the fused-multiply-add bank, at most TWO resident blocks per CU (8 waves; launch_bank_roll) -- run config 3's
+    // block push in 0.389 ms instead of 0.404-0.417 (0.69 of the roofline; n = 4: 0.378 vs 0.407), the reference-order bank 0.451-0.460
+    // instead of 0.467-0.469 at its full occupancy (it is bound by its two instructions per tap and needs the waves).  The
+    // accumulator-ring kernels (n > 16) lose with either change (n = 24 FMA: 0.551 -> 0.67 / 0.88 ms) and keep 3 rows, 4 blocks.
+#ifdef SG_SROLL_P
+    static constexpr int P = SG_SROLL_P;
+#else
+    static constexpr int P = N <= 16 ? 7 : 3;
 #endif
-    static constexpr int P = SG_SROLL_P;                     // rows loaded ahead of the arithmetic (A/B builds override)
     static constexpr int U = WS + P;                         // ring slots = unroll factor of the tick loop
     static constexpr int NP = N + 1;                         // SGPR pairs holding taps 0..2N
 };
@@ -222,6 +229,8 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg_bank_roll_kernel<N, FMA>, 256, 0) != hipSuccess || nb < 1) nb = 2;
         per_cu = nb > 4 ? 4 : nb;
+        if (FMA && N <= 16 && per_cu > 2) per_cu = 2;        // fewer waves, more rows in flight each (see SRoll::P)
+        if (const char *e = getenv("SAVGOL_HIP_STREAM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 4 && v <= nb) per_cu = v; }      // A/B runs
     }
     const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
     job.strips = (unsigned)((job.streams + 127) / 128);
