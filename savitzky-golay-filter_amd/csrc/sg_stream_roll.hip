@@ -33,7 +33,7 @@ struct SRoll {
     // ahead -- and, for the fused-multiply-add bank, at most TWO resident blocks per CU (8 waves; launch_bank_roll) -- run config 3's
     // block push in 0.389 ms instead of 0.404-0.417 (0.69 of the roofline; n = 4: 0.378 vs 0.407), the reference-order bank 0.451-0.460
     // instead of 0.467-0.469 at its full occupancy (it is bound by its two instructions per tap and needs the waves).  The
-    // accumulator-ring kernels (n > 16) lose with either change (n = 24 FMA: 0.551 -> 0.67 / 0.88 ms) and keep 3 rows, 4 blocks.
+    // accumulator-ring kernels (n > 16) have their own ring of rows in flight (bank_accroll_item) and keep 4 blocks per CU.
 #ifdef SG_SROLL_P
     static constexpr int P = SG_SROLL_P;
 #else
@@ -146,15 +146,29 @@ __device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRol
     f32x2 acc[R::WS];                                        // acc[a], a = 1..2N; garbage until a real output reaches it
 #pragma unroll
     for (int a = 0; a < R::WS; ++a) acc[a] = f32x2{0.0f, 0.0f};
-    f32x2 ahead[R::P];
+    // rows in flight: a ring of PA registers that the row loop, unrolled PA times, indexes with literals.  (Until late in round 3
+    // this was `ahead[p] = ahead[p + 1]` in a loop that was not unrolled: a register MOVE of a row still in flight has to wait for it,
+    // so every iteration ended in s_waitcnt vmcnt(0) and nothing was ever ahead -- which is why these kernels lost to the sample
+    // ring by 30-45 % and why more rows "ahead" made them slower.)
+    // The loop is unrolled UA rows deep (hipcc drains every memory operation at the back edge: once per UA rows).
+    // (ring depth x resident blocks swept in tools/r3/exp32.sh: four rows at full occupancy; eight from n = 28, +7 % at n = 32)
+#ifdef SG_SROLL_PA
+    constexpr int PA = SG_SROLL_PA, UA = N <= 24 ? 16 : 8;
+#else
+    constexpr int PA = N >= 28 ? 8 : 4, UA = N <= 24 ? 16 : 8;
+#endif
+    static_assert(UA % PA == 0, "slot = row % PA must carry over from one group of UA rows to the next");
+    f32x2 ahead[PA];
 #pragma unroll
-    for (int p = 0; p < R::P; ++p) ahead[p] = load_row(p);
+    for (int p = 0; p < PA; ++p) ahead[p] = load_row(p);
     const int nrows = nt + 2 * N;
-    for (int r = 0; r < nrows; ++r) {
-        const f32x2 x = ahead[0];
-#pragma unroll
-        for (int p = 0; p + 1 < R::P; ++p) ahead[p] = ahead[p + 1];
-        ahead[R::P - 1] = load_row(r + R::P);
+    for (int r0 = 0; r0 < nrows; r0 += UA) {
+      static_for<UA>([&](auto uc) -> bool {
+        constexpr int u = decltype(uc)::value;
+        const int r = r0 + u;
+        if (r >= nrows) return false;                        // uniform
+        const f32x2 x = ahead[u % PA];
+        ahead[u % PA] = load_row(r + PA);
         // volatile asm, products and adds alike: left to the compiler the adds sink to the end of the iteration and all
         // 2N+1 products stay live (see sg_2d_dense.hip)
         f32x2 done;
@@ -189,6 +203,8 @@ __device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRol
             if constexpr (VEC) *reinterpret_cast<f32x2 *>(orow + s0) = y;
             else { if (live0) orow[s0] = y.x; if (live1) orow[s0 + 1] = y.y; }
         }
+        return true;
+      });
     }
 }
 
