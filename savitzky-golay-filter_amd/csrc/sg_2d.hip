@@ -6,7 +6,7 @@
 // mirror then clamp (REFLECT) (:428-445); VALID writes only the interior of a same-size frame (:410-414).
 //
 // Method 1 = the dense window in the SAME summation order and rounding as the reference -> bit-identical outputs:
-// sg_2d_dense.hip for square windows with half window <= 8 (packed math, input-row stationary), otherwise
+// sg_2d_dense.hip for square windows (packed math, input-row stationary), otherwise
 // sg2d_direct_kernel below (LDS tile + halo, one pixel per lane; 225 taps at n=7 make it VALU/LDS bound).
 // Kernels 2 and 3 (method 2 / auto): W is exactly low rank, W(x,y) = sum_t G_t(y) Q_t(x) with r <= 4 terms, so the
 // frame is filtered as r column passes and r row passes: 2 r (2n+1) FMAs per pixel instead of (2n+1)^2, back in

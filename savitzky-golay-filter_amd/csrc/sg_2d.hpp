@@ -123,7 +123,7 @@ inline int sg2d_launch_rolling3(int n, int terms, const Job2D &job, const float 
 
 // sg_2d_dense.hip: the bit-exact dense kernel on packed math, square windows with half window <= DENSE_ROLL_MAX_N.
 // 0 = launched, 1 = not covered (the caller uses sg2d_direct_kernel of sg_2d.hip), -1 = error.  h_w = the kernel on the host.
-constexpr int DENSE_ROLL_MAX_N = 8;
+constexpr int DENSE_ROLL_MAX_N = 16;
 struct DeviceCtx;
 int sg2d_launch_dense_rolling(const Job2D &job, const float *h_w, DeviceCtx *ctx, unsigned images, hipStream_t st);
 

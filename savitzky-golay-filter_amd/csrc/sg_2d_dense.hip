@@ -1,4 +1,4 @@
-// sg_2d_dense.hip -- the bit-exact 2-D path for square windows with half window <= 8, on packed math.
+// sg_2d_dense.hip -- the bit-exact 2-D path for square windows (every half window 1..16), on packed math.
 //
 // Reference arithmetic (src/savgol2d.c:374-393, :417-453): one fp32 accumulator per output pixel, the window walked
 // row-major (wy outer, wx inner), `sum += W[wy][wx] * in[..]` with multiply and add rounded separately, then * scale.
