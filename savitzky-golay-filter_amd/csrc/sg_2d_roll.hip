@@ -32,7 +32,10 @@
 
 namespace sg {
 
-template <int N, bool ACC = false>
+// TR > 0: TILE form (round 4).  The item is TR output rows; ALL its TR + 2N input rows are loaded up front (P = TR - 1 rows "ahead"),
+// the row loop runs once over literal slots and the wave exits: short-lived waves handed out in address order, the 1-D kernel's life
+// cycle.  The 2N halo rows are read again by the tile below -- out of L2 when blocks that share an XCD take neighbouring tiles.
+template <int N, bool ACC = false, int TR = 0>
 struct Roll {
     // halo lanes on each side of a strip: ceil(N/4) are needed; more where that buys whole memory lines.  A strip stores
     // 1024 - 32*HL bytes per row starting 16*HL bytes into its loaded KiB: with HL = 1 (3) the stores of neighbouring strips meet
@@ -55,9 +58,9 @@ struct Roll {
     // (accumulating passes, n >= 9: the output rows they add to are prefetched through a ring of four slots, which wants U to be a
     //  multiple of four: P = 5 at odd half windows)
 #ifdef SG_ROLL_P
-    static constexpr int P = SG_ROLL_P;
+    static constexpr int P = TR > 0 ? TR - 1 : SG_ROLL_P;
 #else
-    static constexpr int P = (ACC && (N & 1) && N < 15) ? 5 : (N >= 6 ? 3 : 1);
+    static constexpr int P = TR > 0 ? TR - 1 : ((ACC && (N & 1) && N < 15) ? 5 : (N >= 6 ? 3 : 1));
 #endif
     static constexpr int U = 2 * N + 1 + P;                 // ring slots = unroll factor of the row loop
     // branch-free row loop (buffer stores whose range check replaces the `if`, whole groups of U rows without an exit test).
@@ -66,9 +69,9 @@ struct Roll {
     // is as fast or faster at every half window (n=7: 1.96 vs 2.04 ms, n=12: 2.87 vs 3.04), so it is off; the macro keeps the
     // variant buildable for the next compiler.
 #ifdef SG_ROLL_STRAIGHT
-    static constexpr bool STRAIGHT = SG_ROLL_STRAIGHT != 0;
+    static constexpr bool STRAIGHT = TR > 0 || SG_ROLL_STRAIGHT != 0;
 #else
-    static constexpr bool STRAIGHT = false;
+    static constexpr bool STRAIGHT = TR > 0;                // a tile's waits must stay counted: 2N + TR loads are in flight when its first row starts
 #endif
     static constexpr int BUFW = 256 + 8 * HL;               // LDS floats per term row (strip + pad both sides)
     static constexpr int NP = N / 2 + 1;                    // SGPR pairs holding taps 0..N
@@ -138,12 +141,13 @@ __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
 //
 // ACC (NOUT = 1): the result is ADDED to what the output frame holds -- the second launch of a kernel whose terms do not fit one
 // (taps live in SGPRs: 4 terms at n >= 9, 3 at n >= 13).  The stored row's previous content is loaded one row step ahead.
-template <int N, int NT, int NOUT, bool VEC, bool BOX, bool ACC>
+template <int N, int NT, int NOUT, bool VEC, bool BOX, bool ACC, int TR = 0>
 __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *mine, const float *in, float *const (&outs)[NOUT],
                                           int xload, int yb, int nout, int lane, int xlo, int xhi, int ylo, int yhi)
 {
-    typedef Roll<N, ACC> R;
+    typedef Roll<N, ACC, TR> R;
     static_assert(!BOX || (NT == 2 && NOUT == 1), "the additive form is one output of two terms");
+    static_assert(TR == 0 || !ACC, "tiles are plain passes");
     static_assert(!ACC || (NOUT == 1 && !BOX && !R::STRAIGHT), "accumulating passes are single-output launches of the general form");
     static_assert(R::U % 2 == 0, "the LDS row alternates with the ring slot: U must be even");
     const int c0 = xload + 4 * lane;                         // this lane's first column (frame coordinates)
@@ -404,6 +408,21 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 #pragma unroll
         for (int j = 0; j < LEAD; ++j) prevq[j] = load_prev(yb + j);
     }
+    if constexpr (TR > 0) {
+        // the tile: every row is in flight already.  Step uu = vertical pass of row uu + 1, horizontal pass + store of row uu; rows past
+        // the frame (nout < TR) are computed from clamped re-reads and dropped by the store's descriptor.  No branch in here.
+        static_for(std::make_integer_sequence<int, TR>{}, [&](auto uuc) -> bool {
+            constexpr int uu = decltype(uuc)::value;
+            wave_lds_sync();
+            if constexpr (NB == 2) fetch(std::integral_constant<int, 0>{}, uu & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (uu + 1 < TR) vertical(std::integral_constant<int, uu + 1>{}, (uu + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            finish_row(uu & 1, yb + uu, f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+            return true;
+        });
+        return;
+    }
     // Iteration m runs the vertical pass of row m and the horizontal pass + store of row m-1.  Whole groups of U iterations, no
     // early exit: the iterations past the band (at most U-1, their loads clamped to real rows) compute rows nobody stores.  An
     // exit test per row would be a branch per row, with the same cost to the wait counts as a branch around the store.
@@ -439,6 +458,19 @@ constexpr int roll_min_waves(int, int, int) { return SG_ROLL_MINWAVES; }
 constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt >= 3 && n >= 6) || n == 7 || n == 8 || (n == 6 && nt == 2 && nout == 2) || (nout == 3 && n >= 5) ? 3 : 4); }
 #endif
 
+// TILE form: output rows per tile (0 = this half window keeps the strip walk) and the waves per SIMD its registers must allow.
+// tools/membench_tile2d.hip (profiles/r04_membench_tile2d.txt): the bare tile pattern moves 0.71-0.72 of the roofline at full
+// occupancy whatever the tile height (8 ... 32 rows) and MORE on fewer resident waves (8 per CU: 0.757, 4 per CU: 0.775; the flat copy
+// 0.80) -- so the row registers of a 16-row tile (30 rows x 4 VGPRs) cost nothing that matters.
+#ifndef SG_ROLL_TILE_ROWS
+#define SG_ROLL_TILE_ROWS 16
+#endif
+constexpr int roll_tile_rows(int n, int nt, int nout, bool box) { return (box && nt == 2 && nout == 1 && n >= 5 && n <= 8) ? SG_ROLL_TILE_ROWS : 0; }
+#ifndef SG_ROLL_TILE_WAVES
+#define SG_ROLL_TILE_WAVES 2
+#endif
+constexpr int roll_tile_waves(int) { return SG_ROLL_TILE_WAVES; }
+
 // waves per block: the waves of a block walk neighbouring strips row for row, so a block's loads of one row step are one
 // contiguous run of the frame row
 #ifndef SG_ROLL_WPB
@@ -446,8 +478,8 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #endif
 constexpr int roll_wpb(int n) { (void)n; return SG_ROLL_WPB; }
 
-template <int N, int NT, int NOUT, bool BOX, bool ACC>
-__global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1, float *const out2,
+template <int N, int NT, int NOUT, bool BOX, bool ACC, int TR = 0>
+__global__ __launch_bounds__(64 * roll_wpb(N), TR > 0 ? roll_tile_waves(N) : roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1, float *const out2,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
     typedef Roll<N> R;
@@ -484,9 +516,9 @@ __global__ __launch_bounds__(64 * roll_wpb(N), roll_min_waves(N, NT, NOUT)) void
         const int sx = (int)strip * R::SW;
         // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
         if ((aligned & 3) == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
-            roll_item<N, NT, NOUT, true, BOX, ACC>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+            roll_item<N, NT, NOUT, true, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
         else
-            roll_item<N, NT, NOUT, false, BOX, ACC>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+            roll_item<N, NT, NOUT, false, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
     }
 }
 
@@ -579,7 +611,7 @@ static int roll_box_env()                                   // SAVGOL_HIP_ROLL_B
     static const int v = [] { const char *e = getenv("SAVGOL_HIP_ROLL_BOX"); return e ? atoi(e) : 1; }();
     return v;
 }
-template <int N, int NT, int NOUT, bool BOX, bool ACC = false>
+template <int N, int NT, int NOUT, bool BOX, bool ACC = false, int TR = 0>
 static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *out1, float *out2, unsigned images, int cu_count, hipStream_t st)
 {
     typedef Roll<N> R;
@@ -596,7 +628,7 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
     const size_t lds = sizeof(float) * WPB * 2 * NOUT * NT * R::BUFW;
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC>, 64 * WPB, lds) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC, TR>, 64 * WPB, lds) != hipSuccess || nb < 1)
             nb = WPB <= 8 ? 2 : 1;
         per_cu = nb > (int)(16 / WPB) ? (int)(16 / WPB) : nb;
     }
@@ -618,6 +650,7 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
         // the additive form re-seeds its rolling column sums every U rows of a band: bands that start on multiples of U keep that
         // phase tied to the FRAME row, so a frame's bits do not depend on how many frames share the launch (the band count does)
         if (BOX) band_rows = (band_rows + R::U - 1) / R::U * R::U;
+        if (TR > 0) band_rows = TR;                          // tiles: TR rows each, whatever the batch (the re-seed phase is the tile's first row)
         bands = (unsigned)((job.rows + band_rows - 1) / band_rows);
         per_image = (unsigned long long)strips * bands;
     };
@@ -629,13 +662,13 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
     for (unsigned long long i0 = 0; i0 < images; i0 += img_step) {
         const unsigned long long ni = images - i0 < img_step ? images - i0 : img_step;
         const unsigned long long total = ni * per_image;
-        unsigned grid = persistent ? (unsigned)cu_count * (unsigned)per_cu : (unsigned)((total + WPB - 1) / WPB);
+        unsigned grid = (persistent && TR == 0) ? (unsigned)cu_count * (unsigned)per_cu : (unsigned)((total + WPB - 1) / WPB);
         if ((unsigned long long)grid * WPB > total) grid = (unsigned)((total + WPB - 1) / WPB);
         grid = (grid + 7u) & ~7u;
         Job2D part = job;
         part.in = job.in + (long long)i0 * job.in_pitch;
         part.out = job.out + (long long)i0 * job.out_pitch;
-        hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC>), dim3(grid), dim3(64 * WPB), lds, st, part, taps,
+        hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC, TR>), dim3(grid), dim3(64 * WPB), lds, st, part, taps,
                            out1 ? out1 + (long long)i0 * job.out_pitch : nullptr, out2 ? out2 + (long long)i0 * job.out_pitch : nullptr, strips, bands,
                            band_rows, (unsigned)total, aligned);
     }
@@ -658,8 +691,15 @@ static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], co
     if constexpr (NT == 2 && NOUT == 1) {
         RollTaps<N, 2, 1> box;
         memset(&box, 0, sizeof(box));
-        if (roll_box_env() != 0 && fill_box_taps<N>(box, factors[0], scale[0]))
+        if (roll_box_env() != 0 && fill_box_taps<N>(box, factors[0], scale[0])) {
+            constexpr int TR = roll_tile_rows(N, 2, 1, true);
+            if constexpr (TR > 0) {
+                // SAVGOL_HIP_ROLL_TILE=0: the strip walk of rounds 1-3 (A/B runs)
+                static const int tile_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_TILE"); return e ? atoi(e) : 1; }();
+                if (tile_env != 0) return launch_roll_kernel<N, 2, 1, true, false, TR>(job, box, out1, out2, images, cu_count, st);
+            }
             return launch_roll_kernel<N, 2, 1, true>(job, box, out1, out2, images, cu_count, st);
+        }
     }
     RollTaps<N, NT, NOUT> taps;
     memset(&taps, 0, sizeof(taps));
