@@ -141,7 +141,15 @@ __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
 //
 // ACC (NOUT = 1): the result is ADDED to what the output frame holds -- the second launch of a kernel whose terms do not fit one
 // (taps live in SGPRs: 4 terms at n >= 9, 3 at n >= 13).  The stored row's previous content is loaded one row step ahead.
-template <int N, int NT, int NOUT, bool VEC, bool BOX, bool ACC, int TR = 0>
+// MODE: 0 = remapped scalar loads and masked scalar stores (any frame); 1 = the strip's 256 columns are inside the frame and every stored
+// quad is whole (one dwordx4 load and store per lane and row); 2, 3 = round 4, tile form only: a strip that reaches over the LEFT / RIGHT
+// frame edge on vector loads too.  A lane's quad of columns is either inside the frame or outside it (16-byte aligned rows, cols % 4 == 0);
+// a lane outside loads the quad its columns map to (reference src/savgol2d.c:428-445: REFLECT = the mirrored quad, reversed; CONSTANT =
+// the frame's first / last quad, its edge float broadcast) and fixes the order with selects -- 8 v_cndmask per row, no scalar loads, no
+// branch.  2: padded modes, stored quads are whole.  3: VALID, where the stored range starts and ends inside a quad: four range-checked
+// dword stores per row for the lanes that hold such a quad.  (The edge strips on the scalar path cost the tile form 13 %:
+// profiles/r04_2d_tile_experiments.txt.)
+template <int N, int NT, int NOUT, int MODE, bool BOX, bool ACC, int TR = 0>
 __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *mine, const float *in, float *const (&outs)[NOUT],
                                           int xload, int yb, int nout, int lane, int xlo, int xhi, int ylo, int yhi)
 {
@@ -150,7 +158,23 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     static_assert(TR == 0 || !ACC, "tiles are plain passes");
     static_assert(!ACC || (NOUT == 1 && !BOX && !R::STRAIGHT), "accumulating passes are single-output launches of the general form");
     static_assert(R::U % 2 == 0, "the LDS row alternates with the ring slot: U must be even");
+    constexpr bool VEC = MODE != 0, EDGE = MODE >= 2, PARTIAL = MODE == 3;
+    static_assert(!EDGE || R::STRAIGHT, "edge strips on vector loads store through the range-checked descriptor");
     const int c0 = xload + 4 * lane;                         // this lane's first column (frame coordinates)
+    int qcol = c0;                                           // EDGE: the in-frame quad this lane loads ...
+    bool fx_w = false, fx_x = false, fx_rev = false, fx_b = false;      // ... and how its floats are permuted
+    if constexpr (EDGE) {
+        const bool left = c0 < 0, right = c0 >= job.cols;
+        if (job.boundary == SAVGOL2D_BOUNDARY_REFLECT) {
+            qcol = left ? -c0 - 4 : (right ? 2 * job.cols - c0 - 4 : c0);
+            fx_rev = left || right;
+        } else if (job.boundary == SAVGOL2D_BOUNDARY_CONSTANT) {
+            fx_b = left || right;
+        }
+        qcol = qcol < 0 ? 0 : (qcol > job.cols - 4 ? job.cols - 4 : qcol);      // CONSTANT, VALID, and lanes further out than anything stored needs
+        fx_w = fx_rev || (fx_b && right);                    // .x comes from .w (mirrored, or the frame's last float broadcast)
+        fx_x = fx_rev || (fx_b && left);                     // .w comes from .x
+    }
     int ix0 = 0, ix1 = 0, ix2 = 0, ix3 = 0;
     if constexpr (!VEC) {
         ix0 = fix_index(c0, job.cols, job.boundary); ix1 = fix_index(c0 + 1, job.cols, job.boundary);
@@ -162,7 +186,11 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
 #ifdef SG_ROLL_NT_LOADS                                           // A/B builds: streaming loads (the strip's halo columns then miss L2 for the neighbour)
         if constexpr (VEC) return __builtin_bit_cast(f32x4, __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(row + c0)));
 #else
-        if constexpr (VEC) return *reinterpret_cast<const f32x4 *>(row + c0);
+        if constexpr (EDGE) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(row + qcol);
+            const float nx = fx_w ? q.w : q.x, nw = fx_x ? q.x : q.w;          // a broadcast lane has nx == nw == the edge float
+            return f32x4{nx, fx_b ? nx : (fx_rev ? q.z : q.y), fx_b ? nx : (fx_rev ? q.y : q.z), nw};
+        } else if constexpr (VEC) return *reinterpret_cast<const f32x4 *>(row + c0);
 #endif
         else return f32x4{row[ix0], row[ix1], row[ix2], row[ix3]};
     };
@@ -170,7 +198,21 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     const int yend = yb + nout;                              // first frame row past this band
     __amdgpu_buffer_rsrc_t rsrc[NOUT];                       // VEC stores go through a buffer descriptor per output frame (range-checked)
     const __amdgpu_buffer_rsrc_t rsrc_none = __builtin_amdgcn_make_buffer_rsrc(outs[0], 0, 0, 0x00020000);     // zero records: drops every store
-    const unsigned col_off = out_lane ? (unsigned)(c0 * 4) : 0x80000000u;
+    // EDGE: a lane stores its quad when all of it lies in the stored range; PARTIAL: the floats of a quad that straddles the range's end
+    const bool whole = !EDGE || (c0 >= xlo && c0 + 4 <= xhi);
+    const unsigned col_off = (out_lane && whole) ? (unsigned)(c0 * 4) : 0x80000000u;
+    // (their dword stores go through a per-row descriptor that spans exactly the row's stored range [xlo, xhi): the hardware range check
+    //  drops the floats outside it, so one offset register serves all four)
+    //  (one register per float all the same, each laundered: left to see that the four offsets are consecutive, hipcc merges the four
+    //   dword stores into ONE dwordx4 store, whose range check then passes or fails as a whole -- the frame's border got written)
+    unsigned pcol_off[4] = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
+    if constexpr (PARTIAL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (out_lane && !whole) pcol_off[j] = (unsigned)((c0 - xlo + j) * 4);
+            asm volatile("" : "+v"(pcol_off[j]));
+        }
+    }
     if constexpr (VEC && R::STRAIGHT) {
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
@@ -365,6 +407,14 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             const bool keep_row = yo >= ylo && yo < yhi && yo < yend;                     // uniform
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{r[0].x, r[0].y, r[1].x, r[1].y}), keep_row ? rsrc[o] : rsrc_none,
                                                    (int)(col_off + (unsigned)(yo * job.out_stride * 4)), 0, 2 /* nt */);
+            if constexpr (PARTIAL) {
+                const float v[4] = {r[0].x, r[0].y, r[1].x, r[1].y};
+                const __amdgpu_buffer_rsrc_t prow = __builtin_amdgcn_make_buffer_rsrc(outs[o] + (long long)yo * job.out_stride + xlo, 0,
+                                                                                      keep_row ? (xhi - xlo) * 4 : 0, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), prow, (int)pcol_off[j], 0, 0);
+            }
         } else if (yo >= ylo && yo < yhi && yo < yend) {     // uniform
             float *orow = outs[o] + (long long)yo * job.out_stride;
             if constexpr (VEC) {
@@ -465,9 +515,9 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #ifndef SG_ROLL_TILE_ROWS
 #define SG_ROLL_TILE_ROWS 16
 #endif
-constexpr int roll_tile_rows(int n, int nt, int nout, bool box) { return (box && nt == 2 && nout == 1 && n >= 5 && n <= 8) ? SG_ROLL_TILE_ROWS : 0; }
+constexpr int roll_tile_rows(int n, int nt, int nout, bool box) { return (box && nt == 2 && nout == 1 && n >= 5 && n <= 7) ? SG_ROLL_TILE_ROWS : 0; }
 #ifndef SG_ROLL_TILE_WAVES
-#define SG_ROLL_TILE_WAVES 2
+#define SG_ROLL_TILE_WAVES 3
 #endif
 constexpr int roll_tile_waves(int) { return SG_ROLL_TILE_WAVES; }
 
@@ -476,10 +526,15 @@ constexpr int roll_tile_waves(int) { return SG_ROLL_TILE_WAVES; }
 #ifndef SG_ROLL_WPB
 #define SG_ROLL_WPB 4
 #endif
-constexpr int roll_wpb(int n) { (void)n; return SG_ROLL_WPB; }
+// (tile form: 2 -- a block retires when its slowest wave does, and 2 of a frame row's 18 strips are edge strips; 64 / 256 frames of
+//  4096^2 at n = 7: 1 wave 1.65 / 6.85 ms, 2 waves 1.61 / 6.58, 4 waves 1.69 / 6.84, 8 waves 2.05 / 7.85)
+#ifndef SG_ROLL_TILE_WPB
+#define SG_ROLL_TILE_WPB 2
+#endif
+constexpr int roll_wpb(int n, int tr = 0) { (void)n; return tr > 0 ? SG_ROLL_TILE_WPB : SG_ROLL_WPB; }
 
 template <int N, int NT, int NOUT, bool BOX, bool ACC, int TR = 0>
-__global__ __launch_bounds__(64 * roll_wpb(N), TR > 0 ? roll_tile_waves(N) : roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1, float *const out2,
+__global__ __launch_bounds__(64 * roll_wpb(N, TR), TR > 0 ? roll_tile_waves(N) : roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1, float *const out2,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
     typedef Roll<N> R;
@@ -492,7 +547,7 @@ __global__ __launch_bounds__(64 * roll_wpb(N), TR > 0 ? roll_tile_waves(N) : rol
     // (blockIdx % 8) take neighbouring items (halo columns meet in L2)
     const unsigned nblk = gridDim.x;
     const unsigned blk = (aligned & 8) ? blockIdx.x : (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);      // bit 3: blocks in launch order (A/B: SAVGOL_HIP_ROLL_XCD=0)
-    constexpr unsigned WPB = (unsigned)roll_wpb(N);
+    constexpr unsigned WPB = (unsigned)roll_wpb(N, TR);
     const unsigned nwaves = nblk * WPB;
 
     const bool valid = job.boundary == SAVGOL2D_BOUNDARY_VALID;
@@ -500,7 +555,8 @@ __global__ __launch_bounds__(64 * roll_wpb(N), TR > 0 ? roll_tile_waves(N) : rol
     const int xlo = valid ? job.nx : 0, xhi = valid ? job.cols - job.nx : job.cols;
     const int ylo = valid ? job.ny : 0, yhi = valid ? job.rows - job.ny : job.rows;
 
-    for (unsigned item = blk * WPB + (unsigned)wv; item < total_items; item += nwaves) {
+    // (tile form: one tile per wave, always -- with no loop nothing of the dispatch stays live across the tile's 170 registers)
+    for (unsigned item = blk * WPB + (unsigned)wv; item < total_items; item += (TR > 0 ? 0xffffffffu - item : nwaves)) {
         const unsigned strip = item % strips, ib = item / strips;
         const unsigned band = ib % bands, img = ib / bands;
 #ifdef SG_ROLL_SKIP_EDGE_STRIPS                                   // timing experiment only (wrong frames): what do the frame-edge strips cost?
@@ -516,9 +572,14 @@ __global__ __launch_bounds__(64 * roll_wpb(N), TR > 0 ? roll_tile_waves(N) : rol
         const int sx = (int)strip * R::SW;
         // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
         if ((aligned & 3) == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
-            roll_item<N, NT, NOUT, true, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
-        else
-            roll_item<N, NT, NOUT, false, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+            roll_item<N, NT, NOUT, 1, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+        else if (TR > 0 && (aligned & 7) == 7) {             // bit 2: cols % 4 == 0 and wide enough for one reflection
+            if constexpr (TR > 0) {
+                if (valid) roll_item<N, NT, NOUT, 3, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+                else roll_item<N, NT, NOUT, 2, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+            }
+        } else
+            roll_item<N, NT, NOUT, 0, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
     }
 }
 
@@ -620,12 +681,27 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
     if (job.out_stride % 4 == 0 && job.out_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.out) & 15u) == 0 &&
         (NOUT < 2 || (reinterpret_cast<uintptr_t>(out1) & 15u) == 0) && (NOUT < 3 || (reinterpret_cast<uintptr_t>(out2) & 15u) == 0) &&
         (long long)job.rows * job.out_stride * 4 < 0x7fffff00ll) aligned |= 2;       // the store descriptor holds a 31-bit byte count
+    static const int edge_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_TILE_EDGE"); return e ? atoi(e) : 1; }();     // 0: edge strips on the scalar path (A/B)
+    if (TR > 0 && edge_env && job.cols % 4 == 0 && job.cols >= 32) aligned |= 4;
     static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_XCD"); return e ? atoi(e) : 1; }();
     if (!xcd_env) aligned |= 8;
     const unsigned strips = (unsigned)((job.cols + R::SW - 1) / R::SW);
     static int per_cu = 0;                                   // resident blocks per CU of this instantiation
-    constexpr unsigned WPB = (unsigned)roll_wpb(N);
-    const size_t lds = sizeof(float) * WPB * 2 * NOUT * NT * R::BUFW;
+    constexpr unsigned WPB = (unsigned)roll_wpb(N, TR);
+    size_t lds = sizeof(float) * WPB * 2 * NOUT * NT * R::BUFW;
+    if (TR > 0) {
+        // resident blocks per CU of the tile form (tuning knob): unused dynamic LDS is what limits them
+        static const int cap = [] { const char *e = getenv("SAVGOL_HIP_ROLL_TILE_CAP"); return e ? atoi(e) : 0; }();
+        if (cap > 0) {
+            const size_t want = (size_t)(160 * 1024 / cap) - 1024;
+            if (want > lds) lds = want;
+            static bool raised = false;
+            if (!raised && lds > 65536) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                raised = true;
+            }
+        }
+    }
     if (per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC, TR>, 64 * WPB, lds) != hipSuccess || nb < 1)
