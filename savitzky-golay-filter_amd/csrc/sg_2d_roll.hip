@@ -515,11 +515,22 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #ifndef SG_ROLL_TILE_ROWS
 #define SG_ROLL_TILE_ROWS 16
 #endif
-constexpr int roll_tile_rows(int n, int nt, int nout, bool box) { return (box && nt == 2 && nout == 1 && n >= 5 && n <= 7) ? SG_ROLL_TILE_ROWS : 0; }
+// the general one- and two-term forms of one output frame run as tiles too (derivative frames, orders 4-5 of small windows): 12-20 % faster
+// than the walk at n = 2 ... 7 with one term, 12-20 % (n <= 5) / 1-5 % (n = 6, 7) with two (profiles/r04_2d_tile_experiments.txt)
+#ifndef SG_ROLL_TILE_GENERAL
+#define SG_ROLL_TILE_GENERAL 1
+#endif
+constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
+{
+    if (box && nt == 2 && nout == 1 && n <= 7) return SG_ROLL_TILE_ROWS;
+    if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt <= 2 && n <= 7) return SG_ROLL_TILE_ROWS;
+    return 0;
+}
 #ifndef SG_ROLL_TILE_WAVES
 #define SG_ROLL_TILE_WAVES 3
 #endif
-constexpr int roll_tile_waves(int) { return SG_ROLL_TILE_WAVES; }
+// (the general two-term form at n = 7 spills 52 bytes at 3 waves per SIMD)
+constexpr int roll_tile_waves(int n, int nt = 2, bool box = true) { return (!box && nt == 2 && n >= 7) ? 2 : SG_ROLL_TILE_WAVES; }
 
 // waves per block: the waves of a block walk neighbouring strips row for row, so a block's loads of one row step are one
 // contiguous run of the frame row
@@ -534,7 +545,7 @@ constexpr int roll_tile_waves(int) { return SG_ROLL_TILE_WAVES; }
 constexpr int roll_wpb(int n, int tr = 0) { (void)n; return tr > 0 ? SG_ROLL_TILE_WPB : SG_ROLL_WPB; }
 
 template <int N, int NT, int NOUT, bool BOX, bool ACC, int TR = 0>
-__global__ __launch_bounds__(64 * roll_wpb(N, TR), TR > 0 ? roll_tile_waves(N) : roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1, float *const out2,
+__global__ __launch_bounds__(64 * roll_wpb(N, TR), TR > 0 ? roll_tile_waves(N, NT, BOX) : roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1, float *const out2,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
     typedef Roll<N> R;
@@ -781,6 +792,11 @@ static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], co
     memset(&taps, 0, sizeof(taps));
     for (int o = 0; o < NOUT; ++o)
         if (!fill_taps<N, NT, NOUT>(taps, o, factors[o], scale[o])) return 1;
+    constexpr int TRG = roll_tile_rows(N, NT, NOUT, false);
+    if constexpr (TRG > 0) {
+        static const int tile_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_TILE"); return e ? atoi(e) : 1; }();
+        if (tile_env != 0) return launch_roll_kernel<N, NT, NOUT, false, false, TRG>(job, taps, out1, out2, images, cu_count, st);
+    }
     return launch_roll_kernel<N, NT, NOUT, false>(job, taps, out1, out2, images, cu_count, st);
 }
 

@@ -221,7 +221,12 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     const int mode = (variant == FULL) ? (int)f->config.boundary : (int)SAVGOL_BOUNDARY_POLYNOMIAL;
     const bool poly = (mode == SAVGOL_BOUNDARY_POLYNOMIAL);
     const bool want_edges = poly && variant != VALID && variant != INTERIOR;
-    const bool want_moment = sizeof(T) == 4 && !reference_order && n >= sg::MOMENT_MIN_N && n <= sg::MOMENT_MAX_N && !(flags & SAVGOL_BATCH_PLAIN_SUMMATION);
+    // Block moments only where they cost no accuracy (round 4, tools/diag_1d_accuracy.py): the block's sum is the largest single term of
+    // an output, so where the filter nulls the signal -- moving averages (poly_order 0, 1) on a tone, second derivatives -- its rounding
+    // shows: 1.5-2.9 x the reference's own fp32 error there, <= 1.3 x for poly_order >= 2 with derivative <= 1 (every half window
+    // 24..32, all boundary modes; the plain three-chain kernel: 0.7-1.3 x everywhere).  Those filters take the plain kernel (8 % slower).
+    const bool moment_safe = f->config.poly_order >= 2 && f->config.derivative <= 1;
+    const bool want_moment = sizeof(T) == 4 && !reference_order && n >= sg::MOMENT_MIN_N && n <= sg::MOMENT_MAX_N && !(flags & SAVGOL_BATCH_PLAIN_SUMMATION) && moment_safe;
     const FilterPlan *plan = plan_get(ctx, f, reference_order ? NEED_REF : ((want_edges ? NEED_EDGES : 0u) | (want_moment ? NEED_MOMENT : 0u)));
     if (!plan) return -1;
 

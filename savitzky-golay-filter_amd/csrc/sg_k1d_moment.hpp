@@ -60,6 +60,9 @@ struct MomentConv {
     typedef MomentArgs Args;
     static constexpr int OFF = K::OFF, LO = moment_lo(N), HI = moment_hi(N), BK = HI - LO, NPB = BK / 2;   // NPB pairs in the block
     static constexpr int WS = 2 * N + 1;
+    // partial sums per output (round 4): the taps applied one by one go to chain (tap index) mod 3, the block's moment terms to
+    // chain (moment index) mod 3, joined once at the end -- Conv<float> in sg_k1d.hpp says why three interleaved chains
+    static constexpr int CH = 3;
     static_assert(N >= MOMENT_MIN_N && N <= MOMENT_MAX_N && K::R == 32 && K::VPL == 8, "32 outputs per lane, 8 vectors per lane");
     static_assert(OFF == moment_off(N) && LO % 2 == 0 && HI % 2 == 0 && BK % 4 == 0 && BK >= 16 && BK <= 32, "block geometry");
     static_assert(LO >= 31 + OFF && HI <= OFF + 2 * N + 1, "the block must lie inside every output's window");
@@ -82,20 +85,23 @@ struct MomentConv {
 
     // the pair (X[I], X[I+1]) reaches accumulator pair J with tap k = I - 2J - OFF (even output from X[I], odd from X[I+1])
     template <int I, int P0, int NPAIRS, int J = 0>
-    static __device__ __forceinline__ void feed(f32x2 (&A)[16], const f32x2 (&W)[NPAIRS], const f32x2 x)
+    static __device__ __forceinline__ void feed(f32x2 (&A)[CH][16], const f32x2 (&W)[NPAIRS], const f32x2 x)
     {
         if constexpr (J < 16) {
             constexpr int k = I - 2 * J - OFF;
             if constexpr (k >= 0 && k <= 2 * N) {
                 static_assert((k >> 1) >= P0 && (k >> 1) - P0 < NPAIRS, "tap outside the loaded range");
-                pk_fma_sgpr<(k & 1)>(A[J], W[(k >> 1) - P0], x);
+                // taps 0 .. CH-1 open their chains (only the head feeds them, and only as whole pairs: needs_zero() below)
+                static_assert(k >= CH || P0 == 0, "the tail never sees taps 0 .. CH-1");
+                if constexpr (k < CH) A[k][J] = pk_mul_sgpr<(k & 1)>(W[(k >> 1) - P0], x);
+                else pk_fma_sgpr<(k & 1)>(A[k % CH][J], W[(k >> 1) - P0], x);
             }
             feed<I, P0, NPAIRS, J + 1>(A, W, x);
         }
     }
     // one sample reaches only one half of every pair: X[I] for the even outputs (HALF 0), X[I+1] for the odd ones (HALF 1)
     template <int I, int HALF, int P0, int NPAIRS>
-    static __device__ __forceinline__ void feed_single(f32x2 (&A)[16], const f32x2 (&W)[NPAIRS], const float x)
+    static __device__ __forceinline__ void feed_single(f32x2 (&A)[CH][16], const f32x2 (&W)[NPAIRS], const float x)
     {
         static_for<16>([&](auto jc) -> bool {
             constexpr int J = decltype(jc)::value;
@@ -103,8 +109,8 @@ struct MomentConv {
             if constexpr (k >= 0 && k <= 2 * N) {
                 static_assert((k >> 1) >= P0 && (k >> 1) - P0 < NPAIRS, "tap outside the loaded range");
                 const float w = (k & 1) ? W[(k >> 1) - P0].y : W[(k >> 1) - P0].x;
-                if constexpr (HALF == 0) A[J].x = __builtin_fmaf(w, x, A[J].x);
-                else                     A[J].y = __builtin_fmaf(w, x, A[J].y);
+                if constexpr (HALF == 0) A[k % CH][J].x = __builtin_fmaf(w, x, A[k % CH][J].x);
+                else                     A[k % CH][J].y = __builtin_fmaf(w, x, A[k % CH][J].y);
             }
             return true;
         });
@@ -115,9 +121,14 @@ struct MomentConv {
     static __device__ __forceinline__ void run(const char *win, const MomentArgs &args, float (&acc)[32], unsigned)
     {
         const float *tab = args.table;
-        f32x2 A[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) A[j] = f32x2{0.0f, 0.0f};
+        // chain c of pair J is opened by the head's whole-pair feed of tap c, sample pair (2J + c + OFF, +1) -- unless that pair reaches the
+        // block (the last one or two pairs): those chains start from zero
+        f32x2 A[CH][16];
+        static_for<CH * 16>([&](auto ic) -> bool {
+            constexpr int c = decltype(ic)::value / 16, J = decltype(ic)::value % 16;
+            if constexpr (2 * J + c + OFF + 1 >= LO) A[c][J] = f32x2{0.0f, 0.0f};
+            return true;
+        });
 
         // ---- 1. head: samples below LO ----
         {
@@ -142,12 +153,39 @@ struct MomentConv {
             if constexpr (LO % 4 == 0) feed_single<LO - 1, 0, 0, HEAD_PAIRS>(A, W, prev.y);
         }
 
-        // ---- 2. moments of the block X[LO..HI): M[s] = (sum over even t, sum over odd t) of phi_s(t) X[LO+t] ----
+        // ---- 2. tail: samples from HI on ----
+        {
+            f32x2 W[TAIL_PAIRS];
+            load_pairs<TAIL_PAIRS>(W, tab + MOMENT_OFF_W + 2 * TAIL_P0, A[0][0]);
+            f32x2 prev = f32x2{0.0f, 0.0f};
+            constexpr int Q0 = (HI - 1) / 4;                                // the vector that holds X[HI-1]
+            static_for<K::WQ - Q0>([&](auto qc) -> bool {
+                constexpr int q = Q0 + decltype(qc)::value;
+                const float4 v = vec(win, q);
+                const f32x2 e0 = {v.x, v.y}, e1 = {v.z, v.w};
+                if constexpr (4 * q == HI) feed_single<4 * q - 1, 1, TAIL_P0, TAIL_PAIRS>(A, W, v.x);       // X[HI] pairs with a block sample
+                if constexpr (4 * q - 1 >= HI && q > Q0) feed<4 * q - 1, TAIL_P0, TAIL_PAIRS>(A, W, pk_straddle(prev, e0));
+                if constexpr (4 * q >= HI) feed<4 * q, TAIL_P0, TAIL_PAIRS>(A, W, e0);
+                if constexpr (4 * q + 2 == HI) feed_single<4 * q + 1, 1, TAIL_P0, TAIL_PAIRS>(A, W, v.z);
+                if constexpr (4 * q + 1 >= HI) feed<4 * q + 1, TAIL_P0, TAIL_PAIRS>(A, W, pk_straddle(e0, e1));
+                if constexpr (4 * q + 2 >= HI) feed<4 * q + 2, TAIL_P0, TAIL_PAIRS>(A, W, e1);
+                prev = e1;
+                return true;
+            });
+        }
+        // ---- 3. the taps applied one by one are done: join their three chains.  The block's share comes LAST and through its own short chain
+        //         (smallest moment first): it is the largest single term of an output that cancels -- the moving average that nulls a tone,
+        //         a derivative -- and every add made AFTER it rounds at its magnitude.  Added early, as rounds 2-3 did, the moment kernels
+        //         were up to 2.8 x the reference's own error where the plain kernel is at 1.0 (tools/diag_1d_accuracy.py). ----
+#pragma unroll
+        for (int j = 0; j < 16; ++j) A[0][j] = (A[0][j] + A[1][j]) + A[2][j];
+
+        // ---- 4. moments of the block X[LO..HI): M[s] = (sum over even t, sum over odd t) of phi_s(t) X[LO+t] ----
         f32x2 M[M1];
         {
             constexpr int NP = M1 > 1 ? (M1 - 1) * 8 : 1;
             f32x2 P[NP];                                                    // P[(s-1)*8 + i] = (phi_s(2i), phi_s(2i+1)), i < NPB/2
-            if constexpr (M1 > 1) load_pairs<NP>(P, tab + MOMENT_OFF_PHI, A[15]);
+            if constexpr (M1 > 1) load_pairs<NP>(P, tab + MOMENT_OFF_PHI, A[0][15]);
             static_for<(HI + 3) / 4 - LO / 4>([&](auto qc) -> bool {
                 constexpr int q = LO / 4 + decltype(qc)::value;
                 const float4 v = vec(win, q);
@@ -174,38 +212,23 @@ struct MomentConv {
             for (int s = 0; s < M1; ++s) M[s].x += M[s].y;
         }
 
-        // ---- 3. the block's share of every output: A[J] += (c_s(2J), c_s(2J+1)) * mu_s ----
+        // ---- 5. the block's share of every output, sum_s (c_s(2J), c_s(2J+1)) * mu_s from the highest moment down, then the join ----
         static_for<M1>([&](auto sc) -> bool {
-            constexpr int s = decltype(sc)::value;
+            constexpr int s = M1 - 1 - decltype(sc)::value;
             f32x2 Cs[16];
             load_pairs<16>(Cs, tab + MOMENT_OFF_C + s * 32, M[s]);
 #pragma unroll
-            for (int J = 0; J < 16; ++J) pk_fma_pair_bcast(A[J], Cs[J], M[s]);
+            for (int J = 0; J < 16; ++J) {
+                if constexpr (s == M1 - 1) {
+                    A[1][J] = f32x2{0.0f, 0.0f};
+                    pk_fma_pair_bcast(A[1][J], Cs[J], M[s]);
+                } else pk_fma_pair_bcast(A[1][J], Cs[J], M[s]);
+            }
             return true;
         });
 
-        // ---- 4. tail: samples from HI on ----
-        {
-            f32x2 W[TAIL_PAIRS];
-            load_pairs<TAIL_PAIRS>(W, tab + MOMENT_OFF_W + 2 * TAIL_P0, A[0]);
-            f32x2 prev = f32x2{0.0f, 0.0f};
-            constexpr int Q0 = (HI - 1) / 4;                                // the vector that holds X[HI-1]
-            static_for<K::WQ - Q0>([&](auto qc) -> bool {
-                constexpr int q = Q0 + decltype(qc)::value;
-                const float4 v = vec(win, q);
-                const f32x2 e0 = {v.x, v.y}, e1 = {v.z, v.w};
-                if constexpr (4 * q == HI) feed_single<4 * q - 1, 1, TAIL_P0, TAIL_PAIRS>(A, W, v.x);       // X[HI] pairs with a block sample
-                if constexpr (4 * q - 1 >= HI && q > Q0) feed<4 * q - 1, TAIL_P0, TAIL_PAIRS>(A, W, pk_straddle(prev, e0));
-                if constexpr (4 * q >= HI) feed<4 * q, TAIL_P0, TAIL_PAIRS>(A, W, e0);
-                if constexpr (4 * q + 2 == HI) feed_single<4 * q + 1, 1, TAIL_P0, TAIL_PAIRS>(A, W, v.z);
-                if constexpr (4 * q + 1 >= HI) feed<4 * q + 1, TAIL_P0, TAIL_PAIRS>(A, W, pk_straddle(e0, e1));
-                if constexpr (4 * q + 2 >= HI) feed<4 * q + 2, TAIL_P0, TAIL_PAIRS>(A, W, e1);
-                prev = e1;
-                return true;
-            });
-        }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { acc[2 * j] = A[j].x; acc[2 * j + 1] = A[j].y; }
+        for (int j = 0; j < 16; ++j) { const f32x2 a = A[0][j] + A[1][j]; acc[2 * j] = a.x; acc[2 * j + 1] = a.y; }
     }
 };
 
