@@ -503,6 +503,9 @@ def main():
     ap.add_argument("--images", type=int, default=512, help="2-D: frames per pass (BASELINE config 4 has 512 = 34 GB in + 34 GB out)")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--method", type=int, default=2, help="2-D: 1 = dense (bit-exact), 2 = separable")
+    ap.add_argument("--exchange", choices=["c", "torch"], default="c", help="--rowband: who moves the halos -- c = savgol2d_rowband_exchange_rccl "
+                    "(lib/libsavgol_hip_rccl.so, the C entry point INTEGRATION.md documents; falls back to torch when RCCL does not load), "
+                    "torch = torch.distributed batch_isend_irecv")
     ap.add_argument("--rowband", action="store_true", help="--workload image: split every frame into one row band per GPU and trade the "
                                                            "ny-row halos with the neighbours (RCCL point to point) instead of sharding whole frames")
     ap.add_argument("--c5-channels", type=int, default=4096, help="config 5: channels per GPU (32768 / 8)")
@@ -619,6 +622,16 @@ def main():
             local_rows = torch.empty((Nimg * rows, size), dtype=torch.float32, device=dev)
             sg.synth(local_rows, channel0=band.lo)
             local_band = local_rows.view(Nimg, rows, size)
+            comm, exchange = None, "none (one rank)"
+            if world > 1:
+                exchange = "torch.distributed batch_isend_irecv"
+                if args.exchange == "c" and backend == "nccl":         # (the gloo test hook puts every rank on ONE device: RCCL refuses that)
+                    rccl = importlib.import_module("savgol_amd.rccl")
+                    if rccl.available() and dev.type == "cuda":
+                        uid = [rccl.unique_id() if rank == 0 else None]
+                        dist.broadcast_object_list(uid, src=0)
+                        comm = rccl.Comm(world, rank, uid[0])
+                        exchange = "savgol2d_rowband_exchange_rccl (C ABI: one pack launch + ncclSend/ncclRecv per neighbour, own stream)"
 
             def apply_fn(frames):
                 k, r, c = frames.shape
@@ -634,7 +647,7 @@ def main():
                 if band.thin:
                     band.apply_overlapped(local_band, apply_fn)
                 else:
-                    band.apply_c(f2, local_band, boundary=1, method=args.method)
+                    band.apply_c(f2, local_band, boundary=1, method=args.method, comm=comm)
                 e1.record()
                 if events is not None:
                     events.append((e0, e1))
@@ -642,7 +655,7 @@ def main():
             pix_rank = Nimg * rows * size
             cfg = {"workload": f"BASELINE config 4 shape, row-band split: {Nimg} frames of {size * world} x {size} fp32, one {rows}-row band per GPU, "
                                f"n=7, order 3, CONSTANT; per step: {n}-row halos to both neighbours (RCCL point to point), band filtered meanwhile, edge strips redone",
-                   "sharding": "row bands, nearest-neighbour halo exchange"}
+                   "sharding": "row bands, nearest-neighbour halo exchange", "exchange": exchange}
         else:
             Nimg = args.images
             x = torch.empty((Nimg * size, size), dtype=torch.float32, device=dev); sg.synth(x, channel0=rank * Nimg * size)

@@ -50,7 +50,12 @@ extern "C" {
 int         savgol_hip_device_count(void);          /* usable HIP devices (0 = none)       */
 int         savgol_hip_set_device(int ordinal);     /* device used by THIS thread's calls  */
 int         savgol_hip_get_device(void);
-int         savgol_hip_synchronize(void *stream);
+int         savgol_hip_synchronize(void *stream);       /* also hands unused scratch back to the driver (savgol_hip_trim_scratch) */
+/* Calls that need a temporary frame (staged strided path, reference-order batches, channel ends of very long channels, row-band strips)
+ * take it from the library's own stream-ordered pool, which keeps up to 256 MiB of freed blocks for the next call
+ * (SAVGOL_HIP_SCRATCH_KEEP_MB).  This returns every unused byte of it to the driver now.  0 / -1. */
+int         savgol_hip_trim_scratch(void);
+size_t      savgol_hip_scratch_reserved(void);          /* bytes the pool holds right now (hipMemPoolAttrReservedMemCurrent) */
 /* Multi-GPU: the path shards by independent units (channels, streams, images) with no data-path collective, so the whole
  * "context" is: one process (or thread) per GPU calls savgol_hip_set_device(local_rank) and filters its own contiguous slice.
  * This returns that slice [*lo, *hi) of `total` units for `rank` of `world_size` (the first total % world_size ranks take

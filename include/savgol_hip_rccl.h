@@ -27,6 +27,23 @@ int savgol2d_rowband_exchange_rccl(void *nccl_comm, int rank, int world_size, co
                                    int in_stride, size_t in_image_pitch, size_t images, int half_win_y, float *d_halo_up,
                                    float *d_halo_down, float *d_send_scratch, void *stream);
 
+/* The same with the two peers named by the caller (-1 = no neighbour on that side) instead of rank - 1 / rank + 1.  When both peers are
+ * the SAME rank -- a ring of two, or a single rank exchanging with itself, which is how tests/test_gpu_rccl_exchange.py executes this on
+ * one GPU -- the frame is a ring: d_halo_up receives the peer's LAST half_win_y rows and d_halo_down its FIRST ones.                    */
+int savgol2d_rowband_exchange_rccl_peers(void *nccl_comm, int peer_up, int peer_down, const float *d_band, int band_rows, int cols,
+                                         int in_stride, size_t in_image_pitch, size_t images, int half_win_y, float *d_halo_up,
+                                         float *d_halo_down, float *d_send_scratch, void *stream);
+
+/* The 1-D length split's exchange (savitzky-golay-filter_amd/lengthsplit.py; reference loop served: src/savgolFilter.c:763-766 on a
+ * channel cut across ranks): every rank owns samples [lo, hi) of every channel -- d_segment = channels rows of `own` samples, ld apart,
+ * elem_bytes 4 (fp32) or 8 (fp64) -- sends its first half_window samples of every channel to peer_prev and its last ones to peer_next
+ * and receives the neighbours' into d_halo_prev / d_halo_next (channels x half_window samples each, contiguous).  -1 = no neighbour;
+ * PERIODIC signals close the ring (rank 0's prev = the last rank), and with two ranks or one both peers are the same rank: d_halo_prev
+ * then receives that peer's LAST samples and d_halo_next its FIRST.  d_send_scratch: 2 x channels x half_window samples.  0 / -1.     */
+int savgol_lengthsplit_exchange_rccl(void *nccl_comm, int peer_prev, int peer_next, const void *d_segment, size_t channels, size_t own,
+                                     size_t ld, int half_window, int elem_bytes, void *d_halo_prev, void *d_halo_next,
+                                     void *d_send_scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

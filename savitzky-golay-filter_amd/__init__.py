@@ -101,6 +101,8 @@ SIGNATURES = {
     "savgol_hip_set_device": (C.c_int, [C.c_int]),
     "savgol_hip_get_device": (C.c_int, []),
     "savgol_hip_synchronize": (C.c_int, [_vp]),
+    "savgol_hip_trim_scratch": (C.c_int, []),
+    "savgol_hip_scratch_reserved": (C.c_size_t, []),
     "savgol_hip_shard_range": (C.c_int, [_sz, C.c_int, C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
     "savgol_hip_last_error": (C.c_char_p, []),
     "savgol_hip_version": (C.c_char_p, []),

@@ -159,11 +159,20 @@ static int dense_kernel_env()
 // input and read-modify-writes the output -- 20 B per pixel instead of 8 -- which these arithmetic-bound shapes can afford: order 6
 // at n = 9 / 12 / 16: 1.83 / 2.25 / 3.15 ms per 16 frames on the tile kernel, two rolling passes 1.5-2 x faster (profiles/
 // r03_sweep_2d_orders.txt).  0 = launched, 1 = not covered.  `n` = the (larger) half window the factors are laid out for.
+// do the byte ranges of two frame batches intersect?
+static bool frames_overlap(const float *a, long long a_pitch, int a_stride, const float *b, long long b_pitch, int b_stride, int rows, int cols, size_t images)
+{
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(a), b0 = reinterpret_cast<uintptr_t>(b);
+    const uintptr_t a1 = a0 + sizeof(float) * ((size_t)(images - 1) * (size_t)a_pitch + (size_t)(rows - 1) * (size_t)a_stride + (size_t)cols);
+    const uintptr_t b1 = b0 + sizeof(float) * ((size_t)(images - 1) * (size_t)b_pitch + (size_t)(rows - 1) * (size_t)b_stride + (size_t)cols);
+    return a0 < b1 && b0 < a1;
+}
+
 static int roll_passes(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
 {
     static const int split_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_SPLIT"); return e ? atoi(e) : 1; }();     // 0: A/B against the tile kernel
     int rc = sg2d_launch_rolling(n, terms, job, factors, scale, images, cu_count, st);
-    if (rc == 0 || n < 9 || terms < 3 || terms > 4 || !split_env) return rc;
+    if (rc != 1 || n < 9 || terms < 3 || terms > 4 || !split_env) return rc;      // split only what is "not covered" (1), never an error (-1)
     // 2 + 2 (or 2 + 1) rather than 3 + 1 where three terms fit: the accumulating pass moves 12 B per pixel and takes ~0.9 ms per 16
     // frames at n = 9 whether it carries one term or two, so it may as well carry two (3 + 1: 1.05 + 0.89 ms, 2 + 2: 0.75 + 0.93)
     const int first = 2;
@@ -192,6 +201,14 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
         return -1;
     }
     if (images == 0) return 0;
+    {   // No 2-D kernel may run in place: every output reads its neighbours' inputs, tiles of one frame run in any order, and the
+        // two-pass form of wide windows re-reads the input after the output has been written.  The reference's loop is no different
+        // (src/savgol2d.c:374-393 reads input rows it has long overwritten).  Refuse instead of returning garbage.
+        if (frames_overlap(d_in, in_pitch, in_stride, d_out, out_pitch, out_stride, rows, cols, images)) {
+            sg_set_error("%s: input and output frames overlap (2-D filtering cannot run in place)", who);
+            return -1;
+        }
+    }
     DeviceCtx *ctx = ctx_get();
     if (!ctx) return -1;
     const float *d_w = ctx_table(ctx, f->weights, sizeof(float) * (size_t)f->window_area, 0x2d000000u + (unsigned)(nx * 64 + ny));
@@ -369,6 +386,11 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
     if (rows <= 0 || cols <= 0 || in_stride < cols || out_stride < cols) { sg_set_error("%s: bad image geometry", who); return -1; }
     if (boundary == SAVGOL2D_BOUNDARY_VALID && (rows - 2 * ny <= 0 || cols - 2 * nx <= 0)) { sg_set_error("%s: image smaller than the window", who); return -1; }
     if (images == 0) return 0;
+    for (int i = 0; i < nspec; ++i)
+        if (specs[i].out && frames_overlap(d_in, (long long)in_pitch, in_stride, specs[i].out, (long long)out_pitch, out_stride, rows, cols, images)) {
+            sg_set_error("%s: input and output frames overlap (2-D filtering cannot run in place)", who);
+            return -1;
+        }
     DeviceCtx *ctx = ctx_get();
     if (!ctx) return -1;
 

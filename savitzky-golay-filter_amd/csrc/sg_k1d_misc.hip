@@ -185,10 +185,22 @@ struct alignas(64) SmallMailbox {
     int L, n, mode, store_lo, store_hi, out_shift, negate;
     float dt_inv;
     int cmd;                                                 // 0 = filter a signal, 1 = leave, 2 = ring rows of one SavgolStream
-    int pad;
+    unsigned check;                                          // mailbox_check() of the other 15 words: a torn line does not pass (round 4)
     unsigned long long seq_b;
 };
 static_assert(sizeof(SmallMailbox) == 64, "one line");
+// The kernel reads the line with four independent 16-byte loads and the host publishes it with a plain memcpy: on the pinned-host
+// path a load of the middle could be served before the host's second store and the load of seq_b after it -- new sequence numbers
+// around the previous call's arguments.  Both sides therefore hash the 15 other words (FNV-1a over dwords); the
+// kernel accepts a line only when the sequence numbers AND the hash match, and simply polls again otherwise.
+__host__ __device__ inline unsigned mailbox_check(const unsigned (&w)[16])
+{
+    unsigned c = 0x811C9DC5u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i != 13) c = (c ^ w[i]) * 0x01000193u;
+    return c;
+}
 struct SmallArgs { const SmallMailbox *bell; const float *in; float *out; unsigned *done; unsigned long long idle_ticks; };
 
 __global__ __launch_bounds__(256) void sg_small_service_kernel(const SmallArgs a)
@@ -209,9 +221,9 @@ __global__ __launch_bounds__(256) void sg_small_service_kernel(const SmallArgs a
                              : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(a.bell) : "memory");
                 const unsigned long long sa = (unsigned long long)q0.x | ((unsigned long long)q0.y << 32);
                 const unsigned long long sb = (unsigned long long)q3.z | ((unsigned long long)q3.w << 32);
-                if (sa == seq && sb == seq) {
+                const unsigned w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                if (sa == seq && sb == seq && mailbox_check(w) == w[13]) {
                     if (threadIdx.x == 0) {
-                        unsigned w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
                         __builtin_memcpy(&cmd, w, 64);
                         leave = cmd.cmd == 1;
                     }
@@ -286,7 +298,11 @@ struct SmallService {
     hipStream_t stream = nullptr;
     bool running = false, broken = false;
     unsigned long long seq = 0;                              // calls posted to the CURRENT kernel instance
-    unsigned idle_us = 2000;
+    // how long the resident workgroup waits for the next call before it leaves.  A device-wide synchronise of the caller (or a hipFree)
+    // in that window waits for it: 150 us by default (round 3: 2 ms), SAVGOL_HIP_SMALL_SERVICE_IDLE_US to change it
+    unsigned idle_us = 150;
+    double backoff_s = 0.0;                                  // after an unanswered call: no attempts before retry_at
+    std::chrono::steady_clock::time_point retry_at{};
 };
 
 template <typename T>
@@ -347,6 +363,16 @@ static SmallService *small_service(DeviceCtx *ctx)
     return s;
 }
 
+static void small_post(SmallService *s, SmallMailbox m, unsigned long long seq)
+{
+    m.seq_a = seq; m.seq_b = seq; m.check = 0;
+    unsigned w[16];
+    memcpy(w, &m, 64);
+    m.check = mailbox_check(w);
+    memcpy(s->bell_host, &m, sizeof(m));
+    _mm_sfence();
+}
+
 static bool small_launch(SmallService *s)
 {
     memset(s->bell_host, 0, sizeof(SmallMailbox));
@@ -373,9 +399,7 @@ static int small_roundtrip(sg::SmallService *s, const void *in_bytes, size_t in_
         memcpy(s->in_host, in_bytes, in_size);
         _mm_sfence();                                                 // the samples are on their way before the doorbell
         const unsigned long long seq = ++s->seq;
-        m.seq_a = seq; m.seq_b = seq;
-        memcpy(s->bell_host, &m, sizeof(m));
-        _mm_sfence();
+        small_post(s, m, seq);
         const auto t0 = std::chrono::steady_clock::now();
         unsigned long spins = 0;
         bool exited = false;
@@ -384,18 +408,22 @@ static int small_roundtrip(sg::SmallService *s, const void *in_bytes, size_t in_
             if (d == (unsigned)seq) break;
             if (d == SMALL_EXITED) { exited = true; break; }
             if ((++spins & 0x3ff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) {
-                // no answer: ask the kernel to leave (it also leaves on its idle time-out), give the service up for this process
-                m.cmd = 1; m.seq_a = m.seq_b = seq + 1;
-                memcpy(s->bell_host, &m, sizeof(m));
-                _mm_sfence();
+                // no answer (a GPU busy with the caller's own long kernels may simply not have scheduled the workgroup yet): ask the
+                // kernel to leave (it also leaves on its idle time-out) and stay away for a while -- 1 s, doubling to 64 s -- instead
+                // of giving the service up for the whole process
+                m.cmd = 1;
+                small_post(s, m, seq + 1);
                 (void)hipStreamSynchronize(s->stream);
                 (void)hipGetLastError();
-                s->running = false; s->broken = true;
+                s->running = false;
+                s->backoff_s = s->backoff_s < 1.0 ? 1.0 : (s->backoff_s < 64.0 ? 2.0 * s->backoff_s : 64.0);
+                s->retry_at = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(s->backoff_s));
                 return 1;
             }
         }
         if (!exited) {
             memcpy(output, s->out_host + out_off, sizeof(float) * out_floats);
+            s->backoff_s = 0.0;
             return 0;
         }
         // the kernel left on its idle time-out before it saw this call: wait for it, start a fresh one, post again
@@ -404,6 +432,23 @@ static int small_roundtrip(sg::SmallService *s, const void *in_bytes, size_t in_
     }
     s->broken = true;
     return 1;
+}
+
+// The library is about to do something device-wide (hipFree / hipMalloc of its arena): tell the resident workgroup to leave and wait
+// for it, instead of sitting out its idle time.  The caller holds ctx->mu.
+extern "C" void sg_small_quiesce(void *ctx_v)
+{
+    using namespace sg;
+    DeviceCtx *ctx = static_cast<DeviceCtx *>(ctx_v);
+    SmallService *s = static_cast<SmallService *>(ctx->small);
+    if (!s || s->broken || !s->running) return;
+    SmallMailbox m;
+    memset(&m, 0, sizeof(m));
+    m.cmd = 1;
+    small_post(s, m, ++s->seq);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipGetLastError();
+    s->running = false;
 }
 
 // savgol_apply / _valid / _strided on a short host signal.  0 = done, 1 = not taken (disabled, too long, unavailable).
@@ -416,7 +461,7 @@ extern "C" int sg_small_call(void *ctx_v, const float *d_table, const float *inp
     // n = 5: 20 vs 23 us; tools/time_host_small.py)
     if (L > SMALL_MAX_SAMPLES || L < 2 * n + 1 || (long long)L * (2 * n + 1) > 65536) return 1;
     SmallService *s = small_service(ctx);
-    if (!s || s->broken) return 1;
+    if (!s || s->broken || (s->backoff_s > 0.0 && std::chrono::steady_clock::now() < s->retry_at)) return 1;
     SmallMailbox m;
     memset(&m, 0, sizeof(m));
     m.table = d_table; m.L = L; m.n = n; m.mode = mode; m.store_lo = store_lo; m.store_hi = store_hi;
@@ -432,7 +477,7 @@ extern "C" int sg_small_stream_rows(void *ctx_v, const float *d_table, const flo
     DeviceCtx *ctx = static_cast<DeviceCtx *>(ctx_v);
     if (count < 1 || count > SAVGOL_MAX_HALF_WINDOW + 1 || ws > SAVGOL_MAX_WINDOW) return 1;
     SmallService *s = small_service(ctx);
-    if (!s || s->broken) return 1;
+    if (!s || s->broken || (s->backoff_s > 0.0 && std::chrono::steady_clock::now() < s->retry_at)) return 1;
     float staged[SAVGOL_MAX_WINDOW + 1 + 2 * (SAVGOL_MAX_HALF_WINDOW + 1)];
     memcpy(staged, ring, sizeof(float) * SAVGOL_MAX_WINDOW);
     int *meta = reinterpret_cast<int *>(staged + SAVGOL_MAX_WINDOW);

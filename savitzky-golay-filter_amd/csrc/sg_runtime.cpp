@@ -86,7 +86,13 @@ void *scratch_alloc(DeviceCtx *ctx, size_t bytes, hipStream_t st, const char *wh
             props.location.id = ctx->ordinal;
             hipMemPool_t pool = nullptr;
             if (!hip_ok(hipMemPoolCreate(&pool, &props), "hipMemPoolCreate")) return nullptr;
-            uint64_t keep = ~0ull;                            // never hand freed blocks back while the process lives
+            // Freed blocks stay in the pool up to this many bytes (re-used by the next call without a trip to the driver); what lies
+            // above is handed back at the next synchronisation of the stream.  Round 3 kept EVERYTHING for the life of the process
+            // (threshold UINT64_MAX): the staged strided path's 2 x channels x ld x 4 bytes -- GiBs -- then stayed invisible to
+            // PyTorch's allocator and to the caller's own hipMalloc.  savgol_hip_trim_scratch() / savgol_hip_synchronize()
+            // return the rest.  SAVGOL_HIP_SCRATCH_KEEP_MB overrides.
+            uint64_t keep = 256ull << 20;
+            if (const char *e = getenv("SAVGOL_HIP_SCRATCH_KEEP_MB")) { const long long v = atoll(e); if (v >= 0) keep = (uint64_t)v << 20; }
             (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
             ctx->pool = pool;
         }
@@ -98,9 +104,22 @@ void *scratch_alloc(DeviceCtx *ctx, size_t bytes, hipStream_t st, const char *wh
 
 bool scratch_free(void *p, hipStream_t st, const char *what) { return hip_ok(hipFreeAsync(p, st), what); }
 
+// hand every unused byte of the scratch pool back to the driver (blocks still owned by queued work stay)
+int scratch_trim(DeviceCtx *ctx)
+{
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (!ctx->pool) return 0;
+    return hip_ok(hipMemPoolTrimTo(static_cast<hipMemPool_t>(ctx->pool), 0), "hipMemPoolTrimTo") ? 0 : -1;
+}
+
+}  // namespace sg
+extern "C" void sg_small_quiesce(void *ctx);                 // sg_k1d_misc.hip
+namespace sg {
+
 void *ctx_arena(DeviceCtx *ctx, size_t bytes)
 {
     if (bytes <= ctx->arena_bytes) return ctx->arena;
+    sg_small_quiesce(ctx);                                    // hipFree / hipMalloc wait for the device: not behind a resident service workgroup
     if (ctx->arena) { (void)hipFree(ctx->arena); ctx->arena = nullptr; ctx->arena_bytes = 0; }
     size_t want = bytes + bytes / 4 + 4096;
     void *p = nullptr;
@@ -165,7 +184,28 @@ int savgol_hip_get_device(void)
 
 int savgol_hip_synchronize(void *stream)
 {
-    return sg::hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize") ? 0 : -1;
+    if (!sg::hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize")) return -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && sg::g_ctx[dev]) (void)sg::scratch_trim(sg::g_ctx[dev]);
+    return 0;
+}
+
+size_t savgol_hip_scratch_reserved(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !sg::g_ctx[dev]) return 0;
+    std::lock_guard<std::recursive_mutex> lock(sg::g_ctx[dev]->mu);
+    uint64_t reserved = 0;
+    if (!sg::g_ctx[dev]->pool || hipMemPoolGetAttribute(static_cast<hipMemPool_t>(sg::g_ctx[dev]->pool), hipMemPoolAttrReservedMemCurrent, &reserved) != hipSuccess) return 0;
+    return (size_t)reserved;
+}
+
+int savgol_hip_trim_scratch(void)
+{
+    int dev = 0;
+    if (!sg::hip_ok(hipGetDevice(&dev), "hipGetDevice")) return -1;
+    if (dev < 0 || dev >= 64 || !sg::g_ctx[dev]) return 0;
+    return sg::scratch_trim(sg::g_ctx[dev]);
 }
 
 int savgol_hip_shard_range(size_t total, int world_size, int rank, size_t *lo, size_t *hi)

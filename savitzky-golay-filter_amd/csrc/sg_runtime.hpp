@@ -70,12 +70,16 @@ void *ctx_arena(DeviceCtx *ctx, size_t bytes);
 void *ctx_pinned(DeviceCtx *ctx, size_t bytes);
 
 // Stream-ordered scratch for the calls that need a temporary frame (strided staging, channel ends of very long channels, row-band
-// strips): allocated and freed in the order of `st`, so such a call only enqueues.  From the library's OWN memory pool with the
-// release threshold at its maximum: the default pool hands freed blocks back to the driver at the next opportunity, and on the
-// legacy NULL stream that was observed (examples/rowband_demo.c, round 3) to pull the memory from under kernels that were still
-// queued -- garbage in the row-band strips unless the caller synchronised around the call.  A retained pool never unmaps.
+// strips): allocated and freed in the order of `st`, so such a call only enqueues.  From the library's OWN memory pool: the DEFAULT
+// pool on the legacy NULL stream hands out memory that queued kernels still use -- tools/repro_null_stream_pool.hip reproduces it
+// (profiles/r04_null_stream_pool_repro.txt: 213 632 wrong words in 400 allocate / fill / consume / free rounds; never on a created
+// stream, never with a private pool at ANY release threshold).  Round 3 had blamed the pool's release and pinned the threshold to
+// UINT64_MAX, which would hide GiBs of peak scratch from the caller's allocator; it is the default pool that is broken, not releasing,
+// so the threshold is 256 MiB now (SAVGOL_HIP_SCRATCH_KEEP_MB) and scratch_trim() / savgol_hip_trim_scratch() /
+// savgol_hip_synchronize() hand back the rest.
 void *scratch_alloc(DeviceCtx *ctx, size_t bytes, hipStream_t st, const char *what);   // nullptr + error text on failure
 bool scratch_free(void *p, hipStream_t st, const char *what);
+int scratch_trim(DeviceCtx *ctx);                 // 0 / -1
 
 bool hip_ok(hipError_t e, const char *what);      // false + error text on failure
 

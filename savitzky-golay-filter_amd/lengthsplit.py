@@ -48,8 +48,10 @@ class LengthSplit:
             return self.n, self.n
         return (self.n if self.rank > 0 else 0), (self.n if self.rank < self.world - 1 else 0)
 
-    def exchange(self, local, periodic=False):
-        """local: [channels, hi-lo] tensor.  Returns [channels, left + own + right]."""
+    def exchange(self, local, periodic=False, comm=None):
+        """local: [channels, hi-lo] tensor.  Returns [channels, left + own + right].
+        comm: an rccl.Comm -- the halos then travel through savgol_lengthsplit_exchange_rccl (csrc/sg_rowband_rccl.hip), enqueued on
+        the current stream; without it through torch.distributed's batch_isend_irecv."""
         channels, own = local.shape
         assert own == self.hi - self.lo
         left, right = self.halos(periodic)
@@ -58,6 +60,17 @@ class LengthSplit:
         if self.world == 1:
             return ext
         prev, nxt = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        if comm is not None:
+            local = local.contiguous()
+            halo_l = torch.empty((channels, self.n), dtype=local.dtype, device=local.device) if left else None
+            halo_r = torch.empty((channels, self.n), dtype=local.dtype, device=local.device) if right else None
+            scratch = torch.empty((2, channels, self.n), dtype=local.dtype, device=local.device)
+            comm.lengthsplit_exchange(local, self.n, halo_l, halo_r, scratch, (prev if left else -1, nxt if right else -1))
+            if left:
+                ext[:, :left] = halo_l
+            if right:
+                ext[:, left + own:] = halo_r
+            return ext
         ops, keep = [], []
         send_l = send_r = None
         if left:                                              # my first n samples go left, the neighbour's last n come from there

@@ -95,23 +95,46 @@ class RowBand:
             r.wait()
         return bufs.get("up"), bufs.get("dn")
 
-    def apply_c(self, filter2d, local, boundary=1, method=0, stream=None):
+    def apply_c(self, filter2d, local, boundary=1, method=0, stream=None, comm=None):
         """The same through the C ABI (csrc/sg_2d_rowband.hip), exchange overlapped with the band: post the halo sends / receives,
         enqueue the band itself (savgol2d_apply_batch_f32: it reads no halo), wait for the halos, then the edge strips
-        (savgol2d_apply_rowband_edges_f32).  `local`: [images, own, cols] fp32 on the GPU."""
+        (savgol2d_apply_rowband_edges_f32).  `local`: [images, own, cols] fp32 on the GPU.
+        comm: an rccl.Comm -- the halos then travel through savgol2d_rowband_exchange_rccl (csrc/sg_rowband_rccl.hip: one pack launch and
+        one ncclSend / ncclRecv pair per neighbour) on a side stream of its own, no torch.distributed call on the data path; without it
+        the exchange is torch.distributed's batch_isend_irecv."""
         from . import lib, last_error, _addr, _stream
         images, own, cols = local.shape
         if self.thin:
             raise ValueError(f"row bands thinner than 2 x half window ({2 * self.ny}): use fewer ranks")
         local = local.contiguous()
-        handle = self.start_exchange(local)
         out = torch.empty_like(local)
         L = lib()
+        up = dn = None
+        done = None
+        if comm is not None and self.world > 1:
+            cur = stream or torch.cuda.current_stream()
+            if getattr(self, "_xstream", None) is None:
+                self._xstream = torch.cuda.Stream()
+            up = torch.empty((images, self.ny, cols), dtype=local.dtype, device=local.device) if self.top else None
+            dn = torch.empty((images, self.ny, cols), dtype=local.dtype, device=local.device) if self.bottom else None
+            scratch = torch.empty((2, images, self.ny, cols), dtype=local.dtype, device=local.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            self._xstream.wait_event(ready)                   # the band's rows are there before they are packed
+            comm.rowband_exchange(local, self.ny, up, dn, scratch, stream=self._xstream)
+            done = torch.cuda.Event()
+            done.record(self._xstream)
+            handle = None
+        else:
+            handle = self.start_exchange(local)
         if not (boundary == 0 and own - 2 * self.ny <= 0):
             if L.savgol2d_apply_batch_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols, _addr(out), cols, own * cols, images, boundary, method,
                                           _stream(stream)) != 0:
                 raise RuntimeError(last_error())
-        up, dn = self.finish_exchange(handle)
+        if done is not None:
+            (stream or torch.cuda.current_stream()).wait_event(done)
+        else:
+            up, dn = self.finish_exchange(handle)
         rc = L.savgol2d_apply_rowband_edges_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols,
                                                 _addr(up) if up is not None else None, _addr(dn) if dn is not None else None,
                                                 cols, self.ny * cols, _addr(out), cols, own * cols, images, boundary, method, _stream(stream))

@@ -1017,3 +1017,28 @@ def test_length_split_two_ranks_sharing_the_gpu(sg, sgo, torch_gpu, tmp_path, n)
         ref64 = sgo.Filter(n, 4, 1, 0.5, mode).apply_f64(xh.astype(np.float64))
         fma = np.concatenate([np.load(tmp_path / f"fma{mode}_r{r}.npy") for r in range(world)], axis=1)
         assert normwise(fma, ref64) < TOL_F32_DERIV, (mode, normwise(fma, ref64))
+
+
+def test_scratch_pool_hands_its_memory_back(sg, torch_gpu):
+    """the staged strided path takes 2 x channels x ld x 4 bytes of stream-ordered scratch, and round 3's pool (release
+    threshold UINT64_MAX) was meant to keep the peak for the life of the process -- invisible to PyTorch's allocator and to the caller's
+    hipMalloc.  Now: what the pool holds (hipMemPoolAttrReservedMemCurrent; hipMemGetInfo does not move on ROCm 7.2 whatever a pool
+    releases, tools/probe_pool_trim.hip) is at most its 256 MiB threshold once the stream has been synchronised, and zero after
+    savgol_hip_trim_scratch() or savgol_hip_synchronize()."""
+    torch = torch_gpu
+    L = sg.lib()
+    ch, count = 64, 1 << 20                                           # 64 x 1 Mi records of 8 bytes: 512 MiB array, 512 MiB of scratch
+    aos = torch.randn((ch, count, 2), dtype=torch.float32, device="cuda")
+    f = sg.Filter(8, 3, 0, 1.0, 0)
+
+    def staged_call():                                                # the same field in place: gather -> dense kernels -> scatter
+        assert L.savgol_apply_strided_batch_f32(f.ptr, aos.data_ptr(), 8, 0, count * 8, aos.data_ptr(), 8, 0, count * 8, ch, count, None) == 0, sg.last_error()
+    staged_call()
+    assert L.savgol_hip_scratch_reserved() >= 2 * ch * count * 4      # in flight: the pool holds the two staging frames
+    torch.cuda.synchronize()
+    assert L.savgol_hip_scratch_reserved() <= (256 << 20) + (64 << 20)
+    assert L.savgol_hip_trim_scratch() == 0
+    assert L.savgol_hip_scratch_reserved() == 0
+    staged_call()
+    assert L.savgol_hip_synchronize(None) == 0                        # synchronises the stream, then trims
+    assert L.savgol_hip_scratch_reserved() == 0

@@ -671,3 +671,26 @@ def test_row_bands_apply_c_two_ranks_sharing_the_gpu(sg, torch_gpu, tmp_path):
                 assert np.array_equal(got[:, n:rows - n, n:cols - n], wh[:, n:rows - n, n:cols - n]), (b, method)
             else:
                 assert np.array_equal(got, wh), (b, method)
+
+
+def test_overlapping_frames_are_refused(sg, torch_gpu):
+    """No 2-D kernel can run in place (every output reads its neighbours' inputs; tiles run in any order; wide windows re-read the input
+    after writing).  ADVICE r03: the rule was only a header comment and an overlapping call returned garbage -- now it is -1 with a message,
+    for the plain call and the fused derivative calls alike, and a call on disjoint halves of one buffer still runs."""
+    torch = torch_gpu
+    L = sg.lib()
+    rows, cols = 64, 256
+    buf = torch.randn((2, rows, cols), dtype=torch.float32, device="cuda")
+    f = sg.Filter2D(3, 3, 2)
+    for method in (0, 1, 2):
+        rc = L.savgol2d_apply_batch_f32(f.ptr, buf.data_ptr(), rows, cols, cols, rows * cols, buf.data_ptr(), cols, rows * cols, 1, 1, method, None)
+        assert rc == -1 and "overlap" in sg.last_error()
+        # shifted by a few rows: still overlapping
+        rc = L.savgol2d_apply_batch_f32(f.ptr, buf.data_ptr(), rows, cols, cols, rows * cols, buf.data_ptr() + 4 * 5 * cols, cols, rows * cols, 1, 1, method, None)
+        assert rc == -1
+        rc = L.savgol2d_apply_batch_f32(f.ptr, buf[0].data_ptr(), rows, cols, cols, rows * cols, buf[1].data_ptr(), cols, rows * cols, 1, 1, method, None)
+        assert rc == 0, sg.last_error()
+    gx = torch.empty((rows, cols), dtype=torch.float32, device="cuda")
+    rc = L.savgol2d_gradient_batch_f32(3, 3, 2, buf.data_ptr(), rows, cols, cols, rows * cols, gx.data_ptr(), buf.data_ptr(), cols, rows * cols, 1, 1.0, 1.0, 1, None)
+    assert rc == -1 and "overlap" in sg.last_error()
+    torch.cuda.synchronize()

@@ -38,7 +38,7 @@ def test_optional_rccl_library_exports_its_header(sg):
     must NOT depend on RCCL."""
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "savgol_hip_rccl.h")).read(), flags=re.S)
     names = set(re.findall(r"\b(savgol\w*)\s*\(", txt))
-    assert names == {"savgol2d_rowband_exchange_rccl"}
+    assert names == {"savgol2d_rowband_exchange_rccl", "savgol2d_rowband_exchange_rccl_peers", "savgol_lengthsplit_exchange_rccl"}
     path = os.path.join(os.path.dirname(sg.LIB_PATH), "libsavgol_hip_rccl.so")
     assert os.path.exists(path), "make builds it next to libsavgol_hip.so"
     L = C.CDLL(path)
