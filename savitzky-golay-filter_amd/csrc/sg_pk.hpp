@@ -21,6 +21,7 @@ namespace sg {
 typedef float        f32x2 __attribute__((ext_vector_type(2)));
 typedef float        f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));      // the nontemporal builtins want a native vector type
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // acc += w[SEL] * x, tap pair in SGPRs
 template <int SEL>

@@ -208,6 +208,123 @@ __device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRol
     }
 }
 
+// ---- TILE form (round 4; half windows <= STREAM_RING_MAX_N, stream rows 16-byte aligned) ----
+// The 2-D kernel's lesson (csrc/sg_2d_roll.hip, tools/membench_tile2d.hip): a walk down a strip -- a long-lived wave with a few rows in
+// flight -- tops out at 0.63-0.71 of the roofline bare, short-lived waves that issue ALL their loads up front and exit reach 0.71-0.78.
+// Here: a wave owns 256 adjacent streams (a lane 4 = one 16-byte load per tick row) and TR output ticks; it loads the TR + 2N rows
+// (history from the ring, then this call's samples) back to back into registers, computes its TR rows with literal indices -- the same
+// per-output arithmetic as bank_roll_item, bit for bit in both forms -- stores them and exits.  The 2N halo rows are read again by the
+// tile of the next TR ticks: out of L2, because tiles are dealt so that blocks sharing an XCD walk down a GROUP of neighbouring strips
+// band by band (a whole 256 KiB tick row of 65 536 streams would not stay in a 4 MiB L2 for the 256 tiles between two bands; a group of
+// G strips x (TR + 2N) rows does).  Rows and stores go through range-checked buffer descriptors (streams beyond the bank read 0 and
+// store nothing; a row without an output selects an empty descriptor), so there is no branch between the first load and the last store
+// and hipcc's vmcnt waits stay counted.
+#ifndef SG_STREAM_TILE_ROWS
+#define SG_STREAM_TILE_ROWS 16
+#endif
+#ifndef SG_STREAM_TILE_WPB
+#define SG_STREAM_TILE_WPB 2
+#endif
+struct TileGeom { unsigned strips, bands, group; unsigned long long total; };
+
+#ifndef SG_STREAM_TILE_SPL
+#define SG_STREAM_TILE_SPL 4                                 // streams per lane: 4 = one 16-byte load per row, 2 = one 8-byte load
+#endif
+template <int N, bool FMA>
+__global__ __launch_bounds__(64 * SG_STREAM_TILE_WPB, 2) void sg_bank_tile_kernel(const BankJob job, const SRollTaps<N> taps, const TileGeom geo)
+{
+    typedef SRoll<N> R;
+    constexpr int TR = SG_STREAM_TILE_ROWS, ROWS = TR + 2 * N, SPL = SG_STREAM_TILE_SPL, NP = SPL / 2;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned nblk = gridDim.x;
+    const unsigned blk = (job.aligned & 2) ? blockIdx.x : (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const unsigned long long t = (unsigned long long)blk * SG_STREAM_TILE_WPB + (unsigned)wv;
+    if (t >= geo.total) return;
+    // tile order: groups of `group` neighbouring strips; inside a group band after band, strips fastest
+    const unsigned long long per_group = (unsigned long long)geo.group * geo.bands;
+    const unsigned grp = (unsigned)(t / per_group);
+    const unsigned long long rem = t % per_group;
+    const unsigned gs = geo.strips - grp * geo.group < geo.group ? geo.strips - grp * geo.group : geo.group;     // strips in this (last) group
+    const unsigned band = (unsigned)(rem / gs), strip = grp * geo.group + (unsigned)(rem % gs);
+    if (band >= geo.bands) return;                                       // the last group is narrower: its tail of the t range is empty
+    const size_t t0 = (size_t)band * TR;
+    const unsigned voff = (strip * (64u * SPL) + (unsigned)SPL * (unsigned)lane) * 4u;     // byte offset of this lane's streams in a row
+    const int row_bytes = (int)(job.streams * 4);
+
+    struct Row { f32x2 p[NP]; };
+    auto load_row = [&](int r) -> Row {
+        long long h = (long long)t0 - 2 * N + r;
+        if (h >= (long long)job.ticks) h = (long long)job.ticks - 1;            // past the call: loaded, never used
+        int slot = job.wp0 + (int)(h < 0 ? h : 0);
+        slot = slot < 0 ? slot + R::WS : slot;
+        const float *row = h >= 0 ? job.samples + (size_t)h * job.streams : job.ring + (size_t)slot * job.streams;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row), 0, row_bytes, 0x00020000);
+        Row o;
+        if constexpr (SPL == 4) {
+            const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
+            o.p[0] = f32x2{q.x, q.y}; o.p[1] = f32x2{q.z, q.w};
+        } else {
+            o.p[0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0));
+        }
+        return o;
+    };
+    Row win[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) win[r] = load_row(r);
+
+    static_for<TR>([&](auto mc) -> bool {
+        constexpr int m = decltype(mc)::value;
+        f32x2 a[NP];
+        if constexpr (FMA) {
+            // two chains (even taps, odd taps), one v_pk_fma_f32 per tap and stream pair: bank_roll_item's fast form
+            f32x2 o[NP];
+#pragma unroll
+            for (int c = 0; c < NP; ++c) { o[c] = pk_mul_sgpr<1>(taps.w[0], win[m + 1].p[c]); a[c] = pk_mul_sgpr<0>(taps.w[0], win[m].p[c]); }
+            static_for(std::make_integer_sequence<int, R::WS - 2>{}, [&](auto kc) -> bool {
+                constexpr int k = decltype(kc)::value + 2;
+#pragma unroll
+                for (int c = 0; c < NP; ++c) {
+                    if constexpr (k & 1) pk_fma_sgpr<1>(o[c], taps.w[k >> 1], win[m + k].p[c]);
+                    else                 pk_fma_sgpr<0>(a[c], taps.w[k >> 1], win[m + k].p[c]);
+                }
+                return true;
+            });
+#pragma unroll
+            for (int c = 0; c < NP; ++c) a[c] = a[c] + o[c];
+        } else {
+            // the reference's order (src/savgol_stream.c:25-38): one accumulator from 0, taps ascending, multiply and add rounded separately
+            f32x2 p[NP];
+#pragma unroll
+            for (int c = 0; c < NP; ++c) { a[c] = f32x2{0.0f, 0.0f}; p[c] = pk_mul_sgpr<0>(taps.w[0], win[m].p[c]); }
+            static_for(std::make_integer_sequence<int, R::WS>{}, [&](auto kc) -> bool {
+                constexpr int k = decltype(kc)::value;
+#pragma unroll
+                for (int c = 0; c < NP; ++c) {
+                    f32x2 nx = p[c];
+                    if constexpr (k + 1 < R::WS) nx = pk_mul_sgpr<((k + 1) & 1)>(taps.w[(k + 1) >> 1], win[m + k + 1].p[c]);
+                    a[c] = a[c] + p[c];
+                    p[c] = nx;
+                }
+                return true;
+            });
+        }
+        const size_t tt = t0 + (size_t)m;
+        const bool has_out = tt < job.ticks && job.received0 + tt + 1 >= (unsigned long long)R::WS;     // uniform (reference :166-170)
+        const f32x2 s = f32x2{job.dt_inv, job.dt_inv};
+        float *orow = job.out + (tt < job.ticks ? tt : 0) * job.streams;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow, 0, has_out ? row_bytes : 0, 0x00020000);
+        if constexpr (SPL == 4) {
+            const f32x2 y0 = a[0] * s, y1 = a[1] * s;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{y0.x, y0.y, y1.x, y1.y}), rs, (int)voff, 0, 0);
+        } else {
+            const f32x2 y0 = a[0] * s;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y0), rs, (int)voff, 0, 0);
+        }
+        return true;
+    });
+}
+
 template <int N, bool FMA>
 __global__ __launch_bounds__(256) void sg_bank_roll_kernel(const BankJob job, const SRollTaps<N> taps)
 {
@@ -247,6 +364,31 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
         per_cu = nb > 4 ? 4 : nb;
         if (FMA && N <= 16 && per_cu > 2) per_cu = 2;        // fewer waves, more rows in flight each (see SRoll::P)
         if (const char *e = getenv("SAVGOL_HIP_STREAM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 4 && v <= nb) per_cu = v; }      // A/B runs
+    }
+    if constexpr (N <= STREAM_RING_MAX_N) {
+        // the tile form: rows of whole 16-byte quads (the buffer range check works on whole accesses), rows < 2 GiB, at least two tiles of ticks
+        static const int tile_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_TILE"); return e ? atoi(e) : 1; }();
+        const bool quads = job.streams % 4 == 0 && job.streams * 4 < 0x7fffff00ull &&
+                           ((reinterpret_cast<uintptr_t>(job.samples) | reinterpret_cast<uintptr_t>(job.out) | reinterpret_cast<uintptr_t>(job.ring)) & 15u) == 0;
+        if (tile_env && quads && job.ticks >= 2 * SG_STREAM_TILE_ROWS) {
+            TileGeom geo;
+            geo.strips = (unsigned)((job.streams + 64 * SG_STREAM_TILE_SPL - 1) / (64 * SG_STREAM_TILE_SPL));
+            geo.bands = (unsigned)((job.ticks + SG_STREAM_TILE_ROWS - 1) / SG_STREAM_TILE_ROWS);
+            // strips per group: (TR + 2N) rows x group KiB should stay well inside an XCD's 4 MiB L2 beside the rows in flight
+            static const int group_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_TILE_GROUP"); return e ? atoi(e) : 0; }();
+            geo.group = group_env > 0 ? (unsigned)group_env : (unsigned)(256 / SG_STREAM_TILE_SPL);      // 64 KiB of a tick row
+            if (geo.group > geo.strips) geo.group = geo.strips;
+            const unsigned groups = (geo.strips + geo.group - 1) / geo.group;
+            geo.total = (unsigned long long)groups * geo.group * geo.bands;
+            const unsigned long long blocks = (geo.total + SG_STREAM_TILE_WPB - 1) / SG_STREAM_TILE_WPB;
+            if (blocks < 0x7fffff00ull) {
+                unsigned grid = ((unsigned)blocks + 7u) & ~7u;
+                static const int xcd_tile = [] { const char *e = getenv("SAVGOL_HIP_STREAM_XCD"); return e ? atoi(e) : 1; }();
+                job.aligned = 1 | (xcd_tile ? 0 : 2);
+                hipLaunchKernelGGL((sg_bank_tile_kernel<N, FMA>), dim3(grid), dim3(64 * SG_STREAM_TILE_WPB), 0, st, job, taps, geo);
+                return 0;
+            }
+        }
     }
     const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
     job.strips = (unsigned)((job.streams + 127) / 128);

@@ -5,10 +5,10 @@ from __graft_entry__ import load_package
 sg = load_package()
 import torch
 
-S, T = 65536, 4096
+S, T = 65536, int(os.environ.get("TICKS", "4096"))
 x = torch.randn((T, S), device="cuda")
 out = torch.empty_like(x)
-for n, fma in [(n, f) for n in (4, 8, 16, 17, 24, 32) for f in (False, True)]:
+for n, fma in [(n, f) for n in [int(v) for v in os.environ.get("HALF_WINDOWS", "4,8,16,17,24,32").split(",")] for f in (False, True)]:
     bank = sg.StreamBank(S, n, 2, 1, 1e-3, fma=fma)
     bank.push_block(x, T, out); torch.cuda.synchronize()
     ts = []
