@@ -573,6 +573,9 @@ __global__ __launch_bounds__(256, (K1D<float, N, SG_VPL_NARROW>::MIN_WAVES)) voi
     // ---- results out of the slab, element lane + 64 k of the tile -> its record ----
     const int lo = (int)job.store_lo, hi = (int)job.store_hi;
     char *q = orow + (long long)(ts + lane) * job.out_stride;
+    // (Round 4 tried whole-record stores for two fields of the SAME 8- / 16-byte records -- re-read the record, replace the field, store
+    //  8 / 16 bytes per lane: 265 / 145 Gsamples/s against 324 / 159 with the plain 4-byte stores below.  A partial store into a line the
+    //  tile has just read merges in L2; only a destination array of its own pays the memory a read-modify-write: profiles/r04_strided.txt.)
     if (ts >= lo && ts + TW <= hi) {
 #pragma unroll
         for (int k = 0; k < TW / 64; ++k)

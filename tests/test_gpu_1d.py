@@ -1042,3 +1042,46 @@ def test_scratch_pool_hands_its_memory_back(sg, torch_gpu):
     staged_call()
     assert L.savgol_hip_synchronize(None) == 0                        # synchronises the stream, then trims
     assert L.savgol_hip_scratch_reserved() == 0
+
+
+@pytest.mark.parametrize("rec,n,m,d", [(2, 32, 4, 0), (4, 32, 4, 0), (2, 5, 3, 1), (4, 13, 5, 2), (2, 1, 1, 0)])
+def test_strided_two_fields_of_the_same_records(sg, sgo, torch_gpu, rec, n, m, d):
+    """Two fields of the SAME 8- / 16-byte records (savgol_apply_strided_batch_f32 with d_in == d_out, equal strides, different offsets;
+    reference loop: src/savgolFilter.c:877-934) -- the fused kernel's fastest case, 324 / 159 Gsamples/s, because a partial store into a
+    line the tile has just read merges in L2 (profiles/r04_strided.txt; whole-record stores were tried there and lost).  The filtered
+    field within the fp32 bar of the oracle (polynomial edges, whatever config.boundary says), every other field bit for bit what it
+    was, for counts that end inside a tile and channel pitches with slack."""
+    torch = torch_gpu
+    L = sg.lib()
+    tol = 1e-6 if d == 0 else 1.5e-6
+    for ch, count, slack in ((3, 5000, 0), (2, 2 * n + 1, 3), (4, 2048 + 2 * n + 3, 1), (1, 70001, 0)):
+        pitch = (count + slack) * rec
+        buf = torch.randn((ch, pitch), dtype=torch.float32, device="cuda")
+        before = buf.clone()
+        view = buf.view(ch, count + slack, rec)
+        for (fi, fo) in ((0, 1), (rec - 1, 0)):
+            buf.copy_(before)
+            rc = L.savgol_apply_strided_batch_f32(f_keep(sg, n, m, d), buf.data_ptr(), rec * 4, fi * 4, pitch * 4,
+                                                  buf.data_ptr(), rec * 4, fo * 4, pitch * 4, ch, count, None)
+            assert rc == 0, sg.last_error()
+            torch.cuda.synchronize()
+            got = view.cpu().numpy()
+            was = before.view(ch, count + slack, rec).cpu().numpy()
+            ref = sgo.Filter(n, m, d, 1.0, 0).apply_f64(was[:, :count, fi].astype(np.float64))
+            bar = max(tol, 1.5 * normwise(sgo.Filter(n, m, d, 1.0, 0).apply(np.ascontiguousarray(was[:, :count, fi])), ref)) if d else tol
+            assert normwise(got[:, :count, fo], ref) < bar, (rec, ch, count, fi, fo)
+            keep = [k for k in range(rec) if k != fo]
+            assert np.array_equal(got[:, :, keep].view(np.uint32), was[:, :, keep].view(np.uint32))
+            assert np.array_equal(got[:, count:].view(np.uint32), was[:, count:].view(np.uint32))
+
+
+_kept_filters = {}
+
+
+def f_keep(sg, n, m, d):
+    """filters kept alive for the whole module (a SavgolFilter freed while its launch is queued would be read after free by nothing --
+    the tables are uploaded at the call -- but ctypes temporaries die before the call returns otherwise)"""
+    key = (n, m, d)
+    if key not in _kept_filters:
+        _kept_filters[key] = sg.Filter(n, m, d, 1.0, 2)
+    return _kept_filters[key].ptr
