@@ -524,13 +524,16 @@ constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
 {
     if (box && nt == 2 && nout == 1 && n <= 7) return SG_ROLL_TILE_ROWS;
     if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt <= 2 && n <= 7) return SG_ROLL_TILE_ROWS;
+    // the fused two- / three-output forms with one term per frame (gradient of order <= 2, Hessian of order <= 3): the three Hessian frames
+    // of 64 x 4096^2 at n = 7 in 3.54 ms instead of 4.02 (2 waves per SIMD: 178 registers)
+    if (SG_ROLL_TILE_GENERAL && !box && nout >= 2 && nt == 1 && n <= 7) return SG_ROLL_TILE_ROWS;
     return 0;
 }
 #ifndef SG_ROLL_TILE_WAVES
 #define SG_ROLL_TILE_WAVES 3
 #endif
 // (the general two-term form at n = 7 spills 52 bytes at 3 waves per SIMD)
-constexpr int roll_tile_waves(int n, int nt = 2, bool box = true) { return (!box && nt == 2 && n >= 7) ? 2 : SG_ROLL_TILE_WAVES; }
+constexpr int roll_tile_waves(int n, int nt = 2, bool box = true, int nout = 1) { return (nout >= 2 || (!box && nt == 2 && n >= 7)) ? 2 : SG_ROLL_TILE_WAVES; }
 
 // waves per block: the waves of a block walk neighbouring strips row for row, so a block's loads of one row step are one
 // contiguous run of the frame row
@@ -545,7 +548,7 @@ constexpr int roll_tile_waves(int n, int nt = 2, bool box = true) { return (!box
 constexpr int roll_wpb(int n, int tr = 0) { (void)n; return tr > 0 ? SG_ROLL_TILE_WPB : SG_ROLL_WPB; }
 
 template <int N, int NT, int NOUT, bool BOX, bool ACC, int TR = 0>
-__global__ __launch_bounds__(64 * roll_wpb(N, TR), TR > 0 ? roll_tile_waves(N, NT, BOX) : roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1, float *const out2,
+__global__ __launch_bounds__(64 * roll_wpb(N, TR), TR > 0 ? roll_tile_waves(N, NT, BOX, NOUT) : roll_min_waves(N, NT, NOUT)) void sg2d_rolling_kernel(const Job2D job, const RollTaps<N, NT, NOUT> taps, float *const out1, float *const out2,
                                                            unsigned strips, unsigned bands, int band_rows, unsigned total_items, int aligned)
 {
     typedef Roll<N> R;
