@@ -299,8 +299,8 @@ struct SmallService {
     bool running = false, broken = false;
     unsigned long long seq = 0;                              // calls posted to the CURRENT kernel instance
     // how long the resident workgroup waits for the next call before it leaves.  A device-wide synchronise of the caller (or a hipFree)
-    // in that window waits for it: 150 us by default (round 3: 2 ms), SAVGOL_HIP_SMALL_SERVICE_IDLE_US to change it
-    unsigned idle_us = 150;
+    // in that window waits for it: 60 us by default (round 3: 2 ms), SAVGOL_HIP_SMALL_SERVICE_IDLE_US to change it
+    unsigned idle_us = 60;
     double backoff_s = 0.0;                                  // after an unanswered call: no attempts before retry_at
     std::chrono::steady_clock::time_point retry_at{};
 };

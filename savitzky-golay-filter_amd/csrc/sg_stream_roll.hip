@@ -365,7 +365,12 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
         if (FMA && N <= 16 && per_cu > 2) per_cu = 2;        // fewer waves, more rows in flight each (see SRoll::P)
         if (const char *e = getenv("SAVGOL_HIP_STREAM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 4 && v <= nb) per_cu = v; }      // A/B runs
     }
-    if constexpr (N <= STREAM_RING_MAX_N) {
+    // Where the tile form pays (profiles/r04_stream_tile.txt; config 3's shape, 65 536 streams x 4096 ... 16 384 ticks, five variants of
+    // streams per lane x rows per tile x waves per block, strips per group 8 ... 256): the reference-order bank at n <= 12 (n = 4: 0.393 vs
+    // 0.420 ms, n = 8: 0.408 vs 0.425); at n = 16 its 2n = 32 halo rows per 16-row tile (3 x the row reads out of L2) cancel the gain
+    // (0.44-0.47 vs 0.45-0.46), and the fused multiply-add bank's walk is level or ahead at every half window (n = 16: 0.400-0.425 vs
+    // 0.403-0.446).  Both forms sit at 0.60-0.69 of the roofline on this 2 GB call, a 0.4 ms launch, whatever the call's length.
+    if constexpr (N <= 12 && !FMA) {
         // the tile form: rows of whole 16-byte quads (the buffer range check works on whole accesses), rows < 2 GiB, at least two tiles of ticks
         static const int tile_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_TILE"); return e ? atoi(e) : 1; }();
         const bool quads = job.streams % 4 == 0 && job.streams * 4 < 0x7fffff00ull &&

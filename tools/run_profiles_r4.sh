@@ -5,15 +5,21 @@
 set -x
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r4_prof; mkdir -p $O
+# ONLY=stream (or f32 / f64 / image): just that kernel's counter passes (after a change to that kernel's sources)
+if [ -z "$ONLY" ]; then
 python bench.py > $O/bench_line.json 2> $O/bench_line.err; echo "bench rc $?"
+fi
 cd /tmp && export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
+if [ -z "$ONLY" ]; then
 for i in 1 2 3 4 5; do
   rocprofv3 --kernel-trace --stats -d $O/repro$i -o run --output-format csv -- python3 $B --no-cpu --no-extra > $O/repro$i.json 2> $O/repro$i.err
 done
+fi
 SQ="GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 pmc() {   # name, bench.py arguments...
   name=$1; shift
+  if [ -n "$ONLY" ] && [ "$ONLY" != "$name" ]; then return; fi
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${name}_fetch -o run --output-format csv -- python3 $B "$@" > $O/${name}_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${name}_write -o run --output-format csv -- python3 $B "$@" > $O/${name}_write.log 2>&1
   rocprofv3 --kernel-trace --pmc $SQ -d $O/${name}_sq -o run --output-format csv -- python3 $B "$@" > $O/${name}_sq.log 2>&1
