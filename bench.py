@@ -286,7 +286,7 @@ def bench_stream(sg, a):
                             "Msamples_per_s": round(S / tick_us, 1)},
         "block_push": {"ticks_per_launch": T, "ms": round(ms, 3), "ns_per_sample": round(ms * 1e6 / samples, 5),
                        "Msamples_per_s": round(samples / ms / 1e3, 1),
-                       "summation": "SAVGOL_STREAMBANK_FMA (one v_pk_fma_f32 per tap and stream pair; <= 2e-6 of the fp64 oracle for this derivative filter)",
+                       "summation": "SAVGOL_STREAMBANK_FMA (one v_pk_fma_f32 per tap and stream pair; <= 1.5e-6 of the fp64 oracle for this derivative filter)",
                        "roofline": with_traffic(roofline(8.0 * samples, ms, kernel="sg_bank_roll_kernel<16,true>", algorithmic_bytes_per_sample=8),
                                                 "r*_stream_block_pmc_summary.json", SOURCES_STREAM)},
         "block_push_reference_order": {"ms": round(ms_ref, 3), "Msamples_per_s": round(samples / ms_ref / 1e3, 1),
@@ -770,12 +770,12 @@ def main():
             checked = float(np.max(np.abs(y[sample].cpu().numpy() - ref)) / np.max(np.abs(ref)))
             assert checked < 1e-6, f"parity lost: normwise error {checked}"
             out["parity_normwise_vs_fp64_oracle"] = checked
-            # a derivative filter through the same kernel (documented bar for d >= 1: 2e-6, include/savgol_hip.h)
+            # a derivative filter through the same kernel (documented bar for d >= 1: 1.5e-6, include/savgol_hip.h)
             fd = sg.Filter(N, M, 1, 1.0, 0)
             fd.apply_batch(x, y, ch, length); torch.cuda.synchronize()
             refd = sgo.Filter(N, M, 1, 1.0, 0).apply_f64(x[sample].cpu().numpy().astype(np.float64))
             out["parity_normwise_vs_fp64_oracle_d1"] = float(np.max(np.abs(y[sample].cpu().numpy() - refd)) / np.max(np.abs(refd)))
-            assert out["parity_normwise_vs_fp64_oracle_d1"] < 2e-6
+            assert out["parity_normwise_vs_fp64_oracle_d1"] < 1.5e-6
         if world == 1:
             # secondary figures, outside the timed region
             L = sg.lib()

@@ -25,13 +25,16 @@
  *     savgol_stream.h / savgol2d.h: synchronous by nature (they return host data).
  * Short host-pointer calls (savgol_apply / _valid / _strided on <= 4096 samples and <= 64 K multiply-adds, every savgol_stream_* call
  * on one SavgolStream) do not launch: one workgroup stays resident behind a doorbell (csrc/sg_k1d_misc.hip) and answers in 6-8 us
- * with the reference's bits.  It leaves by itself after 2 ms without a call -- a device-wide synchronise issued by the caller
- * waits at most that long for it -- and is restarted by the next short call.  Environment: SAVGOL_HIP_SMALL_SERVICE=0 disables
- * it (every call then launches), SAVGOL_HIP_SMALL_SERVICE_IDLE_US sets the idle time (50 ... 5 000 000).
+ * with the reference's bits.  It leaves by itself after 60 us without a call -- a device-wide synchronise issued by the caller
+ * waits at most that long for it -- is told to leave before the library's own hipFree / hipMalloc, is restarted by the next short
+ * call, and after an unanswered call stays away for 1 s, doubling to 64 s.  Environment: SAVGOL_HIP_SMALL_SERVICE=0 disables it
+ * (every call then launches), SAVGOL_HIP_SMALL_SERVICE_IDLE_US sets the idle time (50 ... 5 000 000).  The library installs no
+ * signal handlers unless SAVGOL_HIP_BAR_DOORBELL=1 asks for doorbells in BAR-mapped device memory (probed with a guarded store).
  * Accuracy of the default fp32 device kernels against the double-accumulation oracle (normwise, max|err| / max|ref|):
- * <= 1e-6 for smoothing filters (derivative 0), <= 2e-6 for derivative filters on the 1-D path (the reference's own fp32
- * paths -- batch vs stream -- disagree by 1.3e-6 there), <= 4e-6 for 2-D derivative frames.  Bit-identical-to-the-reference
- * results: SAVGOL_HIP_OPT_REFERENCE_SUMMATION (1-D), method 1 (2-D), and every host-pointer drop-in call.
+ * <= 1e-6 for smoothing filters that pass the signal; everywhere <= max(1e-6, 1.5 x the error of the reference's OWN fp32
+ * arithmetic on the same samples) and <= 1.5e-6 on the 1-D path (three interleaved partial sums per output; measured <= 1.34 x,
+ * 8.2e-7: tests/test_gpu_1d.py); <= 4e-6 for 2-D derivative frames.  Bit-identical-to-the-reference results:
+ * SAVGOL_HIP_OPT_REFERENCE_SUMMATION (1-D), method 1 (2-D), and every host-pointer drop-in call.
  */
 #ifndef SAVGOL_HIP_H
 #define SAVGOL_HIP_H
@@ -175,7 +178,7 @@ SavgolStreamBank *savgol_streambank_create(const SavgolConfig *config, size_t st
 /* Per-bank choice of the summation, fixed at create (the stream analogue of the 1-D batch path's fast default):
  * SAVGOL_STREAMBANK_FMA: centre outputs of _push / _push_block / _push_full (after the filling tick) are fused multiply-adds --
  *   one v_pk_fma_f32 per tap and stream pair instead of a multiply and an add (reference loop src/savgol_stream.c:25-38), half
- *   the vector instructions of the block push.  NOT the reference's bits: <= 1e-6 (smoothing) / 2e-6 (derivatives) normwise of
+ *   the vector instructions of the block push.  NOT the reference's bits: <= 1e-6 (smoothing) / 1.5e-6 (derivatives) normwise of
  *   the fp64 oracle, like the default 1-D batch kernels.  Edge rows (leading burst, _flush, _flush_leading), the resident
  *   tick service and calls of >= 2^31 ticks keep the reference's order.  flags 0 == savgol_streambank_create.               */
 enum { SAVGOL_STREAMBANK_FMA = 1 };
@@ -229,7 +232,9 @@ int    savgol_streambank_load(SavgolStreamBank *bank, const void *host_blob, voi
  * which therefore must not overlap the input), 3 = the separable tile kernel for any half window (diagnostic).
  * Rectangular windows (half_window_x != half_window_y): methods 0 / 2 run the rolling kernel of the LARGER half window on
  * factors zero-padded to it (same results to fp32 rounding).  Caveat of the padding: a zero tap times a non-finite sample is NaN, so in
- * this method NaN / Inf input spreads over the padded (square) window instead of the rectangular one; method 1 does not.  */
+ * this method NaN / Inf input spreads over the padded (square) window instead of the rectangular one; method 1 does not.
+ * The input and output frame stacks must not share a byte (no 2-D kernel can run in place: every output reads its neighbours'
+ * inputs): an overlapping call returns -1 with "overlap" in savgol_hip_last_error(); the derivative calls below alike.        */
 int savgol2d_apply_batch_f32(const Savgol2DFilter *filter,
                              const float *d_in, int rows, int cols, int in_stride, size_t in_image_pitch,
                              float *d_out, int out_stride, size_t out_image_pitch,
