@@ -39,7 +39,8 @@ int savgol2d_rowband_exchange_rccl_peers(void *nccl_comm, int peer_up, int peer_
  * elem_bytes 4 (fp32) or 8 (fp64) -- sends its first half_window samples of every channel to peer_prev and its last ones to peer_next
  * and receives the neighbours' into d_halo_prev / d_halo_next (channels x half_window samples each, contiguous).  -1 = no neighbour;
  * PERIODIC signals close the ring (rank 0's prev = the last rank), and with two ranks or one both peers are the same rank: d_halo_prev
- * then receives that peer's LAST samples and d_halo_next its FIRST.  d_send_scratch: 2 x channels x half_window samples.  0 / -1.     */
+ * then receives that peer's LAST samples and d_halo_next its FIRST.  d_send_scratch: 2 x channels x half_window samples.  At most
+ * 65 535 channels per call (more: shard by channel, which needs no exchange).  0 / -1.                                                 */
 int savgol_lengthsplit_exchange_rccl(void *nccl_comm, int peer_prev, int peer_next, const void *d_segment, size_t channels, size_t own,
                                      size_t ld, int half_window, int elem_bytes, void *d_halo_prev, void *d_halo_next,
                                      void *d_send_scratch, void *stream);

@@ -39,17 +39,13 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(uint32_t *__restrict__ d
 
 bool pack(uint32_t *dst, const uint32_t *src, long long pitch, long long stride, size_t outer, int rows, int cols, hipStream_t st)
 {
+    if (rows < 1 || rows > 65535 || cols < 1) return false;          // grid.y is 16-bit (the entry points refuse more rows than that)
     unsigned gx = (unsigned)((cols + 255) / 256);
     if (gx > 64) gx = 64;
-    // grid.y / grid.z are 16-bit: many short rows (the 1-D split: rows = channels) go through z in slices
-    for (size_t o0 = 0; o0 < outer; o0 += 65535) {
+    for (size_t o0 = 0; o0 < outer; o0 += 65535) {                   // grid.z is 16-bit too: slices of the outer dimension
         const unsigned no = (unsigned)(outer - o0 < 65535 ? outer - o0 : 65535);
-        for (int r0 = 0; r0 < rows; r0 += 65535) {
-            const unsigned nr = (unsigned)(rows - r0 < 65535 ? rows - r0 : 65535);
-            hipLaunchKernelGGL(pack_rows_kernel, dim3(gx, nr, no), dim3(256), 0, st, dst + ((long long)o0 * rows + r0) * cols,
-                               src + (long long)o0 * pitch + (long long)r0 * stride, pitch, stride, rows, cols);
-            if (rows > 65535) return false;                          // dst indexing above assumes rows fit one slice per outer block
-        }
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(gx, (unsigned)rows, no), dim3(256), 0, st, dst + (long long)o0 * rows * cols,
+                           src + (long long)o0 * pitch, pitch, stride, rows, cols);
     }
     return hipGetLastError() == hipSuccess;
 }
@@ -109,12 +105,12 @@ int savgol2d_rowband_exchange_rccl(void *nccl_comm, int rank, int world_size, co
 int savgol_lengthsplit_exchange_rccl(void *nccl_comm, int peer_prev, int peer_next, const void *d_segment, size_t channels, size_t own, size_t ld,
                                      int half_window, int elem_bytes, void *d_halo_prev, void *d_halo_next, void *d_send_scratch, void *stream)
 {
-    if (!nccl_comm || !d_segment || half_window < 1 || own < (size_t)half_window || ld < own || channels == 0 || channels > 65535u * 65535u ||
+    // (more than 65 535 channels: shard by channel, not by length -- one launch dimension carries the channels)
+    if (!nccl_comm || !d_segment || half_window < 1 || own < (size_t)half_window || ld < own || channels == 0 || channels > 65535 ||
         (elem_bytes != 4 && elem_bytes != 8)) return -1;
     const int wpe = elem_bytes / 4;                                  // 4-byte words per sample
     const uint32_t *seg = static_cast<const uint32_t *>(d_segment);
     // one "image" of `channels` rows, each row the n samples next to a cut
-    if (channels > 65535) return -1;                                 // (a batch that large is sharded by channel, not by length)
     return exchange(static_cast<ncclComm_t>(nccl_comm), peer_prev, peer_next, seg, seg + (own - (size_t)half_window) * wpe, 0, (long long)ld * wpe, 1,
                     (int)channels, half_window * wpe, static_cast<uint32_t *>(d_halo_prev), static_cast<uint32_t *>(d_halo_next),
                     static_cast<uint32_t *>(d_send_scratch), static_cast<hipStream_t>(stream));
