@@ -180,7 +180,9 @@ SavgolStreamBank *savgol_streambank_create(const SavgolConfig *config, size_t st
  *   one v_pk_fma_f32 per tap and stream pair instead of a multiply and an add (reference loop src/savgol_stream.c:25-38), half
  *   the vector instructions of the block push.  NOT the reference's bits: <= 1e-6 (smoothing) / 1.5e-6 (derivatives) normwise of
  *   the fp64 oracle, like the default 1-D batch kernels.  Edge rows (leading burst, _flush, _flush_leading), the resident
- *   tick service and calls of >= 2^31 ticks keep the reference's order.  flags 0 == savgol_streambank_create.               */
+ *   tick service and calls of >= 2^31 ticks keep the reference's order.  Half windows <= 16 sum in two interleaved chains in _push
+ *   and _push_block alike; above 16 the block push keeps ONE chain per output (its accumulators live in registers) while the
+ *   per-tick kernel uses two, so the two calls agree to fp32 rounding there, not bit for bit.  flags 0 == savgol_streambank_create. */
 enum { SAVGOL_STREAMBANK_FMA = 1 };
 SavgolStreamBank *savgol_streambank_create_ex(const SavgolConfig *config, size_t streams, unsigned flags);
 void   savgol_streambank_destroy(SavgolStreamBank *bank);

@@ -131,3 +131,20 @@ def test_no_cpu_fallback_without_device(sg):
         f.apply(x)
     assert f.apply_valid(x).size == 0
     assert "no usable HIP device" in sg.last_error()
+
+
+def test_rccl_helper_module_imports_without_a_gpu(sg):
+    """savitzky-golay-filter_amd/rccl.py (ctypes access to librccl + lib/libsavgol_hip_rccl.so) must import on a box without a GPU and say
+    whether the two libraries load; the exchange library exports the three entry points its header declares (checked above) and the
+    argument lists the Python side binds match the header's parameter counts."""
+    import importlib
+    rccl = importlib.import_module("savgol_amd.rccl")
+    assert isinstance(rccl.available(), bool)
+    if rccl.available():
+        _, ext = rccl._libs()
+        assert len(ext.savgol2d_rowband_exchange_rccl.argtypes) == 14 and len(ext.savgol2d_rowband_exchange_rccl_peers.argtypes) == 14
+        assert len(ext.savgol_lengthsplit_exchange_rccl.argtypes) == 13
+        hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "savgol_hip_rccl.h")).read(), flags=re.S)
+        for name, count in (("savgol2d_rowband_exchange_rccl", 14), ("savgol2d_rowband_exchange_rccl_peers", 14), ("savgol_lengthsplit_exchange_rccl", 13)):
+            m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", hdr, flags=re.S)
+            assert m and len(m.group(1).split(",")) == count, name
