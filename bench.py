@@ -619,10 +619,20 @@ def main():
                 if args.exchange == "c" and backend == "nccl":         # (the gloo test hook puts every rank on ONE device: RCCL refuses that)
                     rccl = importlib.import_module("savgol_amd.rccl")
                     if rccl.available() and dev.type == "cuda":
-                        uid = [rccl.unique_id() if rank == 0 else None]
-                        dist.broadcast_object_list(uid, src=0)
-                        comm = rccl.Comm(world, rank, uid[0])
-                        exchange = "savgol2d_rowband_exchange_rccl (C ABI: one pack launch + ncclSend/ncclRecv per neighbour, own stream)"
+                        # every rank must take the same path: agree on success with a MIN all-reduce before the first exchange
+                        ok = torch.ones(1, device=dev)
+                        try:
+                            uid = [rccl.unique_id() if rank == 0 else None]
+                            dist.broadcast_object_list(uid, src=0)
+                            comm = rccl.Comm(world, rank, uid[0])
+                        except Exception as exc:                          # noqa: BLE001 -- any failure means "use the torch path", with the reason in the line
+                            ok.zero_()
+                            exchange += f" (the C exchange did not come up: {exc})"
+                        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                        if ok.item() == 1.0:
+                            exchange = "savgol2d_rowband_exchange_rccl (C ABI: one pack launch + ncclSend/ncclRecv per neighbour, own stream)"
+                        else:
+                            comm = None
 
             def apply_fn(frames):
                 k, r, c = frames.shape
