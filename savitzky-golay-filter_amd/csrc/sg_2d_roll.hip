@@ -145,7 +145,7 @@ __device__ __forceinline__ int fix_row(int i, int n, bool reflect)
 // quad is whole (one dwordx4 load and store per lane and row); 2, 3 = round 4, tile form only: a strip that reaches over the LEFT / RIGHT
 // frame edge on vector loads too.  A lane's quad of columns is either inside the frame or outside it (16-byte aligned rows, cols % 4 == 0);
 // a lane outside loads the quad its columns map to (reference src/savgol2d.c:428-445: REFLECT = the mirrored quad, reversed; CONSTANT =
-// the frame's first / last quad, its edge float broadcast) and fixes the order with selects -- 8 v_cndmask per row, no scalar loads, no
+// the frame's first / last quad, its edge float broadcast) and fixes the order with selects -- 6 v_cndmask per row, no scalar loads, no
 // branch.  2: padded modes, stored quads are whole.  3: VALID, where the stored range starts and ends inside a quad: four range-checked
 // dword stores per row for the lanes that hold such a quad.  (The edge strips on the scalar path cost the tile form 13 %:
 // profiles/r04_2d_tile_experiments.txt.)
@@ -201,10 +201,10 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
     // EDGE: a lane stores its quad when all of it lies in the stored range; PARTIAL: the floats of a quad that straddles the range's end
     const bool whole = !EDGE || (c0 >= xlo && c0 + 4 <= xhi);
     const unsigned col_off = (out_lane && whole) ? (unsigned)(c0 * 4) : 0x80000000u;
-    // (their dword stores go through a per-row descriptor that spans exactly the row's stored range [xlo, xhi): the hardware range check
-    //  drops the floats outside it, so one offset register serves all four)
-    //  (one register per float all the same, each laundered: left to see that the four offsets are consecutive, hipcc merges the four
-    //   dword stores into ONE dwordx4 store, whose range check then passes or fails as a whole -- the frame's border got written)
+    // (their four dword stores go through a per-row descriptor that spans exactly the row's stored range [xlo, xhi): the hardware range
+    //  check drops the floats outside it.  One offset register per float, each laundered: left to see that the four offsets are
+    //  consecutive, hipcc merges the four dword stores into ONE dwordx4 store, whose range check then passes or fails as a whole --
+    //  the frame's border got written, and test_config4_full_size_frames caught it)
     unsigned pcol_off[4] = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
     if constexpr (PARTIAL) {
 #pragma unroll
