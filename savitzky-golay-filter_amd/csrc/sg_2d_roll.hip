@@ -523,6 +523,15 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
 {
     if (box && nt == 2 && nout == 1 && n <= 7) return SG_ROLL_TILE_ROWS;
+    // half window 8: 16 + 16 rows do not fit three waves per SIMD, 10 + 16 do (with 20 bytes of scratch): 6.92 vs 7.61 ms per 256 frames
+    // (12 rows 6.93, 8 rows 7.21; profiles/r04_2d_tile_experiments.txt)
+    if (box && nt == 2 && nout == 1 && n == 8) return 10;
+    if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && n == 8) return 12;     // one term: 1.65 vs 1.97 ms per 64 frames (10 rows: 1.70)
+    // half windows 9, 10 (64 frames, ms, tile vs walk): n = 9 additive 1.97 vs 2.25, one term 1.85 vs 2.09 (10 rows; 8 rows 2.05 / 1.95);
+    // n = 10 additive 2.14 vs 2.31 (8 rows; 10 spill: 2.16), one term 1.91 vs 2.13 (10 rows, 20 bytes of scratch; 8 rows 2.04)
+    if (box && nt == 2 && nout == 1 && (n == 9 || n == 10)) return n == 9 ? 10 : 8;
+    if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && (n == 9 || n == 10)) return 10;
+    // (half windows 11, 12 spill 100-600 bytes at three waves per SIMD even on 6-row tiles: they keep the walk)
     if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt <= 2 && n <= 7) return SG_ROLL_TILE_ROWS;
     // the fused two- / three-output forms with one term per frame (gradient of order <= 2, Hessian of order <= 3): the three Hessian frames
     // of 64 x 4096^2 at n = 7 in 3.54 ms instead of 4.02 (2 waves per SIMD: 178 registers)
