@@ -694,3 +694,40 @@ def test_overlapping_frames_are_refused(sg, torch_gpu):
     rc = L.savgol2d_gradient_batch_f32(3, 3, 2, buf.data_ptr(), rows, cols, cols, rows * cols, gx.data_ptr(), buf.data_ptr(), cols, rows * cols, 1, 1.0, 1.0, 1, None)
     assert rc == -1 and "overlap" in sg.last_error()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n", [2, 5, 7, 8, 9, 10])
+def test_tile_kernel_edge_strips_on_aligned_narrow_and_ragged_frames(sg, sgo, torch_gpu, n):
+    """The tile form's frame-edge strips on vector loads (csrc/sg_2d_roll.hip, MODE 2 / 3; reference index fix-up src/savgol2d.c:428-445):
+    16-byte aligned frames whose width is a multiple of 4 -- narrower than one 240-column strip (BOTH frame edges inside one wave), just
+    over one, two and three strips, widths that leave 4 / 8 / 236 columns for the last strip -- and heights around the tile height
+    (fewer rows than a tile, one row more than a whole number of tiles), every boundary mode, the additive smoothing kernel and a
+    one-term derivative kernel.  Against the double-accumulation oracle, everything outside the stored range untouched; method 1
+    (reference order) on the same frame must agree to fp32 rounding as a second opinion."""
+    torch = torch_gpu
+    rng = np.random.default_rng(1000 + n)
+    for (dx, dy) in ((0, 0), (1, 1)):
+        f = sg.Filter2D(n, n, 3, dx, dy)
+        o = sgo.Filter2D(n, n, 3, dx, dy)
+        tol = TOL_SEP if (dx, dy) == (0, 0) else 4e-6
+        for rows, cols in ((2 * n + 3, 32), (33, 64), (16, 236), (17, 240), (47, 244), (33, 248), (40, 476), (2 * n + 1, 484), (35, 724)):
+            img = rng.normal(0, 1, (3, rows, cols)).astype(np.float32)
+            d = torch.from_numpy(img).cuda()
+            for b in (0, 1, 2):
+                if b == 0 and (rows <= 2 * n or cols <= 2 * n):
+                    continue
+                out = torch.full_like(d, -5.0)
+                f.apply_batch(d, out, rows, cols, 3, boundary=b, method=2)
+                ref1 = torch.full_like(d, -5.0)
+                f.apply_batch(d, ref1, rows, cols, 3, boundary=b, method=1)
+                torch.cuda.synchronize()
+                g, g1 = out.cpu().numpy(), ref1.cpu().numpy()
+                for k in (0, 2):
+                    hi = o.apply_f64acc(img[k], cols, b if b else 1)
+                    sel = np.ones((rows, cols), bool)
+                    if b == 0:
+                        sel[:] = False
+                        sel[n:rows - n, n:cols - n] = True
+                    assert np.all(g[k][~sel] == -5.0), (n, dx, rows, cols, b)
+                    assert normwise(g[k][sel], hi[sel]) < tol, (n, dx, rows, cols, b, normwise(g[k][sel], hi[sel]))
+                    assert np.abs(g[k][sel] - g1[k][sel]).max() <= 8e-6 * np.abs(hi[sel]).max(), (n, dx, rows, cols, b)
