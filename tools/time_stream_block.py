@@ -5,7 +5,7 @@ from __graft_entry__ import load_package
 sg = load_package()
 import torch
 
-S, T = 65536, int(os.environ.get("TICKS", "4096"))
+S, T = int(os.environ.get("STREAMS", "65536")), int(os.environ.get("TICKS", "4096"))
 x = torch.randn((T, S), device="cuda")
 out = torch.empty_like(x)
 for n, fma in [(n, f) for n in [int(v) for v in os.environ.get("HALF_WINDOWS", "4,8,16,17,24,32").split(",")] for f in (False, True)]:
