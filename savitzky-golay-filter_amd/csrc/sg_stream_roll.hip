@@ -397,10 +397,23 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
     }
     const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * 4u;
     job.strips = (unsigned)((job.streams + 127) / 128);
-    // one item per resident wave when the call is long enough (a band re-reads 2n warm-up rows: keep it >= 8 windows)
-    size_t bands = (nwaves + job.strips - 1) / job.strips;
+    // Bands of ticks: the resident waves take the strips x bands items round robin, so the call lasts (rounds of items) x (rows per band +
+    // 2n warm-up rows).  Rounds 1-3 took ceil(waves / strips) bands, which is right when the strips divide the waves (65 536 streams: 512
+    // strips, 4 bands, one round) and badly wrong next to it: 66 560 streams = 520 strips x 4 bands = 2080 items on 2048 waves -- a second
+    // round for 32 items, 0.595 ms where 65 536 streams take 0.44.  Now the band count with the cheapest (rounds x rows) is taken
+    // (a band re-reads 2n warm-up rows: keep it >= 8 windows).
     const size_t max_bands = job.ticks / (size_t)(8 * R::WS) > 0 ? job.ticks / (size_t)(8 * R::WS) : 1;
-    if (bands > max_bands) bands = max_bands;
+    size_t bands = 1;
+    {
+        double best = 1e300;
+        const size_t top = max_bands < 64 ? max_bands : 64;
+        for (size_t b = 1; b <= top; ++b) {
+            const size_t rows = (job.ticks + b - 1) / b + 2 * (size_t)N;
+            const size_t rounds = ((size_t)job.strips * b + nwaves - 1) / nwaves;
+            const double cost = (double)rounds * (double)rows;
+            if (cost < best * 0.999) { best = cost; bands = b; }
+        }
+    }
     job.band_ticks = (int)((job.ticks + bands - 1) / bands);
     job.bands = (unsigned)((job.ticks + (size_t)job.band_ticks - 1) / (size_t)job.band_ticks);
     const unsigned long long total = (unsigned long long)job.strips * job.bands;
