@@ -32,6 +32,21 @@
 
 namespace sg {
 
+#ifdef SG_STAMPS2D   // diagnostic build only (tools/stamp_2d.py): s_memtime stamps of ONE wave's phases.  Never timed as a product number.
+__device__ unsigned long long *g_stamps2d;
+__device__ __forceinline__ void stamp2d(bool on, int slot)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (on && slot < 512 && (threadIdx.x & 63) == 0) g_stamps2d[slot] = t;
+}
+#define SG_STAMP2D(slot) stamp2d(stamp_on && (slot) < 128, stamp_base + (slot))
+#else
+#define SG_STAMP2D(slot) do {} while (0)
+#endif
+
 // TR > 0: TILE form (round 4).  The item is TR output rows; ALL its TR + 2N input rows are loaded up front (P = TR - 1 rows "ahead"),
 // the row loop runs once over literal slots and the wave exits: short-lived waves handed out in address order, the 1-D kernel's life
 // cycle.  The 2N halo rows are read again by the tile below -- out of L2 when blocks that share an XCD take neighbouring tiles.
@@ -451,9 +466,18 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
         });
     };
 
+#ifdef SG_STAMPS2D
+    // four candidate waves mid-launch (blocks 8 apart: one XCD), each with its own 128 slots; the tool reads the first that was an interior strip
+    const unsigned stamp_c = (blockIdx.x - (gridDim.x / 2 & ~7u)) >> 3;
+    const bool stamp_on = MODE == 1 && (blockIdx.x & 7u) == 0 && blockIdx.x >= (gridDim.x / 2 & ~7u) && stamp_c < 4 && (threadIdx.x >> 6) == 0;
+    const int stamp_base = (int)(stamp_c & 3u) * 128;
+#endif
+    SG_STAMP2D(0);
 #pragma unroll
     for (int r = 0; r < R::U; ++r) win[r] = load_row(r);         // rows 0..2N for the first output row, P more in flight
+    SG_STAMP2D(1);                                               // all the item's first loads are issued
     vertical(std::integral_constant<int, 0>{}, 0);
+    SG_STAMP2D(2);                                               // rows 0..2N have arrived and row 0's vertical pass is done
     if constexpr (ACC) {
 #pragma unroll
         for (int j = 0; j < LEAD; ++j) prevq[j] = load_prev(yb + j);
@@ -467,8 +491,10 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             if constexpr (NB == 2) fetch(std::integral_constant<int, 0>{}, uu & 1);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (uu + 1 < TR) vertical(std::integral_constant<int, uu + 1>{}, (uu + 1) & 1);
+            SG_STAMP2D(3 + 2 * uu);                              // row uu+1's input has arrived, its vertical pass is done
             __builtin_amdgcn_sched_barrier(0);
             finish_row(uu & 1, yb + uu, f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+            SG_STAMP2D(4 + 2 * uu);                              // row uu's horizontal pass is done, its store issued
             return true;
         });
         return;
@@ -487,9 +513,11 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             if constexpr (NB == 2) fetch(std::integral_constant<int, 0>{}, uu & 1);     // ... and its first window is on its way while row m's vertical pass runs
             __builtin_amdgcn_sched_barrier(0);
             vertical(std::integral_constant<int, (uu + 1) % R::U>{}, (uu + 1) & 1);
+            SG_STAMP2D(3 + 2 * (m - 1));
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (ACC) finish_row(uu & 1, yb + m - 1, prevq[uu % PR]);
             else finish_row(uu & 1, yb + m - 1, f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+            SG_STAMP2D(4 + 2 * (m - 1));
             return true;
         });
     }
@@ -879,5 +907,15 @@ int SEP_ROLL_FN3(int n, int terms, const Job2D &job, const float *f0, float s0, 
     const float ss[3] = {s0, s1, s2};
     return dispatch_roll3<SEP_ROLL_MIN_N, 1>(n, terms, job, ff, ss, out1, out2, images, cu_count, st);
 }
+
+#ifdef SG_STAMPS2D
+}  // namespace sg
+extern "C" __attribute__((visibility("default"))) int savgol_hip_debug_set_stamps2d(void *d_buffer_512_u64)
+{
+    unsigned long long *p = static_cast<unsigned long long *>(d_buffer_512_u64);
+    return hipMemcpyToSymbol(HIP_SYMBOL(sg::g_stamps2d), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+namespace sg {
+#endif
 
 }  // namespace sg
