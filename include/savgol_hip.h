@@ -53,7 +53,7 @@ extern "C" {
 int         savgol_hip_device_count(void);          /* usable HIP devices (0 = none)       */
 int         savgol_hip_set_device(int ordinal);     /* device used by THIS thread's calls  */
 int         savgol_hip_get_device(void);
-int         savgol_hip_synchronize(void *stream);       /* also hands unused scratch back to the driver (savgol_hip_trim_scratch) */
+int         savgol_hip_synchronize(void *stream);       /* hipStreamSynchronize; the scratch pool keeps its threshold (savgol_hip_trim_scratch hands it back) */
 /* Calls that need a temporary frame (staged strided path, reference-order batches, channel ends of very long channels, row-band strips)
  * take it from the library's own stream-ordered pool, which keeps up to 256 MiB of freed blocks for the next call
  * (SAVGOL_HIP_SCRATCH_KEEP_MB).  This returns every unused byte of it to the driver now.  0 / -1. */
@@ -304,6 +304,12 @@ int savgol_hip_synth_f32(float *d_dst, size_t channel0, size_t channels, size_t 
                          uint64_t seed, void *stream);
 int savgol_hip_synth_f64(double *d_dst, size_t channel0, size_t channels, size_t length, size_t ld,
                          uint64_t seed, void *stream);
+
+/* What the memory system gives a plain stream of the same buffers, for the bench line's roofline.copy_frac / read_only_frac (SURVEY.md 8d:
+ * "a device copy timed in the same harness"): one 16-byte nontemporal vector per thread.  bytes and both addresses multiples of 16.
+ * _read stores nothing (d_sink4 may be NULL; 4 bytes that are never written in practice).  Enqueue only.  0 / -1. */
+int savgol_hip_stream_copy(const void *d_in, void *d_out, size_t bytes, void *stream);
+int savgol_hip_stream_read(const void *d_in, size_t bytes, void *d_sink4, void *stream);
 
 #ifdef __cplusplus
 }

@@ -159,13 +159,59 @@ static int dense_kernel_env()
 // input and read-modify-writes the output -- 20 B per pixel instead of 8 -- which these arithmetic-bound shapes can afford: order 6
 // at n = 9 / 12 / 16: 1.83 / 2.25 / 3.15 ms per 16 frames on the tile kernel, two rolling passes 1.5-2 x faster (profiles/
 // r03_sweep_2d_orders.txt).  0 = launched, 1 = not covered.  `n` = the (larger) half window the factors are laid out for.
-// do the byte ranges of two frame batches intersect?
+// Do two frame batches share a byte?  EXACT for strided layouts (round 4 compared the bounding byte ranges only, which refused
+// side-by-side views of one buffer -- in = buf[:, :cols], out = buf[:, cols:], stride 2 cols -- and frames interleaved at a common pitch).
+// Units below are floats relative to `a`; a batch is the set { i*pitch + r*stride + c : i < images, r < rows, c < cols }.
+static bool rows_share(long long a, long long sa, long long b, long long sb, int rows, int cols)
+{
+    // two single frames: merge their row intervals in address order (strides are >= cols, so each frame's rows are sorted and disjoint)
+    int ia = 0, ib = 0;
+    while (ia < rows && ib < rows) {
+        const long long a0 = a + ia * sa, b0 = b + ib * sb;
+        if (a0 < b0 + cols && b0 < a0 + cols) return true;
+        if (a0 + cols <= b0 + cols) ++ia; else ++ib;
+    }
+    return false;
+}
 static bool frames_overlap(const float *a, long long a_pitch, int a_stride, const float *b, long long b_pitch, int b_stride, int rows, int cols, size_t images)
 {
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(a), b0 = reinterpret_cast<uintptr_t>(b);
-    const uintptr_t a1 = a0 + sizeof(float) * ((size_t)(images - 1) * (size_t)a_pitch + (size_t)(rows - 1) * (size_t)a_stride + (size_t)cols);
-    const uintptr_t b1 = b0 + sizeof(float) * ((size_t)(images - 1) * (size_t)b_pitch + (size_t)(rows - 1) * (size_t)b_stride + (size_t)cols);
-    return a0 < b1 && b0 < a1;
+    const long long a_frame = (long long)(rows - 1) * a_stride + cols, b_frame = (long long)(rows - 1) * b_stride + cols;      // floats one frame spans
+    const uintptr_t a1 = a0 + sizeof(float) * ((size_t)(images - 1) * (size_t)a_pitch + (size_t)a_frame);
+    const uintptr_t b1 = b0 + sizeof(float) * ((size_t)(images - 1) * (size_t)b_pitch + (size_t)b_frame);
+    if (!(a0 < b1 && b0 < a1)) return false;                                    // bounding ranges apart: the common case
+    // layouts this test does not model exactly are refused as before: bases a fraction of a float apart, frames of one batch running into
+    // each other, negative pitches
+    if ((a0 > b0 ? a0 - b0 : b0 - a0) % sizeof(float) != 0) return true;
+    if (images > 1 && (a_pitch < a_frame || b_pitch < b_frame)) return true;
+    const long long delta = (a0 > b0 ? (long long)((a0 - b0) / sizeof(float)) : -(long long)((b0 - a0) / sizeof(float)));     // a - b in floats
+    if (a_stride == b_stride && (images == 1 || a_pitch == b_pitch)) {
+        // equal strides and pitches: frame i row r col c of `a` meets frame i' row r' col c' of `b` iff
+        // delta = di*pitch + dr*stride + dc with |di| < images, |dr| < rows, |dc| < cols.  Frames and rows of one batch do not run into
+        // each other (pitch >= frame span, stride >= cols), so only two candidates per level can match.
+        const long long s = a_stride, p = images > 1 ? a_pitch : 0;
+        auto fdiv = [](long long x, long long y) { long long q = x / y; if ((x % y != 0) && ((x < 0) != (y < 0))) --q; return q; };
+        for (int ci = 0; ci < (images > 1 ? 2 : 1); ++ci) {
+            const long long di = images > 1 ? fdiv(-delta, p) + ci : 0;
+            if (di <= -(long long)images || di >= (long long)images) continue;
+            const long long rem = -delta - di * p;                                // = dr*stride + dc
+            for (int cr = 0; cr < 2; ++cr) {
+                const long long dr = fdiv(rem, s) + cr;
+                if (dr <= -(long long)rows || dr >= (long long)rows) continue;
+                const long long dc = rem - dr * s;
+                if (dc > -(long long)cols && dc < (long long)cols) return true;
+            }
+        }
+        return false;
+    }
+    // different strides or pitches: merge the frames' spans in address order, rows of the frame pairs whose spans intersect
+    size_t ia = 0, ib = 0;
+    while (ia < images && ib < images) {
+        const long long fa = delta + (long long)ia * a_pitch, fb = (long long)ib * b_pitch;
+        if (fa < fb + b_frame && fb < fa + a_frame && rows_share(fa, a_stride, fb, b_stride, rows, cols)) return true;
+        if (fa + a_frame <= fb + b_frame) ++ia; else ++ib;
+    }
+    return false;
 }
 
 static int roll_passes(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)

@@ -24,8 +24,19 @@
 #include <cstdio>
 
 #include "savgol_hip_rccl.h"
+#include "sg_exchange_order.hpp"
 
 namespace {
+
+// RCCL as the transport of sg::exchange_post (the posting order lives in sg_exchange_order.hpp, where a CPU test can run it too)
+struct RcclTransport {
+    ncclComm_t comm;
+    hipStream_t st;
+    bool group_start() { return ncclGroupStart() == ncclSuccess; }
+    bool group_end() { return ncclGroupEnd() == ncclSuccess; }
+    bool send(const void *p, size_t words, int peer) { return ncclSend(p, words, ncclUint32, peer, comm, st) == ncclSuccess; }
+    bool recv(void *p, size_t words, int peer) { return ncclRecv(p, words, ncclUint32, peer, comm, st) == ncclSuccess; }
+};
 
 // words = 4-byte units.  Block (o, r) of `cols` words at src + o * pitch + r * stride  ->  dst + (o * rows + r) * cols
 __global__ __launch_bounds__(256) void pack_rows_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, long long pitch, long long stride, int rows, int cols)
@@ -51,8 +62,7 @@ bool pack(uint32_t *dst, const uint32_t *src, long long pitch, long long stride,
 }
 
 // first = the block next to the cut towards peer_a (sent to a), last = the block next to the cut towards peer_b (sent to b).
-// recv_a <- what a sends towards us (its LAST block), recv_b <- b's FIRST block.  When both peers are the same rank (a ring of two,
-// or a single rank talking to itself) the pair's messages match in posting order, so the receives are posted b first.
+// recv_a <- what a sends towards us (its LAST block), recv_b <- b's FIRST block; the posting order is sg::exchange_post's (sg_exchange_order.hpp).
 int exchange(ncclComm_t comm, int peer_a, int peer_b, const uint32_t *first, const uint32_t *last, long long pitch, long long stride, size_t outer,
              int rows, int cols, uint32_t *recv_a, uint32_t *recv_b, uint32_t *scratch, hipStream_t st)
 {
@@ -62,20 +72,8 @@ int exchange(ncclComm_t comm, int peer_a, int peer_b, const uint32_t *first, con
     uint32_t *send_a = scratch, *send_b = scratch + per_side;
     if (a && !pack(send_a, first, pitch, stride, outer, rows, cols, st)) return -1;
     if (b && !pack(send_b, last, pitch, stride, outer, rows, cols, st)) return -1;
-    if (!a && !b) return 0;
-    if (ncclGroupStart() != ncclSuccess) return -1;
-    bool ok = true;
-    if (a) ok = ok && ncclSend(send_a, per_side, ncclUint32, peer_a, comm, st) == ncclSuccess;
-    if (b) ok = ok && ncclSend(send_b, per_side, ncclUint32, peer_b, comm, st) == ncclSuccess;
-    if (a && b && peer_a == peer_b) {
-        ok = ok && ncclRecv(recv_b, per_side, ncclUint32, peer_b, comm, st) == ncclSuccess &&
-             ncclRecv(recv_a, per_side, ncclUint32, peer_a, comm, st) == ncclSuccess;
-    } else {
-        if (a) ok = ok && ncclRecv(recv_a, per_side, ncclUint32, peer_a, comm, st) == ncclSuccess;
-        if (b) ok = ok && ncclRecv(recv_b, per_side, ncclUint32, peer_b, comm, st) == ncclSuccess;
-    }
-    if (ncclGroupEnd() != ncclSuccess) return -1;
-    return ok ? 0 : -1;
+    RcclTransport t{comm, st};
+    return sg::exchange_post(t, peer_a, peer_b, send_a, send_b, recv_a, recv_b, per_side);
 }
 
 }  // namespace

@@ -182,30 +182,39 @@ int savgol_hip_get_device(void)
     return d;
 }
 
+// the context of the calling thread's current device if one exists (never creates it); g_ctx is read under its creation lock
+static sg::DeviceCtx *current_ctx()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(sg::g_mu);
+    return sg::g_ctx[dev];
+}
+
+// Synchronises the stream and nothing else.  (Round 4 also trimmed the scratch pool to ZERO here: a caller that synchronises once per step on
+// a scratch-using path -- staged strided calls, reference-order batches, row-band strips -- then paid a driver unmap / remap of its staging
+// frames every iteration, ADVICE r04.  The pool returns everything above its keep threshold at this synchronise by itself; handing back the
+// rest is savgol_hip_trim_scratch()'s job.)
 int savgol_hip_synchronize(void *stream)
 {
-    if (!sg::hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize")) return -1;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && sg::g_ctx[dev]) (void)sg::scratch_trim(sg::g_ctx[dev]);
-    return 0;
+    return sg::hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize") ? 0 : -1;
 }
 
 size_t savgol_hip_scratch_reserved(void)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !sg::g_ctx[dev]) return 0;
-    std::lock_guard<std::recursive_mutex> lock(sg::g_ctx[dev]->mu);
+    sg::DeviceCtx *ctx = current_ctx();
+    if (!ctx) return 0;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     uint64_t reserved = 0;
-    if (!sg::g_ctx[dev]->pool || hipMemPoolGetAttribute(static_cast<hipMemPool_t>(sg::g_ctx[dev]->pool), hipMemPoolAttrReservedMemCurrent, &reserved) != hipSuccess) return 0;
+    if (!ctx->pool || hipMemPoolGetAttribute(static_cast<hipMemPool_t>(ctx->pool), hipMemPoolAttrReservedMemCurrent, &reserved) != hipSuccess) return 0;
     return (size_t)reserved;
 }
 
 int savgol_hip_trim_scratch(void)
 {
-    int dev = 0;
-    if (!sg::hip_ok(hipGetDevice(&dev), "hipGetDevice")) return -1;
-    if (dev < 0 || dev >= 64 || !sg::g_ctx[dev]) return 0;
-    return sg::scratch_trim(sg::g_ctx[dev]);
+    sg::DeviceCtx *ctx = current_ctx();
+    return ctx ? sg::scratch_trim(ctx) : 0;
 }
 
 int savgol_hip_shard_range(size_t total, int world_size, int rank, size_t *lo, size_t *hi)

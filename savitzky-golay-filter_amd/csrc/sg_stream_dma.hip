@@ -1,0 +1,294 @@
+// sg_stream_dma.hip -- savgol_streambank_push_block, LDS-DMA tile form (round 5).
+//
+// Reference loop: src/savgol_stream.c:25-38 (the ring dot product) driven by :152-178 (one push per sample) -- here `ticks` pushes of
+// every stream in one launch, a convolution down the tick axis of samples[tick][stream].
+//
+// Why another form.  The walk (sg_bank_roll_kernel) keeps few rows in flight per wave; the register tiles (sg_bank_tile_kernel) load
+// TR + 2n rows up front but hold them ALL in VGPRs until the last output is done (212 registers at n = 16: two waves per SIMD), and a
+// wave that computes issues no memory traffic -- bare, that access pattern streams at 0.72-0.73 of 8 TB/s, with the arithmetic in it at
+// 0.60-0.66 (tools/membench_streamtile.hip, profiles/r05_membench_streamtile.txt).  Here the rows never touch a VGPR on their way in:
+//   * a wave owns 128 adjacent streams (a lane 2 = one 8-byte LDS read per row) x TR ticks and a private LDS slab of TR + 2n rows;
+//   * it issues every row load up front as LDS-DMA (global_load_lds_dwordx4: 1 KiB = two 512-byte rows per instruction, no VGPR
+//     destination), then consumes the rows IN ARRIVAL ORDER behind counted s_waitcnt vmcnt(k): each arriving row is read once from the
+//     slab and fed into every accumulator it touches ("input stationary": row r is tap r - m of output m).  The arithmetic overlaps the
+//     arrival of the later rows inside ONE wave, registers hold only the TR accumulators, and a finished output row is stored at once;
+//   * per output the arithmetic is bank_roll_item's, bit for bit in both banks: reference order = one accumulator from 0, taps ascending,
+//     multiply and add rounded separately (rows arrive in ascending tap order for every output); FMA = two chains (even / odd taps);
+//   * tiles are dealt like the register tiles': blocks that share an XCD walk down a group of neighbouring strips band by band, so the 2n
+//     halo rows a tile shares with the one above are L2 hits.
+// Bare, this pattern streams at 0.75-0.76 (the flat copy on the same box: 0.79).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#include "sg_internal.h"
+#include "sg_pk.hpp"
+#include "sg_runtime.hpp"
+#include "sg_stream_roll.hpp"
+
+namespace sg {
+
+#ifndef SG_DMA_WPB
+#define SG_DMA_WPB 4                                         // waves per block (independent: only how waves are dealt to CUs and how LDS is carved)
+#endif
+#ifndef SG_DMA_MAX_N
+#define SG_DMA_MAX_N 16
+#endif
+
+// output ticks per tile TR: the slab is TR + 2n rows of 512 bytes, the accumulators 2 (reference order) or 4 (two FMA chains) VGPRs per tick
+template <int N, int TR_> struct DmaShape {
+    static constexpr int TR = TR_;
+    static constexpr int ROWS = TR + 2 * N, NI = ROWS / 2, RB = 512, SLAB = ROWS * RB;
+    static_assert(TR % 2 == 0, "a DMA instruction moves two rows");
+};
+// defaults (A/B'd on config 3's shape, profiles/r05_stream_dma.txt)
+#ifndef SG_DMA_TR
+#define SG_DMA_TR 32
+#endif
+#ifndef SG_DMA_PAIRS
+#define SG_DMA_PAIRS 16                                      // row pairs (KiB) of LDS ring per wave = how far the row loads run ahead of the arithmetic
+#endif
+
+template <int K> __device__ __forceinline__ void wait_vm()
+{
+    static_assert(K >= 0 && K < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K) : "memory");
+}
+
+// one 1 KiB LDS-DMA: lane l's 16 bytes land at lds_dst + 16 l.  Inline asm (the compiler then neither counts it nor drains it at the
+// first LDS read: the waits are counted by hand below); M0 is the compiler's, so it is saved and restored in the same statement.
+__device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// vmcnt bookkeeping, all at compile time.  The wave's vector-memory queue, in issue order: the DP DMAs of the prologue, then per step j
+// (= row pair j): the stores of the outputs that rows 2j, 2j + 1 finish, then DMA j + DP (if that pair exists).
+template <int N, int TR, int DP> struct DmaQueue {
+    static constexpr int NI = (TR + 2 * N) / 2;
+    static constexpr int done(int r) { return r - 2 * N < 0 ? 0 : (r - 2 * N > TR ? TR : r - 2 * N); }     // outputs finished by rows < r = stores issued
+    static constexpr int dmas(int a, int b) { int c = 0; for (int j = a; j < b; ++j) c += (j >= 0 && j + DP < NI) ? 1 : 0; return c; }  // DMAs issued by steps [a, b)
+    // operations younger than DMA p when step g starts (p = g + 1 is the pair step g waits for)
+    static constexpr int younger(int p, int g)
+    {
+        if (p < DP) return (DP - 1 - p) + done(2 * g) + dmas(0, g);                     // a prologue DMA: the rest of the prologue, then every step so far
+        const int born = p - DP;                                                        // issued at the END of step `born`
+        return (done(2 * g) - done(2 * born + 2)) + dmas(born + 1, g);
+    }
+};
+
+template <int N, bool FMA, int TRT, int WPB, int DP, int FCH = 2>
+__global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job, const SRollTaps<N> taps, const TileGeom geo)
+{
+    typedef SRoll<N> R;
+    typedef DmaShape<N, TRT> D;
+    typedef DmaQueue<N, TRT, DP> Q;
+    constexpr int TR = D::TR, NI = D::NI, RB = D::RB, RING = DP * 1024;
+    static_assert(DP >= 2 && DP <= NI, "ring of row pairs");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned nblk = gridDim.x;
+    const unsigned blk = (job.aligned & 2) ? blockIdx.x : (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const unsigned t = blk * WPB + (unsigned)wv;                                          // the launch keeps the tile count below 2^31
+    if (t >= (unsigned)geo.total) return;
+    // tile order: groups of `group` neighbouring strips; inside a group band after band, strips fastest (32-bit scalar divisions)
+    const unsigned per_group = geo.group * geo.bands;
+    const unsigned grp = t / per_group;
+    const unsigned rem = t - grp * per_group;
+    const unsigned gs = geo.strips - grp * geo.group < geo.group ? geo.strips - grp * geo.group : geo.group;
+    const unsigned band = rem / gs, strip = grp * geo.group + (rem - band * gs);
+    if (band >= geo.bands) return;
+    const long long t0 = (long long)band * TR;
+    const unsigned ring = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)lds) + (unsigned)wv * (unsigned)RING;   // LDS byte address, wave-uniform
+    const int sub = lane >> 5, chunk = lane & 31;                                                 // row of the pair, 16-byte chunk of the row
+    const size_t col = (size_t)strip * 128 + (size_t)chunk * 4;
+
+    // source of row pair i: slab row r = history index t0 - 2N + r (history: ring contents, then this call's samples)
+    const bool inside = t0 >= 2 * N && t0 + TR <= (long long)job.ticks;                           // uniform: every row is one of this call's samples
+    const float *const p0 = job.samples + (size_t)(inside ? t0 - 2 * N + sub : 0) * job.streams + col;
+    const size_t pstep = 2 * job.streams;
+    auto issue = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const float *src;
+        if (inside) {
+            src = p0 + (size_t)i * pstep;
+        } else {
+            long long h = t0 - 2 * N + 2 * i + sub;
+            if (h >= (long long)job.ticks) h = (long long)job.ticks - 1;                          // past the call: loaded, never used
+            int slot = job.wp0 + (int)(h < 0 ? h : 0);
+            slot = slot < 0 ? slot + R::WS : slot;
+            src = (h >= 0 ? job.samples + (size_t)h * job.streams : job.ring + (size_t)slot * job.streams) + col;
+        }
+        dma16(src, ring + (unsigned)(i % DP) * 1024u);
+    };
+    static_for<DP>([&](auto ic) -> bool { issue(ic); return true; });
+
+    // ---- consume the rows in arrival order ----
+    const char *mine = lds + (size_t)wv * RING + lane * 8;
+    const int row_bytes = (int)(job.streams * 4);
+    const unsigned voff = (strip * 128u + 2u * (unsigned)lane) * 4u;                              // byte offset of this lane's streams in a row
+    constexpr int CH = FMA ? FCH : 1;                                                             // FMA bank: two chains (even / odd taps) or one
+    f32x2 acc[CH][TR];
+    auto row_in = [&](auto rc) -> f32x2 {
+        constexpr int r = decltype(rc)::value;
+        return *reinterpret_cast<const f32x2 *>(mine + ((r / 2) % DP) * 1024 + (r & 1) * RB);
+    };
+    auto feed = [&](auto rc, const f32x2 x) {
+        constexpr int r = decltype(rc)::value;
+        constexpr int mlo = r - 2 * N > 0 ? r - 2 * N : 0, mhi = r < TR - 1 ? r : TR - 1;
+        if constexpr (FMA) {
+            static_for<mhi - mlo + 1>([&](auto ic) -> bool {
+                constexpr int m = mlo + decltype(ic)::value, k = r - m;
+                // two chains (even taps, odd taps), one v_pk_fma_f32 per tap: bank_roll_item's fast form, bit for bit -- or ONE chain in the
+                // reference's order (taller tiles fit the registers; each term rounds once where the reference rounds twice)
+                if constexpr (k < CH) acc[k][m] = pk_mul_sgpr<k>(taps.w[0], x);
+                else pk_fma_sgpr<(k & 1)>(acc[(k & 1) % CH][m], taps.w[k >> 1], x);
+                return true;
+            });
+        } else {
+            // the reference's order (src/savgol_stream.c:25-38): sum = 0; sum += w[k] * x[k], k ascending, product and sum rounded separately.
+            // Volatile asm for products and sums alike, each product issued one output ahead of its sum: left to the compiler, all the
+            // products of a row are hoisted in front of the sums and stay live (256 registers and scratch; see bank_accroll_item)
+            f32x2 p;
+            {
+                constexpr int k0 = r - mlo;
+                if constexpr ((k0 & 1) == 0) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(taps.w[k0 >> 1]), "v"(x));
+                else                         asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(p) : "s"(taps.w[k0 >> 1]), "v"(x));
+            }
+            static_for<mhi - mlo + 1>([&](auto ic) -> bool {
+                constexpr int m = mlo + decltype(ic)::value, k = r - m;
+                f32x2 pn = p;
+                if constexpr (m < mhi) {
+                    constexpr int kn = k - 1;
+                    if constexpr ((kn & 1) == 0) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(pn) : "s"(taps.w[kn >> 1]), "v"(x));
+                    else                         asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(pn) : "s"(taps.w[kn >> 1]), "v"(x));
+                }
+                if constexpr (k == 0) asm volatile("v_pk_add_f32 %0, %1, 0 op_sel_hi:[1,0]" : "=v"(acc[0][m]) : "v"(p));       // 0 + p: a product of -0 sums to +0, as in the reference
+                else                  asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[0][m]) : "v"(p));
+                p = pn;
+                return true;
+            });
+        }
+        if constexpr (r >= 2 * N && r - 2 * N < TR) {                                             // output m = r - 2N has seen its last row
+            constexpr int m = r - 2 * N;
+            f32x2 a = acc[0][m];
+            if constexpr (CH == 2) a = a + acc[1][m];
+            const long long tt = t0 + m;
+            const bool has_out = tt < (long long)job.ticks && job.received0 + (unsigned long long)tt + 1 >= (unsigned long long)R::WS;   // uniform (reference :166-170)
+            const f32x2 y = a * f32x2{job.dt_inv, job.dt_inv};
+            float *orow = job.out + (size_t)(tt < (long long)job.ticks ? tt : 0) * job.streams;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow, 0, has_out ? row_bytes : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), rs, (int)voff, 0, 0);
+        }
+    };
+    // Step g consumes pair g (already in xa, xb), after it has waited for pair g + 1 and issued its LDS reads (their latency hides behind
+    // the arithmetic), and ends by issuing DMA g + DP into the ring slot pair g has just left.  A row without an output still issues its
+    // store (into an empty descriptor), so the queue arithmetic above is static.
+    wait_vm<Q::younger(0, 0)>();
+    f32x2 xa = row_in(std::integral_constant<int, 0>{}), xb = row_in(std::integral_constant<int, 1>{});
+    static_for<NI>([&](auto gc) -> bool {
+        constexpr int g = decltype(gc)::value;
+        f32x2 na = xa, nb = xb;
+        if constexpr (g + 1 < NI) {
+            wait_vm<Q::younger(g + 1, g)>();
+            na = row_in(std::integral_constant<int, 2 * g + 2>{});
+            nb = row_in(std::integral_constant<int, 2 * g + 3>{});
+            __builtin_amdgcn_sched_barrier(0);                                                    // keep these reads AHEAD of pair g's arithmetic (left alone, hipcc sinks them to their use)
+        }
+        feed(std::integral_constant<int, 2 * g>{}, xa);
+        feed(std::integral_constant<int, 2 * g + 1>{}, xb);
+        if constexpr (g + DP < NI) {
+            // pair g's slot is free: its two LDS reads were issued a step ago and their data has just been consumed -- but "consumed" is the
+            // compiler's business, so drain the LDS queue explicitly before the DMA may overwrite the slot
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue(std::integral_constant<int, g + DP>{});
+        }
+        xa = na; xb = nb;
+        return true;
+    });
+}
+
+template <int N, bool FMA, int TRT, int WPB, int DPR, int FCH = 2>
+static int launch_bank_dma(const float *center, BankJob job, hipStream_t st)
+{
+    typedef SRoll<N> R;
+    typedef DmaShape<N, TRT> D;
+    SRollTaps<N> taps;
+    memset(&taps, 0, sizeof(taps));
+    for (int k = 0; k < R::WS; ++k) {
+        if (k & 1) taps.w[k >> 1].y = center[k]; else taps.w[k >> 1].x = center[k];
+    }
+    TileGeom geo;
+    geo.strips = (unsigned)(job.streams / 128);
+    geo.bands = (unsigned)((job.ticks + D::TR - 1) / D::TR);
+    static const int group_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_GROUP"); return e ? atoi(e) : 0; }();
+    geo.group = group_env > 0 ? (unsigned)group_env : 128u;                                      // 64 KiB of a tick row
+    if (geo.group > geo.strips) geo.group = geo.strips;
+    const unsigned groups = (geo.strips + geo.group - 1) / geo.group;
+    geo.total = (unsigned long long)groups * geo.group * geo.bands;
+    const unsigned long long blocks = (geo.total + WPB - 1) / WPB;
+    if (geo.total >= 0x7fffff00ull) return 1;
+    const unsigned grid = ((unsigned)blocks + 7u) & ~7u;
+    static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_XCD"); return e ? atoi(e) : 1; }();
+    job.aligned = 1 | (xcd_env ? 0 : 2);
+    constexpr int DP = DPR < D::NI ? DPR : D::NI;                                                 // ring of row pairs (all of the tile's pairs: every load up front)
+    constexpr size_t lds = (size_t)WPB * DP * 1024;
+    static_assert(lds <= 160 * 1024, "slabs of one block must fit the CU's LDS");
+    static const bool attr_ok = [] {
+        return lds <= 65536 || hipFuncSetAttribute(reinterpret_cast<const void *>(sg_bank_dma_kernel<N, FMA, TRT, WPB, DP, FCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    }();
+    if (!attr_ok) return 1;
+    hipLaunchKernelGGL((sg_bank_dma_kernel<N, FMA, TRT, WPB, DP, FCH>), dim3(grid), dim3(64 * WPB), lds, st, job, taps, geo);
+    return 0;
+}
+
+template <int N, bool FMA>
+static int launch_bank_dma_shape(const float *center, const BankJob &job, hipStream_t st)
+{
+#ifdef SG_DMA_EXPERIMENT        // A/B build: tile height and waves per block picked per process (tools/experiments.sh stream_dma)
+    static const int tr = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_TR"); return e ? atoi(e) : SG_DMA_TR; }();
+    static const int wpb = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_WPB"); return e ? atoi(e) : SG_DMA_WPB; }();
+    static const int dp = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_PAIRS"); return e ? atoi(e) : SG_DMA_PAIRS; }();
+    static const int fch = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_CHAINS"); return e ? atoi(e) : 2; }();
+#define SG_DMA_TRY(T, W, P) if (tr == T && wpb == W && dp == P && fch == 2) return launch_bank_dma<N, FMA, T, W, P, 2>(center, job, st);
+#define SG_DMA_TRY1(T, W, P) if (tr == T && wpb == W && dp == P && fch == 1) return launch_bank_dma<N, FMA, T, W, P, 1>(center, job, st);
+    SG_DMA_TRY(32, 4, 16) SG_DMA_TRY(32, 4, 8) SG_DMA_TRY(32, 4, 12) SG_DMA_TRY(32, 8, 8) SG_DMA_TRY(64, 4, 16) SG_DMA_TRY(64, 4, 8) SG_DMA_TRY(64, 4, 12)
+    SG_DMA_TRY(48, 4, 8) SG_DMA_TRY(48, 4, 12) SG_DMA_TRY(96, 4, 12) SG_DMA_TRY(64, 8, 8) SG_DMA_TRY(64, 2, 12) SG_DMA_TRY(128, 4, 12)
+    SG_DMA_TRY1(32, 4, 8) SG_DMA_TRY1(32, 4, 12) SG_DMA_TRY1(64, 4, 8) SG_DMA_TRY1(64, 4, 12) SG_DMA_TRY1(64, 4, 16) SG_DMA_TRY1(96, 4, 12) SG_DMA_TRY1(64, 8, 8)
+    SG_DMA_TRY1(48, 4, 12) SG_DMA_TRY1(128, 4, 12) SG_DMA_TRY1(64, 2, 12)
+#undef SG_DMA_TRY1
+#undef SG_DMA_TRY
+#endif
+    return launch_bank_dma<N, FMA, SG_DMA_TR, SG_DMA_WPB, SG_DMA_PAIRS>(center, job, st);
+}
+
+template <int N>
+static int dispatch_bank_dma(int n, int fma, const float *center, const BankJob &job, hipStream_t st)
+{
+    if (n == N) return fma ? launch_bank_dma_shape<N, true>(center, job, st) : launch_bank_dma_shape<N, false>(center, job, st);
+    if constexpr (N < SG_DMA_MAX_N) return dispatch_bank_dma<N + 1>(n, fma, center, job, st);
+    else return 1;
+}
+
+#ifndef SG_DMA_MIN_N
+#define SG_DMA_MIN_N 1
+#endif
+
+// 0 = launched; 1 = not covered: half window outside [SG_DMA_MIN_N, SG_DMA_MAX_N], streams not a multiple of 128, rows not 16-byte aligned or
+// 2 GiB and longer (the store descriptors), or fewer than two tiles of ticks
+int sg_bank_dma_launch(int n, int fma, const float *center, const BankJob &job, int /*cu_count*/, hipStream_t st)
+{
+    if (n < SG_DMA_MIN_N || n > SG_DMA_MAX_N) return 1;
+    if (job.streams % 128 != 0 || job.streams * 4 >= 0x7fffff00ull) return 1;
+    if (((reinterpret_cast<uintptr_t>(job.samples) | reinterpret_cast<uintptr_t>(job.out) | reinterpret_cast<uintptr_t>(job.ring)) & 15u) != 0) return 1;
+    if (job.ticks < 64) return 1;
+    return dispatch_bank_dma<SG_DMA_MIN_N>(n, fma, center, job, st);
+}
+
+}  // namespace sg

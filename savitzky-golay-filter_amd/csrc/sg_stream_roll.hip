@@ -22,42 +22,9 @@
 #include "sg_pk.hpp"
 #include "sg_runtime.hpp"
 #include "sg_stream.hpp"
+#include "sg_stream_roll.hpp"
 
 namespace sg {
-
-template <int N>
-struct SRoll {
-    static constexpr int WS = 2 * N + 1;
-    // rows loaded ahead of the arithmetic (A/B builds override).  Round 3, after the counters had said that a walk is short of
-    // requests in flight rather than of memory (profiles/r03_strip_walk_counters.txt): the sample-ring kernels (n <= 16) with 7 rows
-    // ahead -- and, for the fused-multiply-add bank, at most TWO resident blocks per CU (8 waves; launch_bank_roll) -- run config 3's
-    // block push in 0.389 ms instead of 0.404-0.417 (0.69 of the roofline; n = 4: 0.378 vs 0.407), the reference-order bank 0.451-0.460
-    // instead of 0.467-0.469 at its full occupancy (it is bound by its two instructions per tap and needs the waves).  The
-    // accumulator-ring kernels (n > 16) have their own ring of rows in flight (bank_accroll_item) and keep 4 blocks per CU.
-#ifdef SG_SROLL_P
-    static constexpr int P = SG_SROLL_P;
-#else
-    static constexpr int P = N <= 16 ? 7 : 3;
-#endif
-    static constexpr int U = WS + P;                         // ring slots = unroll factor of the tick loop
-    static constexpr int NP = N + 1;                         // SGPR pairs holding taps 0..2N
-};
-
-template <int N>
-struct SRollTaps { f32x2 w[SRoll<N>::NP]; };
-
-struct BankJob {
-    const float *ring;               // [WS][streams], slot (wp0 - k) mod WS = sample -k of the history
-    const float *samples;            // [ticks][streams]
-    float       *out;                // [ticks][streams]
-    size_t       streams, ticks;
-    unsigned long long received0;    // samples per stream before this call
-    int          wp0;
-    float        dt_inv;
-    unsigned     strips, bands;
-    int          band_ticks;
-    int          aligned;            // rows of samples / ring / out start 8-byte aligned (streams even, bases aligned)
-};
 
 // One item: streams s0, s0+1 of every lane, output ticks t0 .. t0+nt-1.  Row r of the band = history index
 // t0 - 2N + r; output tick m needs rows m .. m+2N, row r lives in ring slot r % U.
@@ -225,7 +192,6 @@ __device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRol
 #ifndef SG_STREAM_TILE_WPB
 #define SG_STREAM_TILE_WPB 2
 #endif
-struct TileGeom { unsigned strips, bands, group; unsigned long long total; };
 
 #ifndef SG_STREAM_TILE_SPL
 #define SG_STREAM_TILE_SPL 4                                 // streams per lane: 4 = one 16-byte load per row, 2 = one 8-byte load
@@ -405,12 +371,22 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
     const size_t max_bands = job.ticks / (size_t)(8 * R::WS) > 0 ? job.ticks / (size_t)(8 * R::WS) : 1;
     size_t bands = 1;
     {
+        // Candidates: every count up to the one that gives each resident wave an item (ceil(waves / strips), what rounds 1-3 took), bounded
+        // by max_bands.  (round 4 stopped the search at 64, so a bank of FEW strips and a long block -- 1024 streams = 8 strips
+        // x 100 000 ticks -- ran on 512 of its 2048 waves; the search is coarse above 64 to stay a few hundred steps.)
         double best = 1e300;
-        const size_t top = max_bands < 64 ? max_bands : 64;
-        for (size_t b = 1; b <= top; ++b) {
+        const size_t fill = (nwaves + job.strips - 1) / (size_t)job.strips;
+        size_t top = fill > 64 ? fill : 64;
+        if (top > max_bands) top = max_bands;
+        for (size_t b = 1; b <= top; b += (b < 64 ? 1 : (b / 64 < 1 ? 1 : b / 64))) {
             const size_t rows = (job.ticks + b - 1) / b + 2 * (size_t)N;
             const size_t rounds = ((size_t)job.strips * b + nwaves - 1) / nwaves;
             const double cost = (double)rounds * (double)rows;
+            if (cost < best * 0.999) { best = cost; bands = b; }
+        }
+        if (top > 64) {                                      // the exact fill count is always a candidate
+            const size_t b = top;
+            const double cost = (double)(((size_t)job.strips * b + nwaves - 1) / nwaves) * (double)((job.ticks + b - 1) / b + 2 * (size_t)N);
             if (cost < best * 0.999) { best = cost; bands = b; }
         }
     }
@@ -454,6 +430,9 @@ int sg_bank_roll_launch(int n, const float *center_weights, const float *ring, c
     memset(&job, 0, sizeof(job));
     job.ring = ring; job.samples = samples; job.out = out;
     job.streams = streams; job.ticks = ticks; job.received0 = received0; job.wp0 = wp0; job.dt_inv = dt_inv;
+    // round 5: the LDS-DMA tile form where it covers the call (sg_stream_dma.hip; SAVGOL_HIP_STREAM_DMA=0 for A/B runs against the forms below)
+    static const int dma_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA"); return e ? atoi(e) : 1; }();
+    if (dma_env && sg_bank_dma_launch(n, fma, center_weights, job, cu_count, st) == 0) return 0;
     return dispatch_bank_roll<1>(n, fma, center_weights, job, cu_count, st);
 }
 

@@ -29,6 +29,7 @@ def _libs():
         _rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
         _rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
         _rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        _rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         _rccl.ncclGetErrorString.restype = C.c_char_p
         _rccl.ncclGetErrorString.argtypes = [C.c_int]
         _ext = C.CDLL(os.environ.get("SAVGOL_HIP_RCCL_LIB") or os.path.join(_HERE, "lib", "libsavgol_hip_rccl.so"))
@@ -76,6 +77,14 @@ class Comm:
         rc = nccl.ncclCommInitRank(C.byref(self.handle), self.world, uid, self.rank)
         if rc != 0:
             raise RuntimeError(f"ncclCommInitRank: {nccl.ncclGetErrorString(rc).decode()}")
+
+    def count(self):
+        """ranks in the communicator as RCCL itself reports them (ncclCommCount): what bench.py prints as `rccl_ranks`"""
+        n = C.c_int(-1)
+        rc = _libs()[0].ncclCommCount(self.handle, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"ncclCommCount: {_libs()[0].ncclGetErrorString(rc).decode()}")
+        return n.value
 
     def close(self):
         if getattr(self, "handle", None) and self.handle.value:

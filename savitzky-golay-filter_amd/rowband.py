@@ -118,6 +118,13 @@ class RowBand:
             up = torch.empty((images, self.ny, cols), dtype=local.dtype, device=local.device) if self.top else None
             dn = torch.empty((images, self.ny, cols), dtype=local.dtype, device=local.device) if self.bottom else None
             scratch = torch.empty((2, images, self.ny, cols), dtype=local.dtype, device=local.device)
+            # up / dn / scratch come from torch's caching allocator on ITS current stream, but are written on the exchange stream and read
+            # on `cur`: tell the allocator, or it may hand the blocks to someone else while the pack kernel, ncclSend / ncclRecv or the edge
+            # strips still use them
+            for buf in (up, dn, scratch, local, out):
+                if buf is not None:
+                    buf.record_stream(self._xstream)
+                    buf.record_stream(cur)
             ready = torch.cuda.Event()
             ready.record(cur)
             self._xstream.wait_event(ready)                   # the band's rows are there before they are packed

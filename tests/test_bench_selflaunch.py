@@ -30,3 +30,17 @@ def test_gpus_flag_launches_that_many_ranks():
 def test_mismatch_between_flag_and_world_size_is_an_error():
     r = _run(["--gpus", "4"], {"SAVGOL_BENCH_DRYRUN": "1", "WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_rowband_two_ranks_dry_run_plans_the_bands():
+    """--workload image --rowband --gpus 2: the self-launch, the band plan (the two bands tile the doubled frame, rank 0
+    has a neighbour below and none above) and the choice of exchange travel through the dry run; nothing re-execs after GPU init because
+    nothing touches the GPU at all here."""
+    r = _run(["--gpus", "2", "--workload", "image", "--rowband", "--size", "256"], {"SAVGOL_BENCH_DRYRUN": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rowband"] is True and d["exchange"] == "c"
+    assert d["frame_rows"] == 512 and d["rows_over_ranks"] == 512 and d["rank0_band"] == [0, 256]
+    assert d["rank0_neighbours"] == {"up": False, "down": True}

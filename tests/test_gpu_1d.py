@@ -2,27 +2,35 @@
 
 Parity metric (hard part 3): normwise  max|a-b| / max|b|.
 Tolerances, stated once:
-  * fp32 kernels vs the fp64-accumulate oracle (fp32 tables promoted):      TOL_F32  = 1e-6
+  * fp32 kernels vs the fp64-accumulate oracle (fp32 tables promoted):      TOL_F32  = 1e-6  (north_star's bar)
   * fp64 kernels vs the same oracle:                                         TOL_F64  = 1e-12
-  * fp32 kernels vs the reference's own fp32 output (golden fixtures): the reference itself sits
-    up to ~1e-6 from the oracle (4 chains, separate mul/add), so             TOL_GOLD = 2e-6
-  * derivative filters (d >= 1) amplify rounding (sum|w||x| >> max|out|): the reference's own fp32 output is up to
-    1.4e-6 from the oracle there; round 4's three-chain kernels stay within 1.3 x the reference's own error
-    (test_fp32_kernels_against_the_reference_s_own_fp32_error), the bound is TOL_F32_DERIV = 1.5e-6 (round 3: 2e-6)
-  * order-10 / 4th-derivative case (weights cancel catastrophically; the reference's own fp32 result
-    is 1e-5 off the oracle there) uses the looser bound stated at the test.
+  * round 5: there is no wider fixed fp32 bar any more.  Where a comparison needs more than 1e-6 it is because the
+    REFERENCE's own fp32 output on the same samples is further than 1e-6 from the double answer (derivative filters: sum|w||x| >> max|out|;
+    the order-10 / 4th-derivative golden case, where the reference is 1e-5 off): the bar is then bar32() = max(1e-6, 1.1 x that error),
+    measured in the test from the oracle's bit-exact restatement of the reference's arithmetic (or the golden fixture), never a constant.
+    The same bar holds for the distance of a default kernel from the reference's own fp32 OUTPUT (the golden fixtures).
+    tests/_util.check() logs every such comparison under SAVGOL_PARITY_LOG; tools/parity_margins.py prints the worst per test.
 """
 import ctypes as C
 
 import numpy as np
 import pytest
 
-from tests._util import fuzz, normwise, same_bits
+from tests._util import check, fp32_bar, fuzz, normwise, same_bits
 from tests.golden.make_golden import APPLY_CASES
 
 pytestmark = pytest.mark.gpu
 
-TOL_F32, TOL_F32_DERIV, TOL_F64, TOL_GOLD = 1e-6, 1.5e-6, 1e-12, 2e-6
+TOL_F32, TOL_F64 = 1e-6, 1e-12
+
+
+def bar32(o, x, ref64=None):
+    """1e-6, or 1.1 x the reference's OWN fp32 error on these samples (o: the oracle's filter, whose .apply is the reference's
+    arithmetic bit for bit) where the reference itself is further than 1e-6 from the double answer"""
+    x = np.asarray(x)
+    if ref64 is None:
+        ref64 = o.apply_f64(x.astype(np.float64))
+    return fp32_bar(normwise(o.apply(np.ascontiguousarray(x, np.float32)), ref64))
 
 
 @pytest.fixture(scope="module")
@@ -80,8 +88,9 @@ def test_batch_kernels_vs_reference_golden(sg, sgo, golden, torch_gpu, ci):
         want = g[f"c{ci}_mode{mode}_out"]
         y = f.apply_tensor(xd)[0].cpu().numpy()
         hi = sgo.Filter(n, m, d, dt, mode).apply_f64(x.astype(np.float64))
-        assert normwise(y, hi) < (2e-5 if hard else TOL_F32 if d == 0 else TOL_F32_DERIV), (ci, mode, normwise(y, hi))
-        assert normwise(y, want) < (4e-5 if hard else TOL_GOLD), (ci, mode, normwise(y, want))
+        bar = fp32_bar(normwise(want, hi))                # 1e-6 unless the reference's own output (the fixture) is further than that from the double answer
+        check(normwise(y, hi), bar, ("golden vs oracle", ci, mode, hard))
+        check(normwise(y, want), bar, ("golden vs reference output", ci, mode, hard))
         assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_REFERENCE_SUMMATION, 1) == 0
         try:
             y = f.apply_tensor(xd)[0].cpu().numpy()
@@ -144,7 +153,7 @@ def test_leading_edge_sign_quirk_reproduced(sg, golden, torch_gpu):
     g = golden("apply1d")
     y = sg.Filter(5, 2, 1).apply(g["quirk_in"])
     assert np.allclose(y[:5], -3.0, atol=1e-3) and np.allclose(y[5:], 3.0, atol=1e-3)
-    assert normwise(y, g["quirk_out"]) < TOL_GOLD
+    assert same_bits(y, g["quirk_out"])                 # host-pointer call: the reference's bits
 
 
 # ------------------------------------------------------------------------------------------------
@@ -158,7 +167,7 @@ def test_batch_every_half_window(sg, sgo, torch_gpu, n, dtype):
     m = min(4, 2 * n)
     d = int(rng.integers(0, min(m, 2) + 1))
     dt = float(rng.choice([1.0, 0.5]))
-    tdt, ndt, tol = (torch.float32, np.float32, TOL_F32 if d == 0 else TOL_F32_DERIV) if dtype == "f32" else (torch.float64, np.float64, TOL_F64)
+    tdt, ndt = (torch.float32, np.float32) if dtype == "f32" else (torch.float64, np.float64)
     tile = 2048 if dtype == "f32" else 1024
     ch = 3
     for length in (2 * n + 1, tile - 1, tile + 2 * n + 5, 3 * tile):
@@ -169,12 +178,18 @@ def test_batch_every_half_window(sg, sgo, torch_gpu, n, dtype):
         for mode in range(4):
             f = sg.Filter(n, m, d, dt, mode)
             y = f.apply_tensor(x).cpu().numpy()
-            ref = sgo.Filter(n, m, d, dt, mode).apply_f64(xh.astype(np.float64))
-            assert normwise(y, ref) < tol, (n, dtype, length, mode, normwise(y, ref))
+            o = sgo.Filter(n, m, d, dt, mode)
+            ref = o.apply_f64(xh.astype(np.float64))
+            tol = TOL_F64 if dtype == "f64" else bar32(o, xh, ref)
+            check(normwise(y, ref), tol, (n, dtype, d, length, mode))
         f = sg.Filter(n, m, d, dt, 0)
         v = f.apply_tensor(x, valid=True).cpu().numpy()
-        ref = sgo.Filter(n, m, d, dt, 0).apply_f64(xh.astype(np.float64))[:, n:length - n]
-        assert v.shape == ref.shape and normwise(v, ref) < tol, (n, dtype, length, "valid")
+        o = sgo.Filter(n, m, d, dt, 0)
+        ref = o.apply_f64(xh.astype(np.float64))[:, n:length - n]
+        tol = TOL_F64 if dtype == "f64" else fp32_bar(normwise(o.apply(np.ascontiguousarray(xh, np.float32))[:, n:length - n], ref)) if length > 2 * n else TOL_F32
+        assert v.shape == ref.shape
+        if v.size:
+            check(normwise(v, ref), tol, (n, dtype, d, length, "valid"))
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
@@ -484,16 +499,14 @@ def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu, n):
     x = torch.empty((6, 70001), dtype=torch.float32, device="cuda")
     sg.synth(x)
     xh = x.cpu().numpy().astype(np.float64)
-    for (m, d, mode, tol, dt) in [(4, 0, 0, 1e-6, 1.0), (4, 0, 1, 1e-6, 1.0), (4, 0, 2, 1e-6, 1.0), (4, 0, 3, 1e-6, 1.0), (2, 0, 1, 1e-6, 1.0),
-                                  (6, 0, 1, 1e-6, 1.0), (4, 1, 3, 1.5e-6, 1.0), (4, 2, 0, 1.5e-6, 1.0), (3, 1, 2, 1.5e-6, 1.0),
-                                  (4, 1, 0, 1.5e-6, 0.25), (4, 2, 1, 1.5e-6, 1e-3)]:          # time_step != 1: the dt_inv multiply after the sum
+    for (m, d, mode, dt) in [(4, 0, 0, 1.0), (4, 0, 1, 1.0), (4, 0, 2, 1.0), (4, 0, 3, 1.0), (2, 0, 1, 1.0),
+                             (6, 0, 1, 1.0), (4, 1, 3, 1.0), (4, 2, 0, 1.0), (3, 1, 2, 1.0),
+                             (4, 1, 0, 0.25), (4, 2, 1, 1e-3)]:          # time_step != 1: the dt_inv multiply after the sum
         f = sg.Filter(n, m, d, dt, mode)
         ref = sgo.Filter(n, m, d, dt, mode).apply_f64(xh)
-        if d == 2:
-            # second derivatives at half windows 24..32 (taps of both signs, outputs ~1e-3 of the input): round 2 allowed 2e-5 here, round 3
-            # 2e-6 or twice the reference's own fp32 error; round 4 (three chains, plain kernel for d = 2): the derivative bar (1.5e-6) --
-            # or 1.5 x the reference's own fp32 error on the same samples (the oracle's bit-exact restatement) where that is larger
-            tol = max(1.5e-6, 1.5 * normwise(sgo.Filter(n, m, d, dt, mode).apply(xh.astype(np.float32)), ref))
+        # 1e-6; derivative filters at half windows 24..32 (taps of both signs, outputs ~1e-3 of the input: round 2 allowed 2e-5 here, round 3
+        # 2e-6, round 4 1.5e-6) get 1.1 x the reference's own fp32 error on the same samples where THAT exceeds 1e-6 -- nothing else
+        tol = bar32(sgo.Filter(n, m, d, dt, mode), xh, ref)
         a = f.apply_tensor(x).cpu().numpy()
         assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 1) == 0
         try:
@@ -504,9 +517,10 @@ def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu, n):
             assert not np.array_equal(a, b), "the option did not switch kernels"
         else:          # round 4: moving averages and second derivatives keep the plain kernel (the block's sum costs accuracy there)
             assert np.array_equal(a, b), "poly_order < 2 / derivative 2 must run the plain kernel"
-        assert normwise(a, ref) < tol and normwise(b, ref) < tol, (m, d, mode, normwise(a, ref), normwise(b, ref))
+        check(normwise(a, ref), tol, ("default", n, m, d, mode))
+        check(normwise(b, ref), tol, ("plain", n, m, d, mode))
         v = f.apply_tensor(x, valid=True).cpu().numpy()
-        assert normwise(v, ref[:, n:-n]) < tol
+        check(normwise(v, ref[:, n:-n]), fp32_bar(normwise(sgo.Filter(n, m, d, dt, mode).apply(xh.astype(np.float32))[:, n:-n], ref[:, n:-n])), ("valid", n, m, d, mode))
     # a table that is not a polynomial: same result with and without the option (both run the plain kernel)
     f = sg.Filter(n, 4, 0, 1.0, 1)
     f.ptr.contents.center_weights[20] += 3e-4
@@ -565,7 +579,8 @@ def test_opt_in_boundary_aware_strided_call(sg, sgo, torch_gpu, mode):
         assert L.savgol_apply_strided_batch_f32(f.ptr, d_in.data_ptr(), 12, 4, 0, d_out.data_ptr(), 12, 4, 0, 1, count, None) == 0, sg.last_error()
         torch.cuda.synchronize()
         got = d_out.cpu().numpy()
-        assert normwise(got[:, 1], want) < 2e-6 and np.all(got[:, 0] == -9.0)
+        check(normwise(got[:, 1], want), 1e-6, "boundary-aware strided vs the reference's output")
+        assert np.all(got[:, 0] == -9.0)
     finally:
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_BOUNDARY_AWARE, 0)
 
@@ -666,13 +681,14 @@ def test_fp32_kernels_against_the_reference_s_own_fp32_error(sg, sgo, torch_gpu,
     (csrc/sg_k1d.hpp, Conv<float>; tools/emulate_fp32_chains.py says why round robin and why three), the block-moment kernel's block
     term added last and only for poly_order >= 2, derivative <= 1, POLYNOMIAL edge rows summed in double: 0.7-1.3 x the reference
     at every half window of this sweep (profiles/r04_fp32_accuracy_sweep.txt).
-    So: <= max(1e-6, 1.5 x the reference's own error) everywhere, 1e-6 outright for well-conditioned smoothing, <= 1.5e-6 always."""
+    Round 5: the bar is max(1e-6, 1.1 x the reference's own error) -- 1e-6 outright wherever the reference itself
+    meets 1e-6 -- and the cases where the reference exceeds 1e-6 are printed (they are the only ones with a wider bar)."""
     torch = torch_gpu
     x = torch.empty((5, 40000 + 17 * n), dtype=torch.float32, device="cuda")
     sg.synth(x, channel0=3 * n)
     xh = x.cpu().numpy()
     xmax = float(np.max(np.abs(xh)))
-    bad, worst_ratio, worst_e = [], 0.0, 0.0
+    bad, wide, worst_ratio, worst_e = [], [], 0.0, 0.0
     for m in range(0, 7):
         for d in range(0, min(m, 2) + 1):
             for mode, dt in ((0, 1.0), (1, 1.0), (2, 0.5), (3, 1.0)):
@@ -682,13 +698,17 @@ def test_fp32_kernels_against_the_reference_s_own_fp32_error(sg, sgo, torch_gpu,
                 got = sg.Filter(n, m, d, dt, mode).apply_tensor(x).cpu().numpy()
                 e = normwise(got, ref64)
                 passes_signal = d == 0 and float(np.max(np.abs(ref64))) >= 0.25 * xmax
-                bar = 1e-6 if passes_signal else max(1e-6, 1.5 * e_ref)
+                bar = 1e-6 if passes_signal else fp32_bar(e_ref)
                 worst_e = max(worst_e, e)
                 if e_ref > 0:
                     worst_ratio = max(worst_ratio, e / max(e_ref, 2.5e-7))
-                if e > bar or e > 1.5e-6:
+                if e_ref > 1e-6:
+                    wide.append((m, d, mode, float(f"{e_ref:.3g}"), float(f"{e:.3g}")))
+                check(e, bar, (n, m, d, mode))
+                if e > bar:
                     bad.append((m, d, mode, e, e_ref, passes_signal))
-    print(f"n={n}: worst normwise error {worst_e:.3e}, worst ratio to the reference's own error {worst_ratio:.2f}")
+    print(f"n={n}: worst normwise error {worst_e:.3e}, worst ratio to the reference's own error {worst_ratio:.2f}; "
+          f"reference itself beyond 1e-6 (m, d, mode, its error, ours): {wide}")
     assert not bad, bad
 
 
@@ -702,13 +722,11 @@ def test_fused_strided_kernel(sg, sgo, torch_gpu, n, m, d, dt):
     torch = torch_gpu
     L = sg.lib()
     rng = np.random.default_rng(100 * n + m)
-    tol = 1e-6 if d == 0 else 2e-6
     for rec, ch, count in ((2, 3, 5000), (3, 2, 2 * n + 1), (5, 4, 2048 + 2 * n + 3), (16, 2, 6200)):
         aos = rng.normal(0, 1, (ch, count, rec)).astype(np.float32)
         aos[:, :, 1] = signal(rng, (ch, count)).astype(np.float32)
         ref64 = sgo.Filter(n, m, d, dt, 0).apply_f64(aos[:, :, 1].astype(np.float64))
-        if d == 2:
-            tol = max(2e-6, normwise(sgo.Filter(n, m, d, dt, 0).apply(aos[:, :, 1]), ref64))
+        tol = bar32(sgo.Filter(n, m, d, dt, 0), aos[:, :, 1], ref64)      # 1e-6 unless the reference's own fp32 error on this field is larger
         f = sg.Filter(n, m, d, dt, sg.SAVGOL_BOUNDARY_REFLECT)                  # must be ignored
         # (a) separate arrays, field 1 -> field 0 of records of the same size
         src = torch.from_numpy(aos).cuda()
@@ -1016,15 +1034,15 @@ def test_length_split_two_ranks_sharing_the_gpu(sg, sgo, torch_gpu, tmp_path, n)
         assert np.array_equal(whole.view(np.uint32), sgo.Filter(n, 4, 1, 0.5, mode).apply(xh).view(np.uint32)), mode
         ref64 = sgo.Filter(n, 4, 1, 0.5, mode).apply_f64(xh.astype(np.float64))
         fma = np.concatenate([np.load(tmp_path / f"fma{mode}_r{r}.npy") for r in range(world)], axis=1)
-        assert normwise(fma, ref64) < TOL_F32_DERIV, (mode, normwise(fma, ref64))
+        check(normwise(fma, ref64), bar32(sgo.Filter(n, 4, 1, 0.5, mode), xh, ref64), ("length split, default kernels", n, mode))
 
 
 def test_scratch_pool_hands_its_memory_back(sg, torch_gpu):
     """the staged strided path takes 2 x channels x ld x 4 bytes of stream-ordered scratch, and round 3's pool (release
     threshold UINT64_MAX) was meant to keep the peak for the life of the process -- invisible to PyTorch's allocator and to the caller's
     hipMalloc.  Now: what the pool holds (hipMemPoolAttrReservedMemCurrent; hipMemGetInfo does not move on ROCm 7.2 whatever a pool
-    releases, tools/probe_pool_trim.hip) is at most its 256 MiB threshold once the stream has been synchronised, and zero after
-    savgol_hip_trim_scratch() or savgol_hip_synchronize()."""
+    releases, tools/probe_pool_trim.hip) is at most its 256 MiB threshold once the stream has been synchronised (torch's synchronise or savgol_hip_synchronize alike), and
+    zero after savgol_hip_trim_scratch()."""
     torch = torch_gpu
     L = sg.lib()
     ch, count = 64, 1 << 20                                           # 64 x 1 Mi records of 8 bytes: 512 MiB array, 512 MiB of scratch
@@ -1040,8 +1058,12 @@ def test_scratch_pool_hands_its_memory_back(sg, torch_gpu):
     assert L.savgol_hip_trim_scratch() == 0
     assert L.savgol_hip_scratch_reserved() == 0
     staged_call()
-    assert L.savgol_hip_synchronize(None) == 0                        # synchronises the stream, then trims
-    assert L.savgol_hip_scratch_reserved() == 0
+    assert L.savgol_hip_synchronize(None) == 0                        # synchronises the stream; the pool keeps its threshold for the next call
+    assert 0 < L.savgol_hip_scratch_reserved() <= (256 << 20) + (64 << 20)
+    staged_call()                                                     # ... which re-uses the kept frames: nothing more is reserved than one call needs
+    torch.cuda.synchronize()
+    assert L.savgol_hip_scratch_reserved() <= (256 << 20) + (64 << 20)
+    assert L.savgol_hip_trim_scratch() == 0 and L.savgol_hip_scratch_reserved() == 0
 
 
 @pytest.mark.parametrize("rec,n,m,d", [(2, 32, 4, 0), (4, 32, 4, 0), (2, 5, 3, 1), (4, 13, 5, 2), (2, 1, 1, 0)])
@@ -1053,7 +1075,6 @@ def test_strided_two_fields_of_the_same_records(sg, sgo, torch_gpu, rec, n, m, d
     was, for counts that end inside a tile and channel pitches with slack."""
     torch = torch_gpu
     L = sg.lib()
-    tol = 1e-6 if d == 0 else 1.5e-6
     for ch, count, slack in ((3, 5000, 0), (2, 2 * n + 1, 3), (4, 2048 + 2 * n + 3, 1), (1, 70001, 0)):
         pitch = (count + slack) * rec
         buf = torch.randn((ch, pitch), dtype=torch.float32, device="cuda")
@@ -1068,8 +1089,8 @@ def test_strided_two_fields_of_the_same_records(sg, sgo, torch_gpu, rec, n, m, d
             got = view.cpu().numpy()
             was = before.view(ch, count + slack, rec).cpu().numpy()
             ref = sgo.Filter(n, m, d, 1.0, 0).apply_f64(was[:, :count, fi].astype(np.float64))
-            bar = max(tol, 1.5 * normwise(sgo.Filter(n, m, d, 1.0, 0).apply(np.ascontiguousarray(was[:, :count, fi])), ref)) if d else tol
-            assert normwise(got[:, :count, fo], ref) < bar, (rec, ch, count, fi, fo)
+            bar = bar32(sgo.Filter(n, m, d, 1.0, 0), was[:, :count, fi], ref)
+            check(normwise(got[:, :count, fo], ref), bar, (rec, n, m, d, ch, count, fi, fo))
             keep = [k for k in range(rec) if k != fo]
             assert np.array_equal(got[:, :, keep].view(np.uint32), was[:, :, keep].view(np.uint32))
             assert np.array_equal(got[:, count:].view(np.uint32), was[:, count:].view(np.uint32))

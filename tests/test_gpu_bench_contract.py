@@ -32,6 +32,40 @@ def test_single_gpu_line():
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["cores"] == 1
     assert d["parity_normwise_vs_fp64_oracle"] < 1e-6
     assert abs(d["value"] - 4 * 256 * 262144 * 3 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 0.01
+    # round 5: the distance from the REFERENCE's own fp32 output, and the copy ceiling measured in this process
+    assert d["parity_normwise_vs_reference_fp32"] < 1e-6 and d["reference_fp32_own_error_vs_fp64_oracle"] < 1e-6 and "reference_fp32_from" in d
+    roof = d["roofline"]
+    assert {"copy_frac", "frac_of_copy", "read_only_frac"} <= set(roof)
+    assert 0.3 < roof["copy_frac"] < 1.0 and 0.3 < roof["read_only_frac"] < 1.0 and abs(roof["frac_of_copy"] - roof["frac"] / roof["copy_frac"]) < 1e-3
+    ex = d["extra"]
+    assert ex["build"]["library"].endswith("libsavgol_hip.so") and "library_sha256_16" in ex["build"]
+    for leg, keys in (("config1", ()), ("config3", ("block_push",)), ("config4", ("modes", "CONSTANT"))):
+        node = ex[leg]
+        assert "error" not in node, node
+        for k in keys:
+            node = node[k]
+        assert node["parity_normwise_vs_reference_fp32"] < 2e-6 and node["parity_normwise_vs_fp64_oracle"] < 2e-6, (leg, node)
+    assert ex["config3"]["block_push"]["roofline"]["copy_frac"] > 0.3 and ex["config4"]["modes"]["CONSTANT"]["roofline"]["frac_of_copy"] > 0.3
+    rb = ex["config4_rowband"]
+    assert "error" not in rb, rb
+    if "skipped" not in rb:
+        assert rb["rccl_ranks"] == 1 and rb["exchange_ms"] > 0 and rb["band_ms"] > 0 and rb["edge_strips_ms"] > 0 and rb["step_ms"] > 0
+        assert rb["parity_normwise_vs_fp64_oracle"] < 1e-6
+
+
+def test_exchange_c_fails_loudly_when_it_cannot_come_up():
+    """--rowband --exchange c must END THE JOB (non-zero exit, a JSON error line) when the C RCCL exchange cannot come up on every rank -- here
+    because both ranks sit on one GPU, which RCCL refuses (the gloo hook) -- instead of silently timing torch.distributed's P2P (round 4);
+    --exchange torch on the same ranks is the explicit fallback and runs."""
+    port = "29619"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           "bench.py", "--gpus", "2", "--workload", "image", "--rowband", "--images", "2", "--size", "512", "--steps", "2", "--warmup", "1"]
+    e = dict(os.environ); e.update({"SAVGOL_BENCH_BACKEND": "gloo", "SAVGOL_BENCH_DEVICE": "0"})
+    r = subprocess.run(cmd + ["--exchange", "c"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode != 0
+    assert "--exchange c" in r.stdout and "--exchange torch" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    d = run(cmd[:7] + ["--master-port", "29621"] + cmd[9:] + ["--exchange", "torch"], env={"SAVGOL_BENCH_BACKEND": "gloo", "SAVGOL_BENCH_DEVICE": "0"})
+    assert d["n_gpus"] == 2 and "torch.distributed" in d["exchange"] and d["rccl_ranks"] is None
 
 
 def test_two_ranks_weak_scaling_plumbing():

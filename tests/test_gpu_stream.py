@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from tests._util import bits, fuzz, normwise
+from tests._util import check, fp32_bar, bits, fuzz, normwise
 from tests.golden.make_golden import STREAM_CASES
 
 pytestmark = pytest.mark.gpu
@@ -223,7 +223,8 @@ def test_stream_bank_config3_shape(sg, sgo, torch_gpu):
 def test_stream_bank_config3_full_size(sg, sgo, torch_gpu):
     """BASELINE config 3 at the size bench.py times (VERDICT r03 missing #3): 65 536 streams x 4096 ticks, n=16, m=2, d=1, dt=1e-3,
     one block push.  Five sampled streams: the reference-order bank bit for bit against the oracle's push loop, the fused multiply-add
-    bank within the derivative bar (1.5e-6) of the double-accumulation oracle; both banks write exactly the ticks that have an output."""
+    bank within 1e-6 of the double-accumulation oracle -- or 1.1 x the error of the REFERENCE's own stream arithmetic (the bit-exact bank's
+    output on the same streams) where that is larger; both banks write exactly the ticks that have an output."""
     torch = torch_gpu
     S, n, T = 65536, 16, 4096
     free, _ = torch.cuda.mem_get_info()
@@ -235,6 +236,7 @@ def test_stream_bank_config3_full_size(sg, sgo, torch_gpu):
     xh = x[:, pick].cpu().numpy()
     f = sgo.Filter(n, 2, 1, 1e-3)
     ref64 = f.apply_f64(xh.T.astype(np.float64).copy())[:, n:T - n]
+    e_ref = 0.0
     for fma in (False, True):
         bank = sg.StreamBank(S, n, 2, 1, 1e-3, fma=fma)
         out = torch.full((T, S), float("nan"), dtype=torch.float32, device="cuda")
@@ -247,8 +249,9 @@ def test_stream_bank_config3_full_size(sg, sgo, torch_gpu):
                 o = sgo.Stream(f)
                 seq = np.array([v for v, ok in (o.push(v) for v in xh[:, j]) if ok], np.float32)
                 assert same_bits(got[:, j], seq), pick[j]
+            e_ref = normwise(got.T, ref64)                     # the reference's own fp32 error on these streams (one chain, multiply and add rounded)
         else:
-            assert normwise(got.T, ref64) < 1.5e-6
+            check(normwise(got.T, ref64), fp32_bar(e_ref), ("config 3 FMA bank", e_ref))
         assert bank.counters[0] == T and bank.counters[1] == T - 2 * n
 
 
@@ -436,11 +439,13 @@ def test_opt_in_boundary_aware_streams_match_the_batch_filter(sg, sgo, torch_gpu
         outs += list(buf[:c])
         got = np.asarray(outs, np.float32)
         assert got.shape == (T,)
-        if want_mode == 0:
-            assert normwise(got, ref[0]) < 2e-6                # stream vs batch: different summation order (reference: 1e-5)
-        else:
-            assert normwise(got, ref64[0]) < (1e-6 if d == 0 else 4e-6), normwise(got, ref64[0])
-            assert normwise(got[n:-n], ref[0][n:-n]) < 2e-6
+        # the bar: 1e-6, or 1.1 x the reference's own fp32 error on this signal -- its batch arithmetic (four chains) on all outputs, its stream
+        # arithmetic (one chain: the oracle's push loop) on the centre outputs -- where that is larger
+        o1 = sgo.Stream(sgo.Filter(n, m, d, dt, 0))
+        centre = np.array([v for v, ok in (o1.push(v) for v in x[0]) if ok], np.float32)
+        bar = fp32_bar(max(normwise(ref[0], ref64[0]), normwise(centre, ref64[0][n:T - n])))
+        assert same_bits(got[n:T - n], centre)                  # centre outputs: the reference's stream arithmetic, bit for bit, in every mode
+        check(normwise(got, ref64[0]), bar, ("boundary-aware stream", n, m, d, mode))
         L.savgol_destroy(f)
         # bank
         bank = sg.StreamBank.__new__(sg.StreamBank)
@@ -460,7 +465,9 @@ def test_opt_in_boundary_aware_streams_match_the_batch_filter(sg, sgo, torch_gpu
         assert gotb.shape == (4, T)
         assert np.array_equal(gotb[0].view(np.uint32), got.view(np.uint32))      # bank == single stream, bit for bit
         for c_ in range(4):
-            assert normwise(gotb[c_], ref64[c_]) < (2e-6 if d == 0 or want_mode else 4e-6) * (2 if d else 1)
+            oc = sgo.Stream(sgo.Filter(n, m, d, dt, 0))
+            cc = np.array([v for v, ok in (oc.push(v) for v in x[c_]) if ok], np.float32)
+            check(normwise(gotb[c_], ref64[c_]), fp32_bar(max(normwise(ref[c_], ref64[c_]), normwise(cc, ref64[c_][n:T - n]))), ("boundary-aware bank", n, m, d, mode, c_))
         L.savgol_streambank_destroy(bank.ptr); bank.ptr = None
     finally:
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_BOUNDARY_AWARE, 0)
@@ -469,9 +476,8 @@ def test_opt_in_boundary_aware_streams_match_the_batch_filter(sg, sgo, torch_gpu
 @pytest.mark.parametrize("n,m,d,dt", [(16, 2, 1, 1e-3), (5, 3, 0, 1.0), (1, 0, 0, 1.0), (17, 4, 2, 0.5), (32, 4, 0, 1.0), (24, 3, 1, 2.0)])
 def test_fma_bank_is_within_the_fp32_bar_of_the_fp64_oracle(sg, sgo, torch_gpu, n, m, d, dt):
     """SAVGOL_STREAMBANK_FMA (savgol_streambank_create_ex): block push (sample ring n <= 16, accumulator ring above) and the
-    per-tick kernel with fused multiply-adds.  Not the reference's bits; the bar is the 1-D batch path's: <= 1e-6 (smoothing) /
-    2e-6 (derivatives) normwise of the double-accumulation oracle -- and never worse than the reference-order bank on the same
-    samples by more than that bar.  Edge rows keep the reference's order: push_full's burst and the flushes stay bit-exact."""
+    per-tick kernel with fused multiply-adds.  Not the reference's bits; the bar is 1e-6 normwise of the double-accumulation oracle, or
+    1.1 x the error of the reference-order bank (= the reference's own arithmetic) on the same samples where that is larger.  Edge rows keep the reference's order: push_full's burst and the flushes stay bit-exact."""
     torch = torch_gpu
     for S, off in ((65536 if n == 16 else 4096, 0), (777, 1)):
         T = 12 * (2 * n + 1) + 5
@@ -490,10 +496,10 @@ def test_fma_bank_is_within_the_fp32_bar_of_the_fp64_oracle(sg, sgo, torch_gpu, 
         pick = [0, 1, S // 2, S - 1]
         xh = xd[:, pick].cpu().numpy().astype(np.float64).T.copy()              # [stream][tick]
         ref64 = sgo.Filter(n, m, d, dt).apply_f64(xh)[:, n:T - n]                  # centre outputs of tick t = batch output t - n
-        bar = 1e-6 if d == 0 else 1.5e-6
         e_fast = normwise(got[2 * n:, pick].cpu().numpy().T, ref64)
         e_ref = normwise(want[2 * n:, pick].cpu().numpy().T, ref64)
-        assert e_fast <= max(bar, e_ref), (n, S, e_fast, e_ref)
+        bar = fp32_bar(e_ref)
+        check(e_fast, bar, ("FMA bank", n, m, d, S, e_ref))
         # whole banks: the two summations agree to the bar everywhere, and do differ somewhere (the flag selects another kernel)
         assert normwise(got[2 * n:].cpu().numpy(), want[2 * n:].cpu().numpy()) <= 2 * bar
         if n >= 5:
