@@ -369,8 +369,10 @@ def bench_stream(sg, a):
     res = {
         "workload": f"BASELINE config 3: {S} streams, n=16, m=2, d=1, dt=1e-3",
         "per_tick_launch": {"wall_latency_us_p50": round(float(lat[len(lat) // 2]), 2), "wall_latency_us_p99": round(float(lat[int(len(lat) * 0.99)]), 2),
-                            "device_us_per_tick_back_to_back": round(tick_us, 3), "ns_per_sample": round(tick_us * 1e3 / S, 4),
-                            "Msamples_per_s": round(S / tick_us, 1)},
+                            "us_per_tick_back_to_back_from_python": round(tick_us, 3), "ns_per_sample": round(tick_us * 1e3 / S, 4),
+                            "Msamples_per_s": round(S / tick_us, 1),
+                            "note": "HIP events around 1000 pushes enqueued from Python: the interpreter's call rate, not the kernel (3.8 us in rocprofv3's "
+                                    "kernel trace); from_c.us_per_tick_back_to_back is the same loop from plain C"},
         "block_push": {"ticks_per_launch": T, "ms": round(ms, 3), "ns_per_sample": round(ms * 1e6 / samples, 5),
                        "Msamples_per_s": round(samples / ms / 1e3, 1),
                        "summation": "SAVGOL_STREAMBANK_FMA (one v_pk_fma_f32 per tap and stream pair, two chains; parity below)",
@@ -425,8 +427,12 @@ def bench_stream(sg, a):
             txt = subprocess.run([demo], capture_output=True, text=True, timeout=120).stdout
             m1 = re.search(r"p50 ([0-9.]+) us\s+p99 ([0-9.]+) us\s+\(launch \+ sync", txt)
             m2 = re.search(r"p50 ([0-9.]+) us\s+p99 ([0-9.]+) us\s+\(resident service", txt)
+            m3 = re.search(r"([0-9.]+) us per tick back to back", txt)
+            m4 = re.search(r"p50 ([0-9.]+) us\s+p99 ([0-9.]+) us\s+\(push_wait", txt)
             if m1 and m2 and "c_api_demo: OK" in txt:
                 res["from_c"] = {"launch_plus_synchronise_us": {"p50": float(m1.group(1)), "p99": float(m1.group(2))},
+                                 "us_per_tick_back_to_back": float(m3.group(1)) if m3 else None,
+                                 "push_wait_us": {"p50": float(m4.group(1)), "p99": float(m4.group(2))} if m4 else None,
                                  "resident_service_us": {"p50": float(m2.group(1)), "p99": float(m2.group(2))},
                                  "note": "examples/c_api_demo.c: 2000 ticks each, thread pinned to the GPU's NUMA node; the service's outputs are compared bit "
                                          "for bit with the per-tick kernel on a twin bank inside the program"}
@@ -595,12 +601,13 @@ def bench_config5_slice(sg, a, rank=0, dev=None, steps=2):
     f = sg.Filter(N, M, 2, 1.0, 0)
     per_launch = []
     ceil = copy_ceiling(sg, x[:chunk], y[:chunk], reps=3)              # one chunk's bytes = one launch's bytes
+    flags = [0]                                                         # the *_ex entry point: 0 = the default fp64 path (1e-12)
 
     def one_pass():
         for c0 in range(0, resident, chunk):
             e0, e1 = ev(), ev()
             e0.record()
-            f.apply_batch(x[c0:c0 + chunk], y[c0:c0 + chunk] if full_out else y, chunk, length, dtype="f64")
+            f.apply_batch(x[c0:c0 + chunk], y[c0:c0 + chunk] if full_out else y, chunk, length, dtype="f64", flags=flags[0])
             e1.record(); per_launch.append((e0, e1))
     one_pass(); torch.cuda.synchronize(); per_launch.clear()
     t0 = time.perf_counter()
@@ -627,6 +634,27 @@ def bench_config5_slice(sg, a, rank=0, dev=None, steps=2):
         out["parity_normwise_vs_fp64_oracle"] = err
         out["cpu_baseline"] = {"note": "the reference has no fp64 path (SURVEY.md fact 1); its fp32 savgol_apply at this shape is the headline's cpu_baseline "
                                        "(same 65-tap loop, n=32)"}
+    # the OPT-IN block-moment path (SAVGOL_BATCH_MOMENT_F64, csrc/sg_k1d_moment64.hpp): the same slice, the same buffers, its own parity figure
+    try:
+        flags[0] = sg.SAVGOL_BATCH_MOMENT_F64
+        per_launch.clear()
+        one_pass(); torch.cuda.synchronize(); per_launch.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_pass()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        lms2 = [p.elapsed_time(q) for p, q in per_launch]
+        opt = {"flag": "SAVGOL_BATCH_MOMENT_F64 (opt-in: within 1e-6 of the fp64 oracle -- measured below -- instead of the default path's 1e-12)",
+               "Msamples_per_s": round(resident * length * steps / el2 / 1e6, 1), "ms_per_pass": round(el2 / steps * 1e3, 3),
+               "roofline": add_ceiling(roofline(16.0 * chunk * length, float(np.mean(lms2)), lms2, kernel="sg1d_center_moment64_kernel<32,5>"), ceil)}
+        if not a.no_cpu:
+            got = (y[c0:c0 + chunk] if full_out else y)[sample].cpu().numpy()
+            opt["parity_normwise_vs_fp64_oracle"] = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+            assert opt["parity_normwise_vs_fp64_oracle"] < 1e-6, opt
+        out["opt_in_block_moments"] = opt
+    except Exception as e:                                               # noqa: BLE001 -- the opt-in leg must not take the default figure down
+        out["opt_in_block_moments"] = {"error": f"{type(e).__name__}: {e}"}
     del x, y
     torch.cuda.empty_cache()
     return out
@@ -640,7 +668,7 @@ def kernel_source_sha(files=None):
 
 
 SOURCES_2D = ["sg_2d_roll.hip", "sg_2d.hpp", "sg_2d.hip"]            # what profiles/r*_2d_config4_pmc_summary.json is stamped with
-SOURCES_STREAM = ["sg_stream_roll.hip", "sg_stream.hpp", "sg_pk.hpp"]   # ... r*_stream_block_pmc_summary.json
+SOURCES_STREAM = ["sg_stream_dma.hip", "sg_stream_roll.hip", "sg_stream_roll.hpp", "sg_stream.hpp", "sg_pk.hpp"]   # ... r*_stream_block_pmc_summary.json
 
 
 def pmc_traffic(alg_bytes, pattern="r*_1d_f32_n32_pmc_summary.json", files=None):
@@ -926,7 +954,7 @@ def run_config5(r):
         for c0 in range(0, resident, chunk):
             e0, e1 = ev(), ev()
             e0.record()
-            f.apply_batch(x[c0:c0 + chunk], y[c0:c0 + chunk] if full_out else y, chunk, length, dtype="f64")
+            f.apply_batch(x[c0:c0 + chunk], y[c0:c0 + chunk] if full_out else y, chunk, length, dtype="f64", flags=sg.SAVGOL_BATCH_MOMENT_F64 if args.f64_moment else 0)
             e1.record()
             if events is not None:
                 events.append((e0, e1))
@@ -941,7 +969,10 @@ def run_config5(r):
                                       f"{resident * length * 8 / 1e9:.1f} GB resident input), n=32, m=4, d=2, POLYNOMIAL, {chunk}-channel chunks per launch, "
                                       + ("output slice resident" if full_out else "one chunk-sized output buffer reused"),
                           "channels_per_gpu": resident, "length": length, "sharding": "channels, no collective"},
-               "roofline": add_ceiling(with_traffic(roofline(16.0 * chunk * length, ms, lms, kernel="sg1d_center_kernel<double,32>"), "r*_1d_f64_n32_pmc_summary.json"), ceil)}
+               "roofline": add_ceiling(with_traffic(roofline(16.0 * chunk * length, ms, lms, kernel="sg1d_center_moment64_kernel<32,5>" if args.f64_moment else "sg1d_center_kernel<double,32>"),
+                                                    "r*_1d_f64m_n32_pmc_summary.json" if args.f64_moment else "r*_1d_f64_n32_pmc_summary.json"), ceil)}
+        if args.f64_moment:
+            out["config"]["summation"] = "SAVGOL_BATCH_MOMENT_F64 (opt-in block moments: bar 1e-6, not the default path's 1e-12)"
         if r.world == 1 and not args.no_cpu:
             from oracle import sgo
             sample = [0, chunk - 1]
@@ -949,7 +980,7 @@ def run_config5(r):
             got = (y[c0:c0 + chunk] if full_out else y)[sample].cpu().numpy()
             ref = sgo.Filter(N, M, 2, 1.0, 0).apply_f64(x[c0:c0 + chunk][sample].cpu().numpy())
             err = normwise(got, ref)
-            assert err < 1e-12, f"parity lost: normwise error {err}"
+            assert err < (1e-6 if args.f64_moment else 1e-12), f"parity lost: normwise error {err}"
             out["parity_normwise_vs_fp64_oracle"] = err
             out["cpu_baseline"] = cpu_baseline(1 << 20, N, M, 2, budget_s=8.0, all_cores=False)
             out["cpu_baseline"]["sample"] += " (fp32: the reference has no fp64 path)"
@@ -1084,6 +1115,7 @@ def main():
                                                            "ny-row halos with the neighbours (RCCL point to point) instead of sharding whole frames")
     ap.add_argument("--c5-channels", type=int, default=4096, help="config 5: channels per GPU (32768 / 8)")
     ap.add_argument("--c5-chunk", type=int, default=1024)
+    ap.add_argument("--f64-moment", action="store_true", help="--workload batch1d_f64: the opt-in block-moment path (SAVGOL_BATCH_MOMENT_F64: 1e-6 instead of 1e-12)")
     args = ap.parse_args()
 
     # ---- N ranks: start them from here, BEFORE anything in this process touches the GPU (never re-exec after that) ----

@@ -120,6 +120,35 @@ int main(void)
     printf("stream bank: %zu streams, n=16 m=2 d=1: per-tick wall latency p50 %.1f us  p99 %.1f us  (launch + sync, from C)\n", S,
            lat[TICKS / 2], lat[(int)(TICKS * 0.99)]);
     CHECK(savgol_streambank_samples_received(bank) == 100 + TICKS);
+    {
+        /* the same tick with the completion taken from a stream-written word instead of hipStreamSynchronize (savgol_streambank_push_wait) */
+        for (int t = 0; t < 100; ++t) CHECK(savgol_streambank_push_wait(bank, d_s, d_o, NULL) == 1);
+        for (int t = 0; t < TICKS; ++t) {
+            const double t0 = now_us();
+            CHECK(savgol_streambank_push_wait(bank, d_s, d_o, NULL) == 1);
+            lat[t] = now_us() - t0;
+        }
+        qsort(lat, TICKS, sizeof(double), cmp_double);
+        printf("stream bank: %zu streams, n=16 m=2 d=1: per-tick wall latency p50 %.1f us  p99 %.1f us  (push_wait: launch + stream-written completion word, from C)\n", S,
+               lat[TICKS / 2], lat[(int)(TICKS * 0.99)]);
+    }
+    {
+        /* the same ticks enqueued back to back with no synchronise in between, HIP events around the lot: the device time per tick when the
+         * kernel is the slower side, the host's launch rate when it is not (the smaller of the two is not visible from here; rocprofv3's
+         * kernel trace has the kernel alone: profiles/README.md) */
+        hipEvent_t e0, e1;
+        float ms = 0.0f;
+        CHECK(hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess);
+        CHECK(hipEventRecord(e0, NULL) == hipSuccess);
+        for (int t = 0; t < TICKS; ++t) CHECK(savgol_streambank_push(bank, d_s, d_o, NULL) == 1);
+        CHECK(hipEventRecord(e1, NULL) == hipSuccess);
+        CHECK(hipEventSynchronize(e1) == hipSuccess);
+        CHECK(hipEventElapsedTime(&ms, e0, e1) == hipSuccess);
+        printf("stream bank: %zu streams, n=16 m=2 d=1: %.2f us per tick back to back (%d launches enqueued from C, no synchronise between them)\n", S,
+               (double)ms * 1e3 / TICKS, (int)TICKS);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        CHECK(savgol_streambank_samples_received(bank) == 200 + 3 * TICKS);
+    }
 
     /* ---- 3b. the same ticks through the resident service: a doorbell instead of a launch + synchronise per tick.  Noisy
      *          input this time, and every tick's output compared bit for bit with the per-tick kernel on a twin bank ---- */

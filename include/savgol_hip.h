@@ -99,7 +99,10 @@ int         savgol_hip_set_option(int option, int value);
  * non-_ex entry points use (savgol_hip_default_flags() returns them as flags).  A flag word is complete: an _ex call
  * ignores the process-wide options.  TILE_NARROW and TILE_WIDE exclude each other; neither = by job size.               */
 enum { SAVGOL_BATCH_REFERENCE_SUMMATION = 1u, SAVGOL_BATCH_PLAIN_SUMMATION = 2u, SAVGOL_BATCH_TILE_NARROW = 4u, SAVGOL_BATCH_TILE_WIDE = 8u,
-       SAVGOL_BATCH_CORRECT_LEADING_EDGE = 16u, SAVGOL_BATCH_BOUNDARY_AWARE = 32u /* strided calls only */ };
+       SAVGOL_BATCH_CORRECT_LEADING_EDGE = 16u, SAVGOL_BATCH_BOUNDARY_AWARE = 32u /* strided calls only */,
+       SAVGOL_BATCH_MOMENT_F64 = 64u /* fp64 calls, half_window 24..32: block moments replace the taps on the lanes' common block (~36 multiply-adds
+                                        per output instead of 65).  The block's share comes from the polynomial fitted to the fp32 table, so the
+                                        result is within ~1e-7 (bar: 1e-6) of the default fp64 path instead of its 1e-12.  Opt-in for that reason. */ };
 unsigned    savgol_hip_default_flags(void);
 /* Diagnostic (host only, no device needed): the constant table the wide-window (24..32) fp32 kernel reads -- SAVGOL_HIP_MOMENT_TABLE_FLOATS
  * floats: centre taps [0,66), block basis phi[s-1][t] at [80,176), own-block coefficients c[s][J][2] at [176,400); layout in
@@ -190,6 +193,10 @@ int    savgol_streambank_reset(SavgolStreamBank *bank, void *stream);
 /* one tick = one sample per stream.  Returns 1 when d_out[0..streams) holds centre outputs,
  * 0 while the windows are still filling (d_out untouched), -1 on error.                       */
 int    savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream);
+/* The same tick, and d_out is complete when the call returns: the stream writes a completion word behind the kernel (hipStreamWriteValue32 into
+ * signal memory) and the host spins on it -- the lowest-latency way to take one tick's outputs (a launch + hipStreamSynchronize costs 5-6 us more;
+ * falls back to exactly that where stream memory operations are unavailable).  Same return value as savgol_streambank_push. */
+int    savgol_streambank_push_wait(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream);
 /* with edges: returns the number of output rows written (0, 1, or up to n+1 on the tick that
  * fills the windows, truncated to max_rows), -1 on error.                                     */
 int    savgol_streambank_push_full(SavgolStreamBank *bank, const float *d_samples,

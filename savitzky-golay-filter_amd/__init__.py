@@ -31,7 +31,7 @@ SAVGOL_HIP_OPT_BOUNDARY_AWARE = 4
 SAVGOL_HIP_OPT_TILE_WIDTH = 5
 SAVGOL_STREAMBANK_FMA = 1
 SAVGOL_BATCH_REFERENCE_SUMMATION, SAVGOL_BATCH_PLAIN_SUMMATION, SAVGOL_BATCH_TILE_NARROW, SAVGOL_BATCH_TILE_WIDE = 1, 2, 4, 8
-SAVGOL_BATCH_CORRECT_LEADING_EDGE, SAVGOL_BATCH_BOUNDARY_AWARE = 16, 32
+SAVGOL_BATCH_CORRECT_LEADING_EDGE, SAVGOL_BATCH_BOUNDARY_AWARE, SAVGOL_BATCH_MOMENT_F64 = 16, 32, 64
 
 
 class SavgolConfig(C.Structure):
@@ -127,6 +127,7 @@ SIGNATURES = {
     "savgol_streambank_destroy": (None, [_vp]),
     "savgol_streambank_reset": (C.c_int, [_vp, _vp]),
     "savgol_streambank_push": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "savgol_streambank_push_wait": (C.c_int, [_vp, _vp, _vp, _vp]),
     "savgol_streambank_push_full": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "savgol_streambank_push_block": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "savgol_streambank_flush": (C.c_int, [_vp, _vp, C.c_int, _vp]),
@@ -378,6 +379,10 @@ class StreamBank:
 
     def push(self, samples, out, stream=None):
         return lib().savgol_streambank_push(self.ptr, _addr(samples), _addr(out), _stream(stream))
+
+    def push_wait(self, samples, out, stream=None):
+        """push + wait for the outputs through a stream-written completion word (savgol_streambank_push_wait)"""
+        return lib().savgol_streambank_push_wait(self.ptr, _addr(samples), _addr(out), _stream(stream))
 
     def push_full(self, samples, out, max_rows, stream=None):
         return lib().savgol_streambank_push_full(self.ptr, _addr(samples), _addr(out), max_rows, _stream(stream))

@@ -90,6 +90,9 @@ struct FilterPlan {
     const float *d_edges = nullptr, *d_ref = nullptr, *d_moment = nullptr;
     int    moment_terms = -1;                       // -1: not fitted yet
     float  moment_table[sg::MOMENT_TABLE_FLOATS];
+    const double *d_moment64 = nullptr;             // the opt-in fp64 block-moment path (SAVGOL_BATCH_MOMENT_F64)
+    int    moment64_terms = -1;
+    double moment64_table[sg::MOMENT64_TABLE_DOUBLES];
 };
 std::mutex g_plan_mu;
 std::unordered_multimap<uint64_t, FilterPlan *> g_plans;
@@ -100,7 +103,7 @@ inline size_t filter_used_bytes(const SavgolFilter *f)
 }
 
 // the plan of (filter content, device); `need` = which lazily built parts this call wants
-enum : unsigned { NEED_EDGES = 1, NEED_REF = 2, NEED_MOMENT = 4 };
+enum : unsigned { NEED_EDGES = 1, NEED_REF = 2, NEED_MOMENT = 4, NEED_MOMENT64 = 8 };
 const FilterPlan *plan_get(DeviceCtx *ctx, const SavgolFilter *f, unsigned need)
 {
     const size_t bytes = filter_used_bytes(f);
@@ -151,6 +154,14 @@ const FilterPlan *plan_get(DeviceCtx *ctx, const SavgolFilter *f, unsigned need)
             if (!p->d_moment) return nullptr;
         }
         p->moment_terms = terms;
+    }
+    if ((need & NEED_MOMENT64) && p->moment64_terms < 0) {
+        const int terms = sg1d_moment64_prepare(n, f->center_weights, p->moment64_table);
+        if (terms > 0) {
+            p->d_moment64 = reinterpret_cast<const double *>(sg::ctx_table(ctx, p->moment64_table, sizeof(p->moment64_table), 0x2000u + (unsigned)n));
+            if (!p->d_moment64) return nullptr;
+        }
+        p->moment64_terms = terms;
     }
     return p;
 }
@@ -213,8 +224,15 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     const size_t out_len = (variant == VALID) ? length - 2 * (size_t)n : length;
     if (in_ld < length || out_ld < out_len) { sg_set_error("%s: row pitch smaller than the row", who); return -1; }
     if (channels == 0) return 0;
-    // tiles read their halo from the input while neighbouring tiles store: overlapping rows would race
-    if (rows_overlap(d_in, in_ld, length, d_out, out_ld, out_len, channels)) { sg_set_error("%s: d_in and d_out overlap (the device batch calls are out of place)", who); return -1; }
+    // IN PLACE (round 5; the reference advertises output == input, include/iterative/savgolFilter.h:148): exactly the same
+    // rows -- same base, same pitch, the full-length variants -- run on the tile kernels with every tile's halo taken from a stash that is
+    // filled first (3 % of the data at n = 32), and give the OUT-OF-PLACE answer, not the reference's own in-place result (which reads samples it
+    // has already overwritten: documented divergence, as for the host-pointer call).  Any other overlap still races and is refused.
+    const bool inplace = static_cast<const void *>(d_in) == static_cast<const void *>(d_out) && in_ld == out_ld && (variant == FULL || variant == FULL_POLY_EDGES);
+    if (!inplace && rows_overlap(d_in, in_ld, length, d_out, out_ld, out_len, channels)) {
+        sg_set_error("%s: d_in and d_out overlap (in place means the SAME rows: d_out == d_in with the same pitch; partial overlaps race)", who);
+        return -1;
+    }
 
     DeviceCtx *ctx = sg::ctx_get();
     if (!ctx) return -1;
@@ -227,7 +245,18 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     // 24..32, all boundary modes; the plain three-chain kernel: 0.7-1.3 x everywhere).  Those filters take the plain kernel (8 % slower).
     const bool moment_safe = f->config.poly_order >= 2 && f->config.derivative <= 1;
     const bool want_moment = sizeof(T) == 4 && !reference_order && n >= sg::MOMENT_MIN_N && n <= sg::MOMENT_MAX_N && !(flags & SAVGOL_BATCH_PLAIN_SUMMATION) && moment_safe;
-    const FilterPlan *plan = plan_get(ctx, f, reference_order ? NEED_REF : ((want_edges ? NEED_EDGES : 0u) | (want_moment ? NEED_MOMENT : 0u)));
+    // fp64, half windows 24..32, on request only: block moments (sg_k1d_moment64.hpp) -- within ~1e-7 of the default path, not its 1e-12
+    const bool want_moment64 = sizeof(T) == 8 && (flags & SAVGOL_BATCH_MOMENT_F64) && n >= sg::MOMENT_MIN_N && n <= sg::MOMENT_MAX_N;
+    if (inplace && reference_order) {
+        // the reference-order kernels read their whole window from the rows: run them from a stream-ordered copy of the input
+        T *copy = static_cast<T *>(sg::scratch_alloc(ctx, channels * in_ld * sizeof(T), st, "scratch (in-place copy for the reference-order kernels)"));
+        if (!copy) return -1;
+        int rc = sg::hip_ok(hipMemcpyAsync(copy, d_in, ((channels - 1) * in_ld + length) * sizeof(T), hipMemcpyDeviceToDevice, st), "in-place copy") ? 0 : -1;
+        if (rc == 0) rc = enqueue_batch<T>(who, f, copy, d_out, channels, length, in_ld, out_ld, variant, st, flags);
+        if (!sg::scratch_free(copy, st, "scratch free (in-place copy)")) rc = -1;
+        return rc;
+    }
+    const FilterPlan *plan = plan_get(ctx, f, reference_order ? NEED_REF : ((want_edges ? NEED_EDGES : 0u) | (want_moment ? NEED_MOMENT : 0u) | (want_moment64 ? NEED_MOMENT64 : 0u)));
     if (!plan) return -1;
 
     if constexpr (sizeof(T) == 4) {
@@ -267,7 +296,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     int vpl = sg::vectors_per_lane(sizeof(T), f->config.half_window);
     const int vpl_wide = sg::wide_vectors_per_lane(sizeof(T), f->config.half_window);
     const int tile_mode = (flags & SAVGOL_BATCH_TILE_NARROW) ? 1 : ((flags & SAVGOL_BATCH_TILE_WIDE) ? 2 : 0);
-    const int wide = vpl_wide != vpl && tile_mode != 1 &&
+    const int wide = vpl_wide != vpl && tile_mode != 1 && !(want_moment64 && plan->moment64_terms > 0 && plan->sym) &&       // (the fp64 moment kernel is laid out for 8 vectors per lane)
                      (tile_mode == 2 || (unsigned long long)channels * ((length + 64u * vpl_wide * E - 1) / (64u * vpl_wide * E)) >= sg::WIDE_TILE_MIN_TILES);
     if (wide) vpl = vpl_wide;
     const unsigned TW = 64u * (unsigned)vpl * E;
@@ -303,6 +332,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     // half windows 24..32, fp32: block moments replace the taps on the lanes' common block when the table is a polynomial
     const float *d_moment = (want_moment && plan->moment_terms > 0) ? plan->d_moment : nullptr;
     const int moment_terms = d_moment ? plan->moment_terms : 0;
+    const double *d_moment64 = (want_moment64 && plan->moment64_terms > 0 && plan->sym) ? plan->d_moment64 : nullptr;     // a table that is not a polynomial keeps the plain kernel
 
     // the POLYNOMIAL edge rows ride in the same launch: two more items per channel behind the tiles (sg1d_edge_item)
     if (d_edges) {
@@ -317,6 +347,20 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         job.out = d_out + c0 * out_ld;
         job.total_tiles = (unsigned)(nc * job.tiles_per_channel);
         job.edge_items = d_edges ? (unsigned)(2 * nc) : 0u;
+        T *stash = nullptr;
+        if (inplace) {
+            // [tile][left NA | right NA], then [channel][end][2n+1] for the edge rows; filled before any tile of this launch stores
+            const int NA = (n + E - 1) / E * E;
+            const size_t halo = (size_t)job.total_tiles * (size_t)(2 * NA), edge = d_edges ? nc * 2 * (size_t)ws : 0;
+            stash = static_cast<T *>(sg::scratch_alloc(ctx, (halo + edge + 4) * sizeof(T), st, "scratch (in-place halo stash)"));
+            if (!stash) return -1;
+            job.stash = stash;
+            job.edge_stash = d_edges ? stash + halo : nullptr;
+            if (sg1d_launch_stash(job.in, job.in_ld, job.length, job.tiles_per_channel, job.total_tiles, (int)TW, NA, (int)(job.flags & sg::JOB_MODE_MASK), stash,
+                                  d_edges ? stash + halo : nullptr, ws, nc, (int)sizeof(T), st) != 0) { sg_set_error("%s: stash launch failed", who); (void)sg::scratch_free(stash, st, "scratch free"); return -1; }
+        }
+        const unsigned edge_items_all = job.edge_items;
+        if (inplace) job.edge_items = 0;                                 // the edge rows overwrite samples tile 0 / the last tile still read: a launch of their own, afterwards
         // one tile per wave, four waves per block, blocks dispatched in order (see sg1d_center_kernel)
         unsigned blocks = (job.total_tiles + job.edge_items + 3u) / 4u;
         blocks = (blocks + 7u) & ~7u;                                    // the XCD remap wants a multiple of 8
@@ -325,7 +369,23 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
                          : moment_terms == 5 ? sg1d_launch_f32_moment_t5(n, &job, d_moment, blocks, st)
                                              : sg1d_launch_f32_moment_t7(n, &job, d_moment, blocks, st);
             if (rc != 0) return -1;
+        } else if (d_moment64) {
+            const int mt = plan->moment64_terms;
+            const int rc = mt == 3 ? sg1d_launch_f64_moment_t3(n, &job, d_moment64, blocks, st)
+                         : mt == 5 ? sg1d_launch_f64_moment_t5(n, &job, d_moment64, blocks, st)
+                                   : sg1d_launch_f64_moment_t7(n, &job, d_moment64, blocks, st);
+            if (rc != 0) return -1;
         } else if (sg::launch_center<T>(n, wide, job, taps, blocks, st) != 0) return -1;
+        if (inplace) {
+            if (edge_items_all) {
+                sg::Job1D ej = job;
+                ej.total_tiles = 0; ej.edge_items = edge_items_all;
+                unsigned eb = (edge_items_all + 3u) / 4u;
+                eb = (eb + 7u) & ~7u;
+                if (sg::launch_center<T>(n, 0, ej, taps, eb, st) != 0) { (void)sg::scratch_free(stash, st, "scratch free"); return -1; }
+            }
+            if (!sg::scratch_free(stash, st, "scratch free (in-place halo stash)")) return -1;
+        }
     }
     return 0;
 }
@@ -570,7 +630,7 @@ static unsigned host_call_flags()
 static bool flags_ok(const char *who, unsigned flags)
 {
     const unsigned known = SAVGOL_BATCH_REFERENCE_SUMMATION | SAVGOL_BATCH_PLAIN_SUMMATION | SAVGOL_BATCH_TILE_NARROW | SAVGOL_BATCH_TILE_WIDE |
-                           SAVGOL_BATCH_CORRECT_LEADING_EDGE | SAVGOL_BATCH_BOUNDARY_AWARE;
+                           SAVGOL_BATCH_CORRECT_LEADING_EDGE | SAVGOL_BATCH_BOUNDARY_AWARE | SAVGOL_BATCH_MOMENT_F64;
     if ((flags & ~known) || ((flags & SAVGOL_BATCH_TILE_NARROW) && (flags & SAVGOL_BATCH_TILE_WIDE))) {
         sg_set_error("%s: bad flags 0x%x", who, flags);
         return false;

@@ -15,9 +15,11 @@
 //     VGPRs, the 2N+1 taps in SGPRs (they arrive as a by-value kernel argument), one v_fmac per
 //     tap per output, no shuffles, no LDS traffic inside the inner product;
 //   * results go back through the slab so that the global stores are coalesced 16-B rows.
-// The slab is padded by 16 B every 128 B, which makes the lane stride 144 B = 36 banks: the
-// per-lane b128 reads, the per-lane b128 result writes and the row-wise accesses are all
-// bank-conflict free (MI355X_MICROARCH.md, LDS table).
+// The slab is padded by 16 B every 128 B, which makes the lane stride 144 B = 36 banks: the per-lane b128 window reads and the row-wise
+// b128 staging writes are bank-conflict free (MI355X_MICROARCH.md, LDS table).  The RESULTS take another layout on their way out (round 5):
+// read back row by row through the padded layout, every ds_read_b128 lane group met two pads and lost a cycle -- exactly 32 conflict cycles
+// per tile, 10.8 % of the LDS-active cycles (profiles/r04_1d_f32_n32_pmc_summary.json) -- so they are written unpadded with an XOR swizzle
+// of the vector index (result_vec_off), conflict free for the per-lane writes and for the row-wise reads alike.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -129,6 +131,12 @@ struct K1D {
 // byte offset of slab vector v: one 16-B pad after every VPL vectors, so a lane's VPL vectors are contiguous and
 // the lane stride is (VPL+1)*16 B = 20 / 28 / 36 banks -- conflict free for the ds_read_b128 lane groups
 template <int VPL> __device__ __forceinline__ constexpr int slab_vec_off(int v) { return 16 * (v + v / VPL); }
+
+// byte offset of RESULT vector v (lane v / VPL's s-th vector, s = v % VPL) for 8 vectors per lane: no pads, the low three bits of the vector
+// index XORed with the owner lane's low three bits.  Per-lane writes (ds_write_b128: groups of 8 consecutive lanes, 32 banks) land on
+// 4 * (s ^ lane % 8): eight different quads of banks.  Row-wise reads (ds_read_b128: the lane groups {0-3, 12-15, 20-27}, ..., 64 banks) of
+// vector p = lane + 64 s' land on 16 different quads as well (worked out in profiles/EXPERIMENTS.md R5.3).
+__device__ __forceinline__ constexpr int result_vec_off8(int v) { return 16 * ((v & ~7) | ((v & 7) ^ ((v >> 3) & 7))); }
 
 
 // ---------------------------------------------------------------------------------------------
@@ -319,7 +327,16 @@ __device__ __forceinline__ void sg1d_edge_item(const Job1D &job, unsigned item, 
     const long long c = item >> 1;
     const T *__restrict__ row = static_cast<const T *>(job.in) + c * job.in_ld;
     T *__restrict__ orow = static_cast<T *>(job.out) + c * job.out_ld;
-    sg1d_edge_rows<T, N>(job.edges, job.flags, job.dt_inv, (item & 1u) != 0, (long long)job.length, lane,
+    const bool trailing = (item & 1u) != 0;
+    if (job.edge_stash) {
+        // in place: the 2n+1 samples of this channel end as they were before any tile stored (Job1D::edge_stash)
+        const T *es = static_cast<const T *>(job.edge_stash) + (long long)item * (2 * N + 1);
+        const long long base = trailing ? (long long)job.length - (2 * N + 1) : 0;
+        sg1d_edge_rows<T, N>(job.edges, job.flags, job.dt_inv, trailing, (long long)job.length, lane,
+                             [&](long long i) { return es[i - base]; }, [&](long long i, T v) { orow[i] = v; });
+        return;
+    }
+    sg1d_edge_rows<T, N>(job.edges, job.flags, job.dt_inv, trailing, (long long)job.length, lane,
                          [&](long long i) { return row[i]; }, [&](long long i, T v) { orow[i] = v; });
 }
 // the same on array-of-structs data (always the edges of a strided call: the reference's savgol_apply_strided ignores config.boundary, :902-928)
@@ -385,6 +402,37 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
     };
 
     // ---- stage tile + halo into the slab ----
+    if (job.stash) {
+        // IN PLACE (out == in): the body [ts, ts + TW) belongs to this tile alone -- nobody else reads or writes it -- and the NA samples on
+        // either side, which the neighbours overwrite in their own time, come from the stash (already remapped / zero-filled per mode)
+        const VT *st = static_cast<const VT *>(job.stash) + (size_t)tile * (2 * HV);
+        if ((job.flags & JOB_VEC_IN) && ts + TW <= L) {
+            const VT *src = reinterpret_cast<const VT *>(row + ts) - HV;              // slab vector v <-> sample ts - NA + v E
+            VT p[VPL + 1];
+#pragma unroll
+            for (int s = 0; s < VPL; ++s) {
+                if (s == 0) p[0] = lane < HV ? st[lane] : ld_stream(src + lane);
+                else p[s] = ld_stream(src + lane + 64 * s);
+            }
+            if (lane < 2 * HV) p[VPL] = lane < HV ? ld_stream(src + TV + lane) : st[lane];          // body tail, then the right halo = st[HV + (lane - HV)]
+#pragma unroll
+            for (int s = 0; s < VPL; ++s) *row_vec(s) = p[s];
+            if (lane < 2 * HV) *row_vec(VPL) = p[VPL];
+        } else {
+            // the last tile of a channel (its body ends at L) and rows without 16-byte alignment: element by element
+            const T *se = reinterpret_cast<const T *>(st);
+            const int tend = ts + TW < L ? ts + TW : L;
+#pragma unroll 4
+            for (int e = lane; e < K::SL; e += 64) {
+                const int g = ts - NA + e;
+                T x = T(0);
+                if (g < ts) x = se[e];
+                else if (g < tend) x = row[g];
+                else if (g < tend + NA) x = se[NA + (g - tend)];
+                *reinterpret_cast<T *>(slab + slab_vec_off<VPL>(e / E) + (e % E) * (int)sizeof(T)) = x;
+            }
+        }
+    } else
     // a tile is "full" when every 16-B vector of tile + halo lies inside the row: the common case
     if ((job.flags & JOB_VEC_IN) && ts - NA >= 0 && ts + TW + NA <= L) {
         const VT *src = reinterpret_cast<const VT *>(row + (ts - NA));
@@ -437,21 +485,28 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
     SG_STAMP(3);
 
     // ---- results back through the slab, then coalesced rows to HBM ----
+    constexpr bool SWZ = (VPL == 8);                     // the swizzled result layout (result_vec_off8); other tile widths keep the padded one
+    {
+        // lane's vector s: byte 128 lane + 16 (s ^ lane % 8) = (128 lane + 16 (lane % 8)) ^ (16 s): one v_xor_b32 with a literal per write
+        const int wbase = SWZ ? 128 * lane + 16 * (lane & 7) : 16 * (lane * (VPL + 1));
 #pragma unroll
-    for (int s = 0; s < VPL; ++s) {
-        VT o;
+        for (int s = 0; s < VPL; ++s) {
+            VT o;
 #pragma unroll
-        for (int e = 0; e < E; ++e) vset(o, e, acc[s * E + e]);
-        *reinterpret_cast<VT *>(slab + 16 * (lane * (VPL + 1) + s)) = o;
+            for (int e = 0; e < E; ++e) vset(o, e, acc[s * E + e]);
+            *reinterpret_cast<VT *>(slab + (SWZ ? (wbase ^ (16 * s)) : wbase + 16 * s)) = o;
+        }
     }
     wave_lds_sync();
     T *__restrict__ orow = gout + (long long)c * job.out_ld - (long long)job.out_shift;
     const int lo = (int)job.store_lo, hi = (int)job.store_hi;
     const bool whole = (job.flags & JOB_VEC_OUT) && ts >= lo && ts + TW <= hi;
     if (whole) {
+        // vector lane + 64 s of the tile: with the swizzle its offset splits into a lane part (one VGPR) and 1024 s (an immediate)
+        const char *const rbase = slab + (SWZ ? result_vec_off8(lane) : 0);
 #pragma unroll
         for (int s = 0; s < VPL; ++s) {
-            const VT o = *row_vec(s);
+            const VT o = SWZ ? *reinterpret_cast<const VT *>(rbase + 1024 * s) : *row_vec(s);
             st_stream(reinterpret_cast<VT *>(orow + ts) + lane + 64 * s, o);
         }
     } else {
@@ -461,7 +516,7 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
         for (int s = 0; s < VPL; ++s) {
             const int p = lane + 64 * s;
             const int g0 = ts + p * E;
-            const VT o = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(p));
+            const VT o = *reinterpret_cast<const VT *>(slab + (SWZ ? result_vec_off8(p) : slab_vec_off<VPL>(p)));
             if (vec && g0 >= lo && g0 + E <= hi) {
                 *reinterpret_cast<VT *>(orow + g0) = o;
             } else {

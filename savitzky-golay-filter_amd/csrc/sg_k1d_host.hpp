@@ -77,6 +77,12 @@ struct Job1D {
     // 2c + 1 = trailing end; edges = the filter's [n][2n+1] edge table on the device, NULL = none
     unsigned    edge_items;
     const float *edges;
+    // IN PLACE (out == in, round 5): no tile may read what a neighbour has already overwritten, so the NA samples on either side of every
+    // tile's body -- already remapped / zero-filled per boundary mode -- are taken from `stash` (tile t: [left NA | right NA], filled by
+    // sg1d_launch_stash before the tiles run), and the edge items read the 2n+1 samples of their channel end from `edge_stash`
+    // ([channel][end][2n+1]).  NULL = out of place: halos and edge samples come from the rows themselves.
+    const void *stash;
+    const void *edge_stash;
 };
 // The fused strided (array-of-structs) kernel, sg1d_strided_kernel<N> (reference savgol_apply_strided, src/savgolFilter.c:877-934):
 // sample i of channel c is the float at in + c * in_pitch + i * in_stride (bytes; the field offset is folded into `in`), all
@@ -129,6 +135,19 @@ constexpr int moment_lo(int n) { return (31 + moment_off(n) + 1) / 2 * 2; }     
 constexpr int moment_hi(int n) { return (moment_off(n) + 2 * n + 1) / 2 * 2; }        // one past its last sample (even)
 struct MomentArgs { const float *table; };
 
+// The opt-in fp64 block-moment path (sg_k1d_moment64.hpp, half windows 24..32, SAVGOL_BATCH_MOMENT_F64): 16 outputs per lane, the window is
+// X[0 .. 16 + 2n + OFF), the common block X[LO .. HI) with LO = 15 + OFF, HI = OFF + 2n + 1 (2n - 14 samples: 50 at n = 32), paired front to back.
+//   doubles [0, 16)     centre taps 0..14 (exact promotions of the fp32 table), one pad
+//   doubles [16, 166)   phi[t][s-1] = P_s((t - (BK-1)/2) / (BK/2)), t = 0..BK/2-1 (<= 25 pairs), s = 1..6: six per pair whatever the term count
+//   doubles [166, 278)  c[s][r], s = 0..6, r = 0..15: the block's share of output r is sum_s c_s(r) mu_s
+constexpr int MOMENT64_MAX_PAIRS = 25;
+constexpr int MOMENT64_OFF_W = 0, MOMENT64_OFF_PHI = 16, MOMENT64_OFF_C = MOMENT64_OFF_PHI + MOMENT64_MAX_PAIRS * 6;
+constexpr int MOMENT64_TABLE_DOUBLES = MOMENT64_OFF_C + MOMENT_MAX_TERMS * 16;
+constexpr int moment64_off(int n) { return (n + 1) / 2 * 2 - n; }                     // OFF of K1D<double, n>
+constexpr int moment64_lo(int n) { return 15 + moment64_off(n); }
+constexpr int moment64_hi(int n) { return moment64_off(n) + 2 * n + 1; }
+struct Moment64Args { const double *table; };
+
 enum : unsigned {
     JOB_MODE_MASK  = 0xffu,             // SavgolBoundaryMode value; 0/unknown: out-of-range reads are 0
     JOB_SCALE      = 1u << 8,           // multiply by dt_inv (dt_inv != 1)
@@ -164,7 +183,15 @@ int sg1d_launch_f32_moment_t7(int n, const sg::Job1D *job, const float *d_table,
 // needs (3, 5, 7) or 0 when n is outside 24..32 or the taps are not a polynomial of degree <= 6 to fp32 rounding
 // (sg_k1d_moment_fit.cpp)
 int sg1d_moment_prepare(int n, const float *center_weights, float *table);
+// the opt-in fp64 counterpart: table[MOMENT64_TABLE_DOUBLES]; same return value
+int sg1d_moment64_prepare(int n, const float *center_weights, double *table);
+int sg1d_launch_f64_moment_t3(int n, const sg::Job1D *job, const double *d_table, unsigned grid, void *stream);
+int sg1d_launch_f64_moment_t5(int n, const sg::Job1D *job, const double *d_table, unsigned grid, void *stream);
+int sg1d_launch_f64_moment_t7(int n, const sg::Job1D *job, const double *d_table, unsigned grid, void *stream);
 
+// fills Job1D::stash / edge_stash for an in-place call (elem_bytes 4 / 8; tile width TW and rounded halo NA as the tile kernel will use them)
+int sg1d_launch_stash(const void *in, long long in_ld, unsigned length, unsigned tiles_per_channel, unsigned total_tiles, int TW, int NA, int mode,
+                      void *stash, void *edge_stash, int ws, size_t channels, int elem_bytes, void *stream);
 int sg1d_launch_reference_order_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
                                     const float *d_table, float dt_inv, int mode, int store_lo, int store_hi, int out_shift,
                                     int negate_leading, size_t channels, void *stream);

@@ -552,6 +552,55 @@ int sg_launch_scatter_f32(const float *src, size_t src_ld, void *base, size_t st
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---- in-place batch calls (round 5): what every tile will need from OUTSIDE its own body, captured before any tile stores ----
+}  // extern "C"
+namespace sg {
+template <typename T>
+__global__ __launch_bounds__(256) void sg1d_stash_kernel(const T *__restrict__ in, long long in_ld, int L, unsigned tiles_per_channel, unsigned total_tiles, int TW,
+                                                         int NA, int mode, T *__restrict__ stash, T *__restrict__ edge_stash, int ws, size_t channels)
+{
+    const size_t halo_items = (size_t)total_tiles * (size_t)(2 * NA);
+    const size_t edge_items = edge_stash ? channels * 2 * (size_t)ws : 0;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < halo_items + edge_items; idx += (size_t)gridDim.x * 256) {
+        if (idx < halo_items) {
+            const unsigned tile = (unsigned)(idx / (size_t)(2 * NA));
+            const int j = (int)(idx % (size_t)(2 * NA));
+            const unsigned c = tile / tiles_per_channel;
+            const int ts = (int)(tile - c * tiles_per_channel) * TW;
+            const int tend = ts + TW < L ? ts + TW : L;
+            int g = j < NA ? ts - NA + j : tend + (j - NA);
+            const T *row = in + (long long)c * in_ld;
+            bool zero = false;
+            if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
+            stash[idx] = zero ? T(0) : row[g];
+        } else {
+            const size_t k = idx - halo_items;
+            const size_t c = k / (2 * (size_t)ws);
+            const int r = (int)(k % (2 * (size_t)ws));
+            const int g = r < ws ? r : L - ws + (r - ws);                              // leading end: samples 0..2n, trailing end: L-ws..L-1
+            edge_stash[k] = in[(long long)c * in_ld + g];
+        }
+    }
+}
+}  // namespace sg
+extern "C" {
+int sg1d_launch_stash(const void *in, long long in_ld, unsigned length, unsigned tiles_per_channel, unsigned total_tiles, int TW, int NA, int mode,
+                      void *stash, void *edge_stash, int ws, size_t channels, int elem_bytes, void *stream)
+{
+    const size_t items = (size_t)total_tiles * (size_t)(2 * NA) + (edge_stash ? channels * 2 * (size_t)ws : 0);
+    if (items == 0) return 0;
+    size_t blocks = (items + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL(sg::sg1d_stash_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float *>(in), in_ld, (int)length, tiles_per_channel,
+                           total_tiles, TW, NA, mode, static_cast<float *>(stash), static_cast<float *>(edge_stash), ws, channels);
+    else
+        hipLaunchKernelGGL(sg::sg1d_stash_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const double *>(in), in_ld, (int)length, tiles_per_channel,
+                           total_tiles, TW, NA, mode, static_cast<double *>(stash), static_cast<double *>(edge_stash), ws, channels);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---- bench utilities: what the memory system gives a plain stream of the same buffers ("a device copy timed in the same
 // harness").  One 16-byte vector per thread, nontemporal, blocks in launch order: the fastest copy shape measured on MI355X
 // (tools/membench2.hip: 0.79-0.81 of 8 TB/s; hipMemcpyDtoD reaches 0.59).

@@ -122,3 +122,59 @@ extern "C" int sg1d_moment_prepare(int n, const float *w, float *table)
     }
     return terms;
 }
+
+// The same for the opt-in fp64 kernel (sg_k1d_moment64.hpp): 16 outputs per lane, the block X[LO .. HI) = 2n - 14 samples.  Everything
+// stays in double: the taps applied one by one are exact promotions of the fp32 table, the block's share comes from the fitted polynomial.
+extern "C" int sg1d_moment64_prepare(int n, const float *w, double *table)
+{
+    if (n < sg::MOMENT_MIN_N || n > sg::MOMENT_MAX_N) return 0;
+    const int WS = 2 * n + 1, OFF = sg::moment64_off(n), LO = sg::moment64_lo(n), HI = sg::moment64_hi(n), BLOCK = HI - LO;
+    double zk[MAXWS], wk[MAXWS], wmax = 0.0;
+    for (int k = 0; k < WS; ++k) {
+        zk[k] = (double)(k - n) / n; wk[k] = (double)w[k];
+        if (!std::isfinite(wk[k])) return 0;
+        if (std::fabs(wk[k]) > wmax) wmax = std::fabs(wk[k]);
+    }
+    if (wmax == 0.0) return 0;
+    int terms = 0;
+    double coef[MAXT] = {};
+    for (int t : {3, 5, 7}) {
+        double c[MAXT] = {}, P[MAXT];
+        if (!fit(t, WS, zk, wk, c)) continue;
+        double worst = 0.0;
+        for (int k = 0; k < WS; ++k) {
+            legendre(zk[k], t, P);
+            double v = 0.0;
+            for (int s = 0; s < t; ++s) v += c[s] * P[s];
+            worst = std::fmax(worst, std::fabs(v - wk[k]));
+        }
+        if (worst <= 3e-7 * wmax) { terms = t; memcpy(coef, c, sizeof(coef)); break; }
+    }
+    if (!terms) return 0;
+    auto p = [&](double k) {
+        double P[MAXT], v = 0.0;
+        legendre((k - n) / n, terms, P);
+        for (int s = 0; s < terms; ++s) v += coef[s] * P[s];
+        return v;
+    };
+    memset(table, 0, sizeof(double) * sg::MOMENT64_TABLE_DOUBLES);
+    for (int k = 0; k < 15; ++k) table[sg::MOMENT64_OFF_W + k] = (double)w[k];
+    double phi[2 * sg::MOMENT64_MAX_PAIRS][MAXT];
+    for (int t = 0; t < BLOCK; ++t) legendre((t - 0.5 * (BLOCK - 1)) / (0.5 * BLOCK), terms, phi[t]);
+    for (int t = 0; t < BLOCK / 2; ++t)
+        for (int s = 1; s < terms; ++s) table[sg::MOMENT64_OFF_PHI + t * 6 + (s - 1)] = phi[t][s];
+    for (int r = 0; r < 16; ++r) {
+        double G[MAXT][MAXT] = {}, b[MAXT] = {}, c[MAXT] = {};
+        for (int t = 0; t < BLOCK; ++t) {
+            // the kernel forms phi_s(BLOCK-1-t) as (-1)^s phi_s(t): use exactly those values
+            double Pr[MAXT];
+            const int tm = t < BLOCK / 2 ? t : BLOCK - 1 - t;
+            for (int s = 0; s < terms; ++s) Pr[s] = (t < BLOCK / 2 || !(s & 1)) ? phi[tm][s] : -phi[tm][s];
+            const double q = p((double)(LO + t - r - OFF));
+            for (int s = 0; s < terms; ++s) { b[s] += Pr[s] * q; for (int u = 0; u < terms; ++u) G[s][u] += Pr[s] * Pr[u]; }
+        }
+        if (!solve(terms, G, b, c)) return 0;
+        for (int s = 0; s < terms; ++s) table[sg::MOMENT64_OFF_C + s * 16 + r] = c[s];
+    }
+    return terms;
+}

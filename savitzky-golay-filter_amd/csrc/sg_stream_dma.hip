@@ -33,6 +33,12 @@ namespace sg {
 #ifndef SG_DMA_WPB
 #define SG_DMA_WPB 4                                         // waves per block (independent: only how waves are dealt to CUs and how LDS is carved)
 #endif
+#ifndef SG_DMA_STORE_AUX
+#define SG_DMA_STORE_AUX 0                                   // cache policy bits of the output stores (2 = nontemporal); A/B'd in profiles/r05_stream_dma.txt
+#endif
+#ifndef SG_DMA_LOAD_NT
+#define SG_DMA_LOAD_NT 0
+#endif
 #ifndef SG_DMA_MAX_N
 #define SG_DMA_MAX_N 16
 #endif
@@ -62,8 +68,13 @@ template <int K> __device__ __forceinline__ void wait_vm()
 __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_dst)
 {
     unsigned keep;
+#if SG_DMA_LOAD_NT
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#endif
 }
 
 // vmcnt bookkeeping, all at compile time.  The wave's vector-memory queue, in issue order: the DP DMAs of the prologue, then per step j
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job
             const f32x2 y = a * f32x2{job.dt_inv, job.dt_inv};
             float *orow = job.out + (size_t)(tt < (long long)job.ticks ? tt : 0) * job.streams;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow, 0, has_out ? row_bytes : 0, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), rs, (int)voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), rs, (int)voff, 0, SG_DMA_STORE_AUX);
         }
     };
     // Step g consumes pair g (already in xa, xb), after it has waited for pair g + 1 and issued its LDS reads (their latency hides behind

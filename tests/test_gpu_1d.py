@@ -476,15 +476,17 @@ def test_reference_summation_batch_mode_is_bit_identical(sg, sgo, torch_gpu, n):
 
 
 def test_overlapping_device_buffers_are_refused(sg, torch_gpu):
-    """The device batch calls are out of place (tiles read halos while their neighbours store); savgol_hip.h says so and
-    the call checks instead of racing silently."""
+    """Partially overlapping device buffers race (tiles read halos while their neighbours store): refused, not run silently.
+    Exactly the same rows -- in place -- are served since round 5 (test_device_batch_in_place below)."""
     torch = torch_gpu
     x = torch.randn((4, 5000), device="cuda")
     f = sg.Filter(8, 3)
     with pytest.raises(RuntimeError, match="overlap"):
-        f.apply_batch(x, x, 4, 5000)
+        f.apply_batch(x, x[1:], 3, 5000)                 # shifted by one row
     with pytest.raises(RuntimeError, match="overlap"):
-        f.apply_batch(x, x[1:], 3, 5000)                 # shifted by one row: still overlapping
+        f.apply_batch(x.data_ptr(), x.data_ptr() + 4 * 8, 1, 4000, 5000, 5000)      # shifted by 8 samples inside the row
+    with pytest.raises(RuntimeError, match="overlap"):
+        f.apply_batch(x, x, 4, 5000, valid=True)         # VALID writes out[j - n]: not the same rows
     y = torch.empty_like(x)
     f.apply_batch(x, y, 4, 5000)                         # disjoint: fine
 
@@ -531,6 +533,49 @@ def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu, n):
     finally:
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_PLAIN_SUMMATION, 0)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n", [32, 31, 30, 29, 28, 27, 26, 25, 24])
+def test_fp64_block_moment_opt_in(sg, sgo, torch_gpu, n):
+    """SAVGOL_BATCH_MOMENT_F64 (round 5, csrc/sg_k1d_moment64.hpp; reference loop src/savgolFilter.c:763-766 on fp64 data, oracle: SURVEY 8c's
+    promoted tables + double accumulation).  The DEFAULT fp64 path stays at 1e-12 of that oracle; the opt-in block-moment path takes its block's
+    share from the polynomial fitted to the fp32 table, so it sits at the fit's residual -- the bar is north_star's 1e-6, measured ~1e-7 -- for every
+    boundary mode, VALID, derivatives 0..2, time steps other than 1, ragged lengths (channel-end tiles, a single short row); the flag selects
+    another kernel (outputs differ), is ignored outside 24..32 and for fp32, and a hand-edited table that is not a polynomial keeps the plain
+    kernel (bit-identical outputs with and without the flag)."""
+    torch = torch_gpu
+    F = sg.SAVGOL_BATCH_MOMENT_F64
+    worst = 0.0
+    for length in (70001, 2 * n + 1, 1024 + 2 * n + 3):
+        x = torch.empty((5, length), dtype=torch.float64, device="cuda")
+        sg.synth(x, channel0=n)
+        xh = x.cpu().numpy()
+        for (m, d, mode, dt) in [(4, 0, 0, 1.0), (4, 0, 1, 1.0), (4, 0, 2, 1.0), (4, 0, 3, 1.0), (2, 0, 1, 1.0), (6, 0, 1, 1.0), (4, 1, 3, 1.0),
+                                 (4, 2, 0, 1.0), (3, 1, 2, 0.25), (4, 2, 1, 1e-3), (0, 0, 1, 1.0), (5, 1, 0, 1.0)]:
+            f = sg.Filter(n, m, d, dt, mode)
+            ref = sgo.Filter(n, m, d, dt, mode).apply_f64(xh)
+            a = f.apply_tensor(x, flags=0).cpu().numpy()
+            b = f.apply_tensor(x, flags=F).cpu().numpy()
+            assert normwise(a, ref) < TOL_F64, (n, m, d, mode, normwise(a, ref))
+            check(normwise(b, ref), 1e-6, ("fp64 block moments", n, m, d, mode, length))
+            worst = max(worst, normwise(b, ref))
+            if length > 4 * n:
+                assert not np.array_equal(a, b), "the flag did not switch kernels"
+                v = f.apply_tensor(x, valid=True, flags=F).cpu().numpy()
+                check(normwise(v, ref[:, n:-n]), 1e-6, ("fp64 block moments, VALID", n, m, d, mode))
+    print(f"n={n}: fp64 block-moment path, worst normwise distance from the fp64 oracle {worst:.3e}")
+    assert worst < 5e-7                                              # what the fit's 3e-7 residual bound allows with room; measured ~1e-7
+    # fp32 ignores the flag; half windows outside 24..32 ignore it
+    x32 = torch.empty((3, 9000), dtype=torch.float32, device="cuda"); sg.synth(x32)
+    f = sg.Filter(n, 4, 0, 1.0, 1)
+    assert torch.equal(f.apply_tensor(x32, flags=0), f.apply_tensor(x32, flags=F))
+    x = torch.empty((3, 9000), dtype=torch.float64, device="cuda"); sg.synth(x)
+    g = sg.Filter(16, 4, 0, 1.0, 1)
+    assert torch.equal(g.apply_tensor(x, flags=0), g.apply_tensor(x, flags=F))
+    # a symmetric table that is not a polynomial: the fit refuses it, both calls run the plain kernel
+    f.ptr.contents.center_weights[20] += 3e-4
+    f.ptr.contents.center_weights[2 * n - 20] += 3e-4
+    assert torch.equal(f.apply_tensor(x, flags=0), f.apply_tensor(x, flags=F))
 
 
 @pytest.mark.parametrize("n,m,d,mode", [(32, 4, 0, 0), (5, 3, 1, 0), (16, 2, 0, 1), (7, 3, 2, 2), (32, 4, 0, 3)])
@@ -665,6 +710,45 @@ def test_wide_and_narrow_tiles_give_the_same_bits_on_ragged_batches(sg, sgo, tor
         assert L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_TILE_WIDTH, 3) == -1
     finally:
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_TILE_WIDTH, 0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n,m,d", [(32, 4, 0), (5, 3, 1), (16, 2, 2), (1, 0, 0), (27, 4, 1), (13, 5, 0)])
+def test_device_batch_in_place(sg, sgo, torch_gpu, n, m, d, dtype):
+    """savgol_apply_batch_f32 / _f64 with d_out == d_in (round 5; the reference advertises `output` may equal `input`,
+    include/iterative/savgolFilter.h:148, loop src/savgolFilter.c:763-766): the in-place call must give the OUT-OF-PLACE answer bit for bit
+    -- same kernels, same arithmetic; every tile's halo comes from a stash filled before any tile stores -- for all four boundary modes,
+    lengths that end inside a tile, one-tile and shorter-than-a-tile channels, a row pitch with slack (the slack untouched), rows without
+    16-byte alignment, the reference-summation flag (a staged copy) and -- fp64 -- the block-moment flag."""
+    torch = torch_gpu
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    tile = 2048 if dtype == "f32" else 1024
+    flag_sets = [0] + ([sg.SAVGOL_BATCH_REFERENCE_SUMMATION] if dtype == "f32" else [sg.SAVGOL_BATCH_MOMENT_F64])
+    for ch, length, ld, off in ((5, 3 * tile + 2 * n + 7, 3 * tile + 2 * n + 12, 0), (3, 2 * n + 1, 2 * n + 4, 0), (2, tile, tile, 0), (4, 70001, 70004, 0), (3, 5000, 5003, 1)):
+        buf = torch.full((ch * ld + 8,), -7.0, dtype=tdt, device="cuda")
+        rows = buf[off:off + ch * ld].view(ch, ld)
+        src = torch.empty((ch, length), dtype=tdt, device="cuda")
+        sg.synth(src, channel0=3 * n + ch)
+        for mode in range(4):
+            f = sg.Filter(n, m, d, 0.5 if d else 1.0, mode)
+            for flags in flag_sets:
+                want = torch.empty((ch, length), dtype=tdt, device="cuda")
+                f.apply_batch(src, want, ch, length, dtype=dtype, flags=flags)
+                rows[:, :length] = src
+                esz = buf.element_size()
+                f.apply_batch(buf.data_ptr() + off * esz, buf.data_ptr() + off * esz, ch, length, ld, ld, dtype=dtype, flags=flags)
+                torch.cuda.synchronize()
+                assert torch.equal(rows[:, :length], want), (n, m, d, dtype, ch, length, mode, flags)
+                assert bool((rows[:, length:] == -7.0).all()) and bool((buf[:off] == -7.0).all()) and bool((buf[off + ch * ld:] == -7.0).all())
+    # and against the oracle, once: the in-place answer is the right answer, not merely the same one
+    x = torch.empty((3, 9000), dtype=tdt, device="cuda"); sg.synth(x)
+    xh = x.cpu().numpy().astype(np.float64)
+    f = sg.Filter(n, m, d, 1.0, 1)
+    f.apply_batch(x, x, 3, 9000, dtype=dtype)
+    torch.cuda.synchronize()
+    o = sgo.Filter(n, m, d, 1.0, 1)
+    ref = o.apply_f64(xh)
+    check(normwise(x.cpu().numpy(), ref), TOL_F64 if dtype == "f64" else bar32(o, xh.astype(np.float32), ref), ("in place vs oracle", n, m, d, dtype))
 
 
 @pytest.mark.parametrize("n", [24, 25, 26, 27, 28, 29, 30, 31, 32, 5, 12, 16, 20])
@@ -1059,7 +1143,7 @@ def test_scratch_pool_hands_its_memory_back(sg, torch_gpu):
     assert L.savgol_hip_scratch_reserved() == 0
     staged_call()
     assert L.savgol_hip_synchronize(None) == 0                        # synchronises the stream; the pool keeps its threshold for the next call
-    assert 0 < L.savgol_hip_scratch_reserved() <= (256 << 20) + (64 << 20)
+    assert L.savgol_hip_scratch_reserved() <= (256 << 20) + (64 << 20)      # (a call that needed more than the threshold leaves anything from 0 to the threshold behind)
     staged_call()                                                     # ... which re-uses the kept frames: nothing more is reserved than one call needs
     torch.cuda.synchronize()
     assert L.savgol_hip_scratch_reserved() <= (256 << 20) + (64 << 20)

@@ -515,3 +515,28 @@ def test_fma_bank_is_within_the_fp32_bar_of_the_fp64_oracle(sg, sgo, torch_gpu, 
         assert fast.flush(e1, n) == ref.flush(e2, n) == n
         assert torch.equal(e1.view(torch.int32), e2.view(torch.int32))
     assert sg.lib().savgol_streambank_create_ex(None, 4, 1) is None
+
+
+def test_push_wait_returns_complete_outputs(sg, sgo, torch_gpu):
+    """savgol_streambank_push_wait (round 5): one tick whose outputs are complete on return -- the stream writes a completion word behind the
+    tick kernel and the host spins on it, no hipStreamSynchronize.  Same values, bit for bit, as savgol_streambank_push + synchronise on a twin
+    bank (the reference's savgol_stream_push arithmetic, src/savgol_stream.c:152-178), through the filling phase, on the default and on another
+    stream, and read back WITHOUT any synchronise in between."""
+    torch = torch_gpu
+    S, n = 4096, 8
+    a, b = sg.StreamBank(S, n, 3, 0, 1.0), sg.StreamBank(S, n, 3, 0, 1.0)
+    x = torch.randn((60, S), device="cuda")
+    oa = torch.zeros(S, device="cuda"); ob = torch.zeros(S, device="cuda")
+    pinned = torch.zeros(S).pin_memory()
+    side = torch.cuda.Stream()
+    for t in range(60):
+        st = side if t % 2 else None
+        if st is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        ra = a.push_wait(x[t], oa, stream=st)
+        rb = b.push(x[t], ob)
+        torch.cuda.synchronize()
+        assert ra == rb == (1 if t >= 2 * n else 0)
+        if ra:
+            assert torch.equal(oa, ob), t
+    assert a.counters[0] == 60 and a.counters[1] == 60 - 2 * n

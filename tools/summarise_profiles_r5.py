@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/r5_prof (tools/run_profiles_r5.sh) into the files under profiles/:
+   r05_headline_repro.json        per fresh process: rocprofv3's average for the headline kernel AND bench.py's own HIP-event average /
+                                  median of the same run, the buffer addresses; min / median / max over the runs
+   r05_bench_kernel_stats.csv     rocprofv3 --stats of run 1, verbatim
+   r05_*_pmc_summary.json         FETCH x2 + WRITE traffic and the SQ counters of the four dominant kernels (tools/pmc_summary.py)
+   r05_bench_line.json            the un-profiled driver-format line of the same box"""
+import csv, glob, json, os, shutil, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(ROOT, "gpurun_out", "r5_prof")
+P = os.path.join(ROOT, "profiles")
+
+
+def last_json(path):
+    for line in reversed(open(path).read().strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise ValueError(path)
+
+
+runs = []
+for i in range(1, 6):
+    stats = glob.glob(os.path.join(O, f"repro{i}", "**", "*kernel_stats.csv"), recursive=True)
+    if not stats or not os.path.exists(os.path.join(O, f"repro{i}.json")):
+        continue
+    line = last_json(os.path.join(O, f"repro{i}.json"))
+    rp = None
+    for row in csv.DictReader(open(stats[0])):
+        if "sg1d_center_moment_kernel" in row["Name"]:
+            rp = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6, "min_ms": float(row["MinNs"]) / 1e6, "max_ms": float(row["MaxNs"]) / 1e6}
+    r = line["roofline"]
+    runs.append({"run": i, "rocprofv3_kernel_stats": rp, "bench_py_events": {k: r.get(k) for k in ("avg_launch_ms", "median_launch_ms", "min_launch_ms", "max_launch_ms", "launches_timed", "frac", "frac_at_median")},
+                 "ms_per_step": line["ms_per_step"], "value_Msamples_per_s": line["value"], "buffers": line.get("buffers")})
+    if i == 1:
+        shutil.copy(stats[0], os.path.join(P, "r05_bench_kernel_stats.csv"))
+alg = 8.0 * 4096 * (1 << 20)
+if runs:
+    rp = [r["rocprofv3_kernel_stats"]["avg_ms"] for r in runs if r["rocprofv3_kernel_stats"]]
+    ev = [r["bench_py_events"]["avg_launch_ms"] for r in runs]
+    med = [r["bench_py_events"]["median_launch_ms"] for r in runs]
+    summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-extra   (five fresh processes, one after the other, one box)",
+               "kernel": "sg1d_center_moment_kernel<32, 5>", "algorithmic_bytes_per_launch": alg, "runs": runs,
+               "rocprofv3_avg_ms": {"min": min(rp), "median": float(np.median(rp)), "max": max(rp)},
+               "bench_py_avg_ms": {"min": min(ev), "median": float(np.median(ev)), "max": max(ev)},
+               "bench_py_median_ms": {"min": min(med), "median": float(np.median(med)), "max": max(med)},
+               "roofline_frac_from_rocprofv3": {"min": alg / (max(rp) * 1e-3) / 8e12, "median": alg / (float(np.median(rp)) * 1e-3) / 8e12, "max": alg / (min(rp) * 1e-3) / 8e12},
+               "check_profile_median_x4_over_ms_per_step": [4 * float(np.median(rp)) / r["ms_per_step"] for r in runs]}
+    json.dump(summary, open(os.path.join(P, "r05_headline_repro.json"), "w"), indent=1)
+    print(json.dumps({k: summary[k] for k in ("rocprofv3_avg_ms", "bench_py_avg_ms", "roofline_frac_from_rocprofv3", "check_profile_median_x4_over_ms_per_step")}, indent=1))
+if os.path.exists(os.path.join(O, "bench_line.json")):
+    shutil.copy(os.path.join(O, "bench_line.json"), os.path.join(P, "r05_bench_line.json"))
+
+SRC_2D = ["sg_2d_roll.hip", "sg_2d.hpp", "sg_2d.hip"]
+SRC_STREAM = ["sg_stream_dma.hip", "sg_stream_roll.hip", "sg_stream_roll.hpp", "sg_stream.hpp", "sg_pk.hpp"]
+jobs = [("f32", "sg1d_center_moment_kernel<32, 5>", 8.0 * 4096 * (1 << 20), None, "r05_1d_f32_n32_pmc_summary.json", "bench.py --no-cpu --no-extra --steps 2 --warmup 1", "BASELINE config 2: 4096 x 2^20 fp32, n=32, m=4"),
+        ("f64", "sg1d_center_kernel<double, 32", 16.0 * 1024 * (1 << 22), None, "r05_1d_f64_n32_pmc_summary.json", "bench.py --workload batch1d_f64 --c5-channels 1024 --no-cpu --steps 2 --warmup 1", "BASELINE config 5 chunk: 1024 x 2^22 fp64, n=32, m=4, d=2"),
+        ("f64m", "sg1d_center_moment64_kernel<32, 5>", 16.0 * 1024 * (1 << 22), None, "r05_1d_f64m_n32_pmc_summary.json", "bench.py --workload batch1d_f64 --c5-channels 1024 --no-cpu --steps 2 --warmup 1 --f64-moment", "BASELINE config 5 chunk, OPT-IN block moments (SAVGOL_BATCH_MOMENT_F64): 1024 x 2^22 fp64, n=32, m=4, d=2"),
+        ("stream", "sg_bank_dma_kernel<16, true", 8.0 * 65536 * 4096, SRC_STREAM, "r05_stream_block_pmc_summary.json", "bench.py --workload stream --no-cpu --no-extra --steps 3 --warmup 1", "BASELINE config 3 block push: 65536 streams x 4096 ticks, n=16, m=2, d=1, SAVGOL_STREAMBANK_FMA"),
+        ("image", "sg2d_rolling_kernel<7, 2, 1, true, false, 16>", 8.0 * 512 * 4096 * 4096, SRC_2D, "r05_2d_config4_pmc_summary.json", "bench.py --workload image --no-cpu --steps 1 --warmup 1", "BASELINE config 4: 512 x 4096^2 fp32, n=7, order 3 (additive form, 16-row tiles)")]
+for name, kernel, algb, src, out, cmd, wl in jobs:
+    if not os.path.isdir(os.path.join(O, name + "_fetch")):
+        continue
+    args = [sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "--kernel", kernel, "--alg-bytes", str(algb), "--fetch", os.path.join(O, name + "_fetch"),
+            "--write", os.path.join(O, name + "_write"), "--sq", os.path.join(O, name + "_sq"), "--command", "rocprofv3 --kernel-trace --pmc <set> -- python3 " + cmd,
+            "--workload", wl, "--out", os.path.join(P, out)]
+    if src:
+        args += ["--sources"] + src
+    r = subprocess.run(args, capture_output=True, text=True)
+    print(name, "rc", r.returncode, r.stderr[-400:] if r.returncode else "")
