@@ -193,9 +193,9 @@ int    savgol_streambank_reset(SavgolStreamBank *bank, void *stream);
 /* one tick = one sample per stream.  Returns 1 when d_out[0..streams) holds centre outputs,
  * 0 while the windows are still filling (d_out untouched), -1 on error.                       */
 int    savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream);
-/* The same tick, and d_out is complete when the call returns: the stream writes a completion word behind the kernel (hipStreamWriteValue32 into
- * signal memory) and the host spins on it -- the lowest-latency way to take one tick's outputs (a launch + hipStreamSynchronize costs 5-6 us more;
- * falls back to exactly that where stream memory operations are unavailable).  Same return value as savgol_streambank_push. */
+/* The same tick, and d_out is complete (in memory: write-through stores) when the call returns: the tick kernel's last block writes a sequence
+ * number into a word of pinned host memory and the host spins on it -- no hipStreamSynchronize.  The lowest-latency way to take one tick's
+ * outputs.  Needs a multiple of 64 streams; otherwise it is push + hipStreamSynchronize.  Same return value as savgol_streambank_push. */
 int    savgol_streambank_push_wait(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream);
 /* with edges: returns the number of output rows written (0, 1, or up to n+1 on the tick that
  * fills the windows, truncated to max_rows), -1 on error.                                     */

@@ -69,12 +69,39 @@ __device__ __forceinline__ float ring_dot_global(const float *__restrict__ ring,
     return ring_dot([&](int slot) { return ring[(size_t)slot * streams + s]; }, w, ws, wp, backward);
 }
 
+// savgol_streambank_push_wait: the tick kernel itself tells the host that it is done.  Outputs leave with write-through stores; every wave
+// drains them (vmcnt(0)), the block meets, one lane takes a ticket; the block that draws the last ticket re-arms the counter and writes the
+// sequence number into a word of pinned host memory the caller spins on -- no hipStreamSynchronize (5-6 us) on the way.
+struct TickSignal {
+    unsigned *counter;               // device word, zero between ticks
+    unsigned *flag;                  // device view of a pinned host word
+    unsigned  seq;                   // what the host waits for; counter == nullptr: no signalling
+};
+__device__ __forceinline__ void tick_signal(const TickSignal &sig)
+{
+    if (!sig.counter) return;                                      // uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(sig.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1) {
+            __hip_atomic_store(sig.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sig.flag, sig.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__device__ __forceinline__ void store_out(float *p, float v, bool through)
+{
+    if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // write-through: in memory once vmcnt drains
+    else *p = v;
+}
+
 // write one sample per stream at slot wp_old, then (if `emit`) the centre output of the window that
 // now starts at wp_new = (wp_old + 1) % ws
 __global__ __launch_bounds__(256) void sg_bank_tick_kernel(float *__restrict__ ring, const float *__restrict__ samples,
                                                            float *__restrict__ out, size_t streams,
                                                            const float *__restrict__ table, int ws, int wp_old,
-                                                           float dt_inv, int emit)
+                                                           float dt_inv, int emit, const TickSignal sig)
 {
     __shared__ float wl[SAVGOL_MAX_WINDOW];
     if (emit) {
@@ -82,13 +109,16 @@ __global__ __launch_bounds__(256) void sg_bank_tick_kernel(float *__restrict__ r
         __syncthreads();
     }
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= streams) return;
-    ring[(size_t)wp_old * streams + s] = samples[s];
-    if (!emit) return;
-    int wp = wp_old + 1;
-    if (wp >= ws) wp -= ws;
-    // the slot just written is read back by the same thread: program order is enough
-    out[s] = __fmul_rn(ring_dot_global(ring, streams, s, wl, ws, wp, false), dt_inv);
+    if (s < streams) {                                             // (no early return: every thread reaches tick_signal's barrier exactly once)
+        ring[(size_t)wp_old * streams + s] = samples[s];
+        if (emit) {
+            int wp = wp_old + 1;
+            if (wp >= ws) wp -= ws;
+            // the slot just written is read back by the same thread: program order is enough
+            store_out(out + s, __fmul_rn(ring_dot_global(ring, streams, s, wl, ws, wp, false), dt_inv), sig.counter != nullptr);
+        }
+    }
+    tick_signal(sig);
 }
 
 // rows of outputs from the current ring contents: row r uses table row rows[r] (0 = centre,
@@ -221,11 +251,14 @@ static int dispatch_block(int n, const float *ring, const float *samples, float 
 template <int N, bool FMA>
 __global__ __launch_bounds__(256) void sg_bank_tick_n_kernel(float *__restrict__ ring, const float *__restrict__ samples,
                                                              float *__restrict__ out, size_t streams, const StreamTaps taps,
-                                                             int wp_old, float dt_inv)
+                                                             int wp_old, float dt_inv, const TickSignal sig)
 {
     constexpr int WS = 2 * N + 1;
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= streams) return;
+    if (s >= streams) {
+        if (sig.counter) tick_signal(sig);                         // only whole-wave tails come here (256-thread blocks, streams a multiple of 64 when signalling)
+        return;
+    }
     const float xnew = samples[s];
     ring[(size_t)wp_old * streams + s] = xnew;
     float v[WS];
@@ -252,23 +285,24 @@ __global__ __launch_bounds__(256) void sg_bank_tick_n_kernel(float *__restrict__
 #pragma unroll
         for (int i = 0; i < WS; ++i) acc = __fadd_rn(acc, __fmul_rn(taps.w[i], v[i]));
     }
-    out[s] = __fmul_rn(acc, dt_inv);
+    store_out(out + s, __fmul_rn(acc, dt_inv), sig.counter != nullptr);
+    tick_signal(sig);
 }
 
 template <int N>
 static int dispatch_tick(int n, bool fma, float *ring, const float *samples, float *out, size_t streams, const StreamTaps &taps, int wp_old,
-                         float dt_inv, hipStream_t st)
+                         float dt_inv, hipStream_t st, const TickSignal &sig)
 {
     if (n == N) {
         if (fma)
             hipLaunchKernelGGL((sg_bank_tick_n_kernel<N, true>), dim3((unsigned)((streams + 255) / 256)), dim3(256), 0, st, ring, samples, out,
-                               streams, taps, wp_old, dt_inv);
+                               streams, taps, wp_old, dt_inv, sig);
         else
             hipLaunchKernelGGL((sg_bank_tick_n_kernel<N, false>), dim3((unsigned)((streams + 255) / 256)), dim3(256), 0, st, ring, samples, out,
-                               streams, taps, wp_old, dt_inv);
+                               streams, taps, wp_old, dt_inv, sig);
         return 1;
     }
-    if constexpr (N < SAVGOL_MAX_HALF_WINDOW) return dispatch_tick<N + 1>(n, fma, ring, samples, out, streams, taps, wp_old, dt_inv, st);
+    if constexpr (N < SAVGOL_MAX_HALF_WINDOW) return dispatch_tick<N + 1>(n, fma, ring, samples, out, streams, taps, wp_old, dt_inv, st, sig);
     else return 0;
 }
 
@@ -590,7 +624,8 @@ void savgol_streambank_destroy(SavgolStreamBank *bank)
     if (!bank) return;
     if (bank->service) (void)savgol_streambank_service_stop(bank);
     if (bank->d_ring) (void)hipFree(bank->d_ring);
-    if (bank->signal) (void)hipFree(const_cast<unsigned *>(bank->signal));
+    if (bank->signal) (void)hipHostFree(const_cast<unsigned *>(bank->signal));
+    if (bank->signal_counter) (void)hipFree(bank->signal_counter);
     savgol_destroy(bank->filter);
     free(bank);
 }
@@ -604,10 +639,10 @@ int savgol_streambank_reset(SavgolStreamBank *bank, void *stream)
     return sg::hip_ok(hipMemsetAsync(bank->d_ring, 0, bytes, static_cast<hipStream_t>(stream)), "hipMemsetAsync") ? 0 : -1;
 }
 
-int savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream)
+static int bank_tick(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream, const sg::TickSignal &sig, const char *who)
 {
-    if (!bank || !d_samples || !d_out) { sg_set_error("savgol_streambank_push: NULL pointer"); return -1; }
-    if (!sg::bank_on_current_device(bank, "savgol_streambank_push")) return -1;
+    if (!bank || !d_samples || !d_out) { sg_set_error("%s: NULL pointer", who); return -1; }
+    if (!sg::bank_on_current_device(bank, who)) return -1;
     const int ws = bank->filter->window_size;
     const int emit = (bank->received + 1 >= (unsigned long long)ws) ? 1 : 0;
     if (emit) {
@@ -615,57 +650,71 @@ int savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float
         memset(&taps, 0, sizeof(taps));
         memcpy(taps.w, bank->filter->center_weights, sizeof(float) * ws);
         sg::dispatch_tick<1>(bank->filter->config.half_window, (bank->flags & SAVGOL_STREAMBANK_FMA) != 0, bank->d_ring, d_samples, d_out, bank->streams, taps, bank->wp,
-                             bank->dt_inv, static_cast<hipStream_t>(stream));
+                             bank->dt_inv, static_cast<hipStream_t>(stream), sig);
     } else {
         hipLaunchKernelGGL(sg::sg_bank_tick_kernel, dim3(sg::bank_blocks(bank)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           bank->d_ring, d_samples, d_out, bank->streams, bank->d_table, ws, bank->wp, bank->dt_inv, 0);
+                           bank->d_ring, d_samples, d_out, bank->streams, bank->d_table, ws, bank->wp, bank->dt_inv, 0, sig);
     }
-    if (!sg::hip_ok(hipGetLastError(), "savgol_streambank_push launch")) return -1;
+    if (!sg::hip_ok(hipGetLastError(), who)) return -1;
     bank->wp = (bank->wp + 1) % ws;
     bank->received++;
     if (emit) bank->emitted++;
     return emit;
 }
 
-// One tick, and its outputs are in d_out when the call returns: savgol_streambank_push followed by a wait that does not go through
-// hipStreamSynchronize (5-6 us of the 13 us a launch + synchronise tick costs from C).  The stream itself writes a sequence number into a word of
-// signal memory behind the tick kernel (hipStreamWriteValue32: a command-processor write, ordered after the kernel), and the host spins on that
-// word.  Where the device or the runtime has no stream memory operations the call is push + hipStreamSynchronize, same results.
+int savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream)
+{
+    return bank_tick(bank, d_samples, d_out, stream, sg::TickSignal{nullptr, nullptr, 0u}, "savgol_streambank_push");
+}
+
+// One tick, and its outputs are in d_out (in memory: write-through stores) when the call returns -- without hipStreamSynchronize, which is 5-6 us
+// of the 13 us a launch + synchronise tick costs from C.  The tick kernel signals its own completion: the block that finishes last writes a
+// sequence number into a word of pinned host memory (tick_signal above) and the host spins on it.  Needs a multiple of 64 streams (whole waves
+// at the barrier); otherwise -- and if pinned memory cannot be had -- the call is push + hipStreamSynchronize, same results.
 int savgol_streambank_push_wait(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream)
 {
-    const int rc = savgol_streambank_push(bank, d_samples, d_out, stream);
-    if (rc < 0) return rc;
+    const char *who = "savgol_streambank_push_wait";
+    if (!bank) { sg_set_error("%s: NULL pointer", who); return -1; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bank->signal_state == 0) {
-        int can = 0;
-        void *p = nullptr;
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, bank->device) == hipSuccess && can &&
-            hipExtMallocWithFlags(&p, 64, hipMallocSignalMemory) == hipSuccess && p) {
-            bank->signal = static_cast<volatile unsigned *>(p);
-            *bank->signal = 0;
-            bank->signal_seq = 0;
-            bank->signal_state = 1;
-        } else {
-            (void)hipGetLastError();
-            bank->signal_state = -1;
-        }
-    }
-    if (bank->signal_state == 1) {
-        const unsigned seq = ++bank->signal_seq;
-        if (hipStreamWriteValue32(st, const_cast<unsigned *>(bank->signal), seq, 0) == hipSuccess) {
-            const auto t0 = std::chrono::steady_clock::now();
-            unsigned long spins = 0;
-            while (*bank->signal != seq) {
-                _mm_pause();
-                if ((++spins & 0xfffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;      // a wedged queue: let the synchronise report it
+        void *host = nullptr, *dev = nullptr, *counter = nullptr;
+        bank->signal_state = -1;
+        if (bank->streams % 64 == 0 && hipHostMalloc(&host, 64, hipHostMallocMapped) == hipSuccess && host) {
+            if (hipHostGetDevicePointer(&dev, host, 0) == hipSuccess && dev && hipMalloc(&counter, 64) == hipSuccess && counter &&
+                hipMemset(counter, 0, 64) == hipSuccess) {
+                bank->signal = static_cast<volatile unsigned *>(host);
+                *bank->signal = 0;
+                bank->signal_dev = static_cast<unsigned *>(dev);
+                bank->signal_counter = static_cast<unsigned *>(counter);
+                bank->signal_seq = 0;
+                bank->signal_state = 1;
+            } else {
+                if (counter) (void)hipFree(counter);
+                (void)hipHostFree(host);
             }
-            if (*bank->signal == seq) return rc;
-        } else {
-            (void)hipGetLastError();
-            bank->signal_state = -1;                                      // the runtime refused the stream write: synchronise from now on
+        }
+        (void)hipGetLastError();
+    }
+    if (bank->signal_state != 1) {
+        const int rc = savgol_streambank_push(bank, d_samples, d_out, stream);
+        if (rc < 0) return rc;
+        return sg::hip_ok(hipStreamSynchronize(st), "savgol_streambank_push_wait: hipStreamSynchronize") ? rc : -1;
+    }
+    const unsigned seq = ++bank->signal_seq;
+    const int rc = bank_tick(bank, d_samples, d_out, stream, sg::TickSignal{bank->signal_counter, bank->signal_dev, seq}, who);
+    if (rc < 0) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long spins = 0;
+    while (*bank->signal != seq) {
+        _mm_pause();
+        if ((++spins & 0xfffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+            // a wedged queue or a faulted kernel: let the synchronise report it, and re-arm the counter for the next tick
+            const bool ok = sg::hip_ok(hipStreamSynchronize(st), "savgol_streambank_push_wait: hipStreamSynchronize");
+            (void)hipMemset(bank->signal_counter, 0, 64);
+            return ok && *bank->signal == seq ? rc : -1;
         }
     }
-    return sg::hip_ok(hipStreamSynchronize(st), "savgol_streambank_push_wait: hipStreamSynchronize") ? rc : -1;
+    return rc;
 }
 
 int savgol_streambank_push_full(SavgolStreamBank *bank, const float *d_samples, float *d_out, int max_rows, void *stream)
@@ -682,7 +731,7 @@ int savgol_streambank_push_full(SavgolStreamBank *bank, const float *d_samples, 
     }
     // the tick that completes the window: store the sample, then n leading rows + the centre row
     hipLaunchKernelGGL(sg::sg_bank_tick_kernel, dim3(sg::bank_blocks(bank)), dim3(256), 0, st, bank->d_ring, d_samples,
-                       d_out, bank->streams, bank->d_table, ws, bank->wp, bank->dt_inv, 0);
+                       d_out, bank->streams, bank->d_table, ws, bank->wp, bank->dt_inv, 0, sg::TickSignal{nullptr, nullptr, 0u});
     bank->wp = (bank->wp + 1) % ws;
     bank->received++;
     sg::RowList rows; memset(&rows, 0, sizeof(rows));

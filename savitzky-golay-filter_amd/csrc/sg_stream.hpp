@@ -21,9 +21,11 @@ struct SavgolStreamBank {
     float         dt_inv;
     void         *service;           // sg::BankService while savgol_streambank_service_* is active, else NULL
     unsigned      flags;             // SAVGOL_STREAMBANK_* of savgol_streambank_create_ex
-    // savgol_streambank_push_wait: a 32-bit completion word the STREAM writes behind the tick kernel (hipStreamWriteValue32 into signal memory) and
-    // the host spins on -- instead of hipStreamSynchronize's several microseconds.  0 = not tried yet, 1 = in use, -1 = unavailable here.
-    volatile unsigned *signal;
+    // savgol_streambank_push_wait: a completion word in pinned host memory that the tick kernel's last block writes and the host spins on --
+    // instead of hipStreamSynchronize's several microseconds.  0 = not tried yet, 1 = in use, -1 = unavailable (push + synchronise).
+    volatile unsigned *signal;       // host view
+    unsigned     *signal_dev;        // device view of the same word
+    unsigned     *signal_counter;    // device word: blocks of the running tick that have finished
     int           signal_state;
     unsigned      signal_seq;
 };

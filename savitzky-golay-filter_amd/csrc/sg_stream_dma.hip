@@ -34,7 +34,8 @@ namespace sg {
 #define SG_DMA_WPB 4                                         // waves per block (independent: only how waves are dealt to CUs and how LDS is carved)
 #endif
 #ifndef SG_DMA_STORE_AUX
-#define SG_DMA_STORE_AUX 0                                   // cache policy bits of the output stores (2 = nontemporal); A/B'd in profiles/r05_stream_dma.txt
+#define SG_DMA_STORE_AUX 2                                   // cache policy bits of the output stores: 2 = nontemporal (written once, never read by this launch:
+                                                             // 0.392 against 0.412 ms on one box, profiles/r05_stream_dma.txt; nontemporal row LOADS lose 30 %: the halo rows are re-read)
 #endif
 #ifndef SG_DMA_LOAD_NT
 #define SG_DMA_LOAD_NT 0

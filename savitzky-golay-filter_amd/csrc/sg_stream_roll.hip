@@ -83,7 +83,7 @@ __device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTa
             if (job.received0 + t + 1 >= (unsigned long long)R::WS) {            // uniform: an output exists (reference :166-170)
                 const f32x2 y = acc * f32x2{job.dt_inv, job.dt_inv};
                 float *orow = job.out + t * job.streams;
-                if constexpr (VEC) *reinterpret_cast<f32x2 *>(orow + s0) = y;
+                if constexpr (VEC) __builtin_nontemporal_store(__builtin_bit_cast(u32x2, y), reinterpret_cast<u32x2 *>(orow + s0));   // written once (round 5: as the LDS-DMA tiles)
                 else { if (live0) orow[s0] = y.x; if (live1) orow[s0 + 1] = y.y; }
             }
             return true;
@@ -167,7 +167,7 @@ __device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRol
         if (r >= 2 * N && job.received0 + (unsigned long long)t + 1 >= (unsigned long long)R::WS) {      // uniform (reference :166-170)
             const f32x2 y = done * f32x2{job.dt_inv, job.dt_inv};
             float *orow = job.out + (size_t)t * job.streams;
-            if constexpr (VEC) *reinterpret_cast<f32x2 *>(orow + s0) = y;
+            if constexpr (VEC) __builtin_nontemporal_store(__builtin_bit_cast(u32x2, y), reinterpret_cast<u32x2 *>(orow + s0));
             else { if (live0) orow[s0] = y.x; if (live1) orow[s0 + 1] = y.y; }
         }
         return true;
