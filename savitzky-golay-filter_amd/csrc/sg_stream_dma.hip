@@ -41,7 +41,7 @@ namespace sg {
 #define SG_DMA_LOAD_NT 0
 #endif
 #ifndef SG_DMA_MAX_N
-#define SG_DMA_MAX_N 16
+#define SG_DMA_MAX_N 32
 #endif
 
 // output ticks per tile TR: the slab is TR + 2n rows of 512 bytes, the accumulators 2 (reference order) or 4 (two FMA chains) VGPRs per tick
@@ -55,7 +55,9 @@ template <int N, int TR_> struct DmaShape {
 #define SG_DMA_TR 32
 #endif
 #ifndef SG_DMA_PAIRS
-#define SG_DMA_PAIRS 16                                      // row pairs (KiB) of LDS ring per wave = how far the row loads run ahead of the arithmetic
+#define SG_DMA_PAIRS 12                                      // row pairs (KiB) of LDS ring per wave = how far the row loads run ahead of the arithmetic
+                                                             // (8 / 12 / 16 / 24: FMA bank 0.401 / 0.401 / 0.405 / 0.479 ms, bit-exact bank sustained 0.551 / 0.545-0.555 /
+                                                             //  0.579-0.592 / 0.710 on one box: a shallow ring leaves LDS for the waves the bit-exact arithmetic needs)
 #endif
 
 template <int K> __device__ __forceinline__ void wait_vm()
@@ -291,10 +293,13 @@ static int dispatch_bank_dma(int n, int fma, const float *center, const BankJob 
 #ifndef SG_DMA_MIN_N
 #define SG_DMA_MIN_N 1
 #endif
+#ifndef SG_DMA_FN
+#define SG_DMA_FN sg_bank_dma_launch_all                     // the Makefile builds two objects (half windows 1..16 and 17..32) with a symbol each
+#endif
 
 // 0 = launched; 1 = not covered: half window outside [SG_DMA_MIN_N, SG_DMA_MAX_N], streams not a multiple of 128, rows not 16-byte aligned or
 // 2 GiB and longer (the store descriptors), or fewer than two tiles of ticks
-int sg_bank_dma_launch(int n, int fma, const float *center, const BankJob &job, int /*cu_count*/, hipStream_t st)
+int SG_DMA_FN(int n, int fma, const float *center, const BankJob &job, int /*cu_count*/, hipStream_t st)
 {
     if (n < SG_DMA_MIN_N || n > SG_DMA_MAX_N) return 1;
     if (job.streams % 128 != 0 || job.streams * 4 >= 0x7fffff00ull) return 1;

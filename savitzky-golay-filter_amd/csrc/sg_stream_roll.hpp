@@ -47,6 +47,16 @@ struct BankJob {
 struct TileGeom { unsigned strips, bands, group; unsigned long long total; };
 
 // sg_stream_dma.hip: the LDS-DMA tile form of the block push (round 5).  0 = launched, 1 = not covered (the caller walks)
-int sg_bank_dma_launch(int n, int fma, const float *center, const BankJob &job, int cu_count, hipStream_t st);
+int sg_bank_dma_launch_lo(int n, int fma, const float *center, const BankJob &job, int cu_count, hipStream_t st);      // half windows 1..16
+int sg_bank_dma_launch_hi(int n, int fma, const float *center, const BankJob &job, int cu_count, hipStream_t st);      // 17..32
+// Which half windows take the LDS-DMA tiles (profiles/r05_stream_dma.txt, config 3's shape, sustained): every n <= 16; above 16 the FMA bank gains
+// 6 % (n = 17) ... 15 % (n = 32) over the accumulator-ring walk and the bit-exact bank 10-19 % from n = 24, while at n = 17 its sustained time is
+// 10 % worse (0.603 against 0.548 ms: twice the vector instructions, and the chip lowers its clock under them) -- it keeps the walk below 20.
+inline int sg_bank_dma_launch(int n, int fma, const float *center, const BankJob &job, int cu_count, hipStream_t st)
+{
+    if (n <= 16) return sg_bank_dma_launch_lo(n, fma, center, job, cu_count, st);
+    if (!fma && n < 20) return 1;
+    return sg_bank_dma_launch_hi(n, fma, center, job, cu_count, st);
+}
 
 }  // namespace sg

@@ -540,3 +540,22 @@ def test_push_wait_returns_complete_outputs(sg, sgo, torch_gpu):
         if ra:
             assert torch.equal(oa, ob), t
     assert a.counters[0] == 60 and a.counters[1] == 60 - 2 * n
+
+
+def test_few_streams_long_block_uses_enough_bands(sg, sgo, torch_gpu):
+    """the walk's band search stopped at 64 bands, so a bank of FEW strips and a long block (1024 streams = 8 strips) ran on a quarter
+    of the resident waves.  Functional check of the repaired search on such a shape (n = 20: the accumulator-ring walk; n = 8 with an odd stream
+    count: the sample-ring walk on the element path): outputs equal the oracle's push loop bit for bit on sampled streams, whatever the band count."""
+    torch = torch_gpu
+    for S, n, T in ((1024, 20, 30000), (1022, 8, 20000)):
+        x = torch.randn((T, S), device="cuda")
+        out = torch.full((T, S), float("nan"), device="cuda")
+        bank = sg.StreamBank(S, n, 3, 1, 0.5)
+        assert bank.push_block(x, T, out) == T - 2 * n
+        torch.cuda.synchronize()
+        f = sgo.Filter(n, 3, 1, 0.5)
+        for j in (0, 1, S // 2 + 1, S - 1):
+            xs = x[:, j].cpu().numpy()
+            o = sgo.Stream(f)
+            seq = np.array([v for v, ok in (o.push(v) for v in xs) if ok], np.float32)
+            assert same_bits(out[2 * n:, j].cpu().numpy(), seq), (S, n, j)
