@@ -1015,8 +1015,9 @@ def run_headline(r):
         samples = float(len(modes)) * ch * length * args.steps * r.world
         import ctypes as C
         tab = (C.c_float * 400)()
-        terms = sg.lib().savgol_hip_moment_table(filters[0].ptr, tab)
-        kernel = f"sg1d_center_moment_kernel<{N},{terms}>" if terms > 0 else f"sg1d_center_kernel<float,{N}>"
+        half = os.environ.get("SAVGOL_HIP_MOMENT_FORM") != "32"              # round 5's half-lane form unless the A/B switch asks for round 2's
+        terms = (sg.lib().savgol_hip_momenth_table if half else sg.lib().savgol_hip_moment_table)(filters[0].ptr, tab)
+        kernel = (f"sg1d_center_momenth_kernel<{N},{terms}>" if half else f"sg1d_center_moment_kernel<{N},{terms}>") if terms > 0 else f"sg1d_center_kernel<float,{N}>"
         traffic, traffic_src = pmc_traffic(alg_bytes)
         out = {
             "metric": "Msamples/s filtered (1D batch, hw=32, poly=4) + % HBM roofline",

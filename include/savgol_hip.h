@@ -110,6 +110,9 @@ unsigned    savgol_hip_default_flags(void);
  * plain 2n+1-tap sum (half windows below 24, poly_order > 6, tables that are not a polynomial), -1 on NULL.                   */
 #define SAVGOL_HIP_MOMENT_TABLE_FLOATS 400
 int         savgol_hip_moment_table(const SavgolFilter *filter, float *table);
+/* the table of the form the fp32 batch calls run since round 5 (csrc/sg_k1d_momenth.hpp: a lane's 32 outputs as two groups of 16; layout in
+ * csrc/sg_k1d_host.hpp, at most 400 floats); same return value: the number of block moments (3, 5, 7), 0 = this filter keeps the plain sum */
+int         savgol_hip_momenth_table(const SavgolFilter *filter, float *table);
 
 /* ---------------------------------------------------------------- table export ------- *
  * The reference's on-disk format for a filter's tables: the C header its savgol_export tool writes

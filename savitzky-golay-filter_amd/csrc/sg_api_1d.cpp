@@ -102,6 +102,12 @@ inline size_t filter_used_bytes(const SavgolFilter *f)
     return offsetof(SavgolFilter, edge_weights) + sizeof(f->edge_weights[0]) * (size_t)f->config.half_window;
 }
 
+static bool moment_form_half()
+{
+    static const bool v = [] { const char *e = getenv("SAVGOL_HIP_MOMENT_FORM"); return !(e && atoi(e) == 32); }();
+    return v;
+}
+
 // the plan of (filter content, device); `need` = which lazily built parts this call wants
 enum : unsigned { NEED_EDGES = 1, NEED_REF = 2, NEED_MOMENT = 4, NEED_MOMENT64 = 8 };
 const FilterPlan *plan_get(DeviceCtx *ctx, const SavgolFilter *f, unsigned need)
@@ -148,9 +154,10 @@ const FilterPlan *plan_get(DeviceCtx *ctx, const SavgolFilter *f, unsigned need)
     }
     if ((need & NEED_MOMENT) && p->moment_terms < 0) {
         // wide-window fast path (half windows 24..32): the polynomial fit of the centre taps (sg_k1d_moment_fit.cpp)
-        const int terms = sg1d_moment_prepare(n, f->center_weights, p->moment_table);
+        // round 5: the half-lane form (sg_k1d_momenth.hpp) unless SAVGOL_HIP_MOMENT_FORM=32 asks for round 2's (A/B runs; read once per process)
+        const int terms = moment_form_half() ? sg1d_momenth_prepare(n, f->center_weights, p->moment_table) : sg1d_moment_prepare(n, f->center_weights, p->moment_table);
         if (terms > 0) {
-            p->d_moment = sg::ctx_table(ctx, p->moment_table, sizeof(p->moment_table), 0x1f00u + (unsigned)n);
+            p->d_moment = sg::ctx_table(ctx, p->moment_table, sizeof(p->moment_table), (moment_form_half() ? 0x2100u : 0x1f00u) + (unsigned)n);
             if (!p->d_moment) return nullptr;
         }
         p->moment_terms = terms;
@@ -365,9 +372,13 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         unsigned blocks = (job.total_tiles + job.edge_items + 3u) / 4u;
         blocks = (blocks + 7u) & ~7u;                                    // the XCD remap wants a multiple of 8
         if (d_moment) {
-            const int rc = moment_terms == 3 ? sg1d_launch_f32_moment_t3(n, &job, d_moment, blocks, st)
-                         : moment_terms == 5 ? sg1d_launch_f32_moment_t5(n, &job, d_moment, blocks, st)
-                                             : sg1d_launch_f32_moment_t7(n, &job, d_moment, blocks, st);
+            const int rc = moment_form_half()
+                               ? (moment_terms == 3 ? sg1d_launch_f32_momenth_t3(n, &job, d_moment, blocks, st)
+                                  : moment_terms == 5 ? sg1d_launch_f32_momenth_t5(n, &job, d_moment, blocks, st)
+                                                      : sg1d_launch_f32_momenth_t7(n, &job, d_moment, blocks, st))
+                               : (moment_terms == 3 ? sg1d_launch_f32_moment_t3(n, &job, d_moment, blocks, st)
+                                  : moment_terms == 5 ? sg1d_launch_f32_moment_t5(n, &job, d_moment, blocks, st)
+                                                      : sg1d_launch_f32_moment_t7(n, &job, d_moment, blocks, st));
             if (rc != 0) return -1;
         } else if (d_moment64) {
             const int mt = plan->moment64_terms;
@@ -585,6 +596,12 @@ int savgol_hip_moment_table(const SavgolFilter *filter, float *table)
 {
     if (!filter || !table) { sg_set_error("savgol_hip_moment_table: NULL pointer"); return -1; }
     return sg1d_moment_prepare(filter->config.half_window, filter->center_weights, table);
+}
+
+int savgol_hip_momenth_table(const SavgolFilter *filter, float *table)
+{
+    if (!filter || !table) { sg_set_error("savgol_hip_momenth_table: NULL pointer"); return -1; }
+    return sg1d_momenth_prepare(filter->config.half_window, filter->center_weights, table);
 }
 
 // Medium host signals: two hipMemcpy calls cost more than the filter.  Between these lengths the CPU copies the signal into

@@ -461,10 +461,15 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
             int g = ts - NA + e;
             const int g0 = g - (e % E);
             const bool direct = vec && g0 >= 0 && g0 + E <= L;
-            if (!direct && g < lim) {
-                bool zero = false;
-                if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
-                const T x = zero ? T(0) : row[g];
+            if (!direct) {
+                // beyond L + NA nothing a STORED output needs is read -- but the slab is whatever the previous block left there, and round 5's
+                // x-stationary inner product multiplies the sample one past a window by a zero tap (0 x NaN): zero-fill instead of skipping
+                T x = T(0);
+                if (g < lim) {
+                    bool zero = false;
+                    if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
+                    if (!zero) x = row[g];
+                }
                 *reinterpret_cast<T *>(slab + slab_vec_off<VPL>(e / E) + (e % E) * (int)sizeof(T)) = x;
             }
         }

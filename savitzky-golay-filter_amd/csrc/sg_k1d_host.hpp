@@ -135,6 +135,18 @@ constexpr int moment_lo(int n) { return (31 + moment_off(n) + 1) / 2 * 2; }     
 constexpr int moment_hi(int n) { return (moment_off(n) + 2 * n + 1) / 2 * 2; }        // one past its last sample (even)
 struct MomentArgs { const float *table; };
 
+// Round 5's fp32 form on HALF-lane blocks (sg_k1d_momenth.hpp): a lane's 32 outputs as two groups of 16, each with the block X[LO .. HI) of ITS window
+// (LO even >= 15 + OFF, HI even <= OFF + 2n + 1: 48 samples at n = 32), paired front to back, two pairs per packed step.
+//   floats [0, 132)    tap pairs (w[k], w[k-1]), k = 0 .. 2n+1, w[-1] = w[2n+1] = 0   (what one broadcast sample feeds into an output pair)
+//   floats [132, 276)  phi pairs [u][s-1] = (phi_s(2u), phi_s(2u+1)), u = 0 .. BK/4-1 (<= 12 steps), s = 1..6: six pairs per step
+//   floats [276, 388)  c pairs [s][j] = (c_s(2j), c_s(2j+1)), s = 0..6, j = 0..7
+constexpr int MOMENTH_MAX_STEPS = 12;
+constexpr int MOMENTH_OFF_W = 0, MOMENTH_OFF_PHI = 132, MOMENTH_OFF_C = MOMENTH_OFF_PHI + MOMENTH_MAX_STEPS * 12;
+constexpr int MOMENTH_TABLE_FLOATS = MOMENTH_OFF_C + MOMENT_MAX_TERMS * 16;
+static_assert(MOMENTH_TABLE_FLOATS <= MOMENT_TABLE_FLOATS, "the half-lane table travels in the same plan slot");
+constexpr int momenth_lo(int n) { return (15 + moment_off(n) + 1) / 2 * 2; }
+constexpr int momenth_hi(int n) { return (moment_off(n) + 2 * n + 1) / 2 * 2; }
+
 // The opt-in fp64 block-moment path (sg_k1d_moment64.hpp, half windows 24..32, SAVGOL_BATCH_MOMENT_F64): 16 outputs per lane, the window is
 // X[0 .. 16 + 2n + OFF), the common block X[LO .. HI) with LO = 15 + OFF, HI = OFF + 2n + 1 (2n - 14 samples: 50 at n = 32), paired front to back.
 //   doubles [0, 16)     centre taps 0..14 (exact promotions of the fp32 table), one pad
@@ -183,6 +195,11 @@ int sg1d_launch_f32_moment_t7(int n, const sg::Job1D *job, const float *d_table,
 // needs (3, 5, 7) or 0 when n is outside 24..32 or the taps are not a polynomial of degree <= 6 to fp32 rounding
 // (sg_k1d_moment_fit.cpp)
 int sg1d_moment_prepare(int n, const float *center_weights, float *table);
+// the half-lane form's table (MOMENTH_TABLE_FLOATS floats) and launchers; same return value
+int sg1d_momenth_prepare(int n, const float *center_weights, float *table);
+int sg1d_launch_f32_momenth_t3(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
+int sg1d_launch_f32_momenth_t5(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
+int sg1d_launch_f32_momenth_t7(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
 // the opt-in fp64 counterpart: table[MOMENT64_TABLE_DOUBLES]; same return value
 int sg1d_moment64_prepare(int n, const float *center_weights, double *table);
 int sg1d_launch_f64_moment_t3(int n, const sg::Job1D *job, const double *d_table, unsigned grid, void *stream);

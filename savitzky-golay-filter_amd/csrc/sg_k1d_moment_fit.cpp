@@ -178,3 +178,69 @@ extern "C" int sg1d_moment64_prepare(int n, const float *w, double *table)
     }
     return terms;
 }
+
+// Round 5's fp32 half-lane form (sg_k1d_momenth.hpp): 16 outputs per group, the block X[LO .. HI) of the group's window, front / back pairing.
+extern "C" int sg1d_momenth_prepare(int n, const float *w, float *table)
+{
+    if (n < sg::MOMENT_MIN_N || n > sg::MOMENT_MAX_N) return 0;
+    const int WS = 2 * n + 1, OFF = sg::moment_off(n), LO = sg::momenth_lo(n), HI = sg::momenth_hi(n), BLOCK = HI - LO;
+    double zk[MAXWS], wk[MAXWS], wmax = 0.0;
+    for (int k = 0; k < WS; ++k) {
+        zk[k] = (double)(k - n) / n; wk[k] = (double)w[k];
+        if (!std::isfinite(wk[k])) return 0;
+        if (std::fabs(wk[k]) > wmax) wmax = std::fabs(wk[k]);
+    }
+    if (wmax == 0.0) return 0;
+    int terms = 0;
+    double coef[MAXT] = {};
+    for (int t : {3, 5, 7}) {
+        double c[MAXT] = {}, P[MAXT];
+        if (!fit(t, WS, zk, wk, c)) continue;
+        double worst = 0.0;
+        for (int k = 0; k < WS; ++k) {
+            legendre(zk[k], t, P);
+            double v = 0.0;
+            for (int s = 0; s < t; ++s) v += c[s] * P[s];
+            worst = std::fmax(worst, std::fabs(v - wk[k]));
+        }
+        if (worst <= 3e-7 * wmax) { terms = t; memcpy(coef, c, sizeof(coef)); break; }
+    }
+    if (!terms) return 0;
+    auto p = [&](double k) {
+        double P[MAXT], v = 0.0;
+        legendre((k - n) / n, terms, P);
+        for (int s = 0; s < terms; ++s) v += coef[s] * P[s];
+        return v;
+    };
+    memset(table, 0, sizeof(float) * sg::MOMENT_TABLE_FLOATS);
+    for (int k = 0; k <= WS; ++k) {                               // pair k = (w[k], w[k-1]); w[-1] = w[2n+1] = 0
+        table[sg::MOMENTH_OFF_W + 2 * k] = k < WS ? w[k] : 0.0f;
+        table[sg::MOMENTH_OFF_W + 2 * k + 1] = k >= 1 ? w[k - 1] : 0.0f;
+    }
+    // block basis, rounded to fp32 as the kernel will use it; the kernel forms phi_s(BLOCK-1-t) as (-1)^s phi_s(t)
+    float phi[2 * sg::MOMENTH_MAX_STEPS * 2][MAXT];
+    for (int t = 0; t < BLOCK / 2; ++t) {
+        double P[MAXT];
+        legendre((t - 0.5 * (BLOCK - 1)) / (0.5 * BLOCK), terms, P);
+        for (int s = 0; s < terms; ++s) phi[t][s] = (float)P[s];
+    }
+    for (int u = 0; u < BLOCK / 4; ++u)
+        for (int s = 1; s < terms; ++s) {
+            table[sg::MOMENTH_OFF_PHI + (u * 6 + (s - 1)) * 2] = phi[2 * u][s];
+            table[sg::MOMENTH_OFF_PHI + (u * 6 + (s - 1)) * 2 + 1] = phi[2 * u + 1][s];
+        }
+    for (int r = 0; r < 16; ++r) {
+        double G[MAXT][MAXT] = {}, b[MAXT] = {}, c[MAXT] = {};
+        for (int t = 0; t < BLOCK; ++t) {
+            double Pr[MAXT];
+            const int tm = t < BLOCK / 2 ? t : BLOCK - 1 - t;
+            Pr[0] = 1.0;
+            for (int s = 1; s < terms; ++s) Pr[s] = (t < BLOCK / 2 || !(s & 1)) ? (double)phi[tm][s] : -(double)phi[tm][s];
+            const double q = p((double)(LO + t - r - OFF));
+            for (int s = 0; s < terms; ++s) { b[s] += Pr[s] * q; for (int u = 0; u < terms; ++u) G[s][u] += Pr[s] * Pr[u]; }
+        }
+        if (!solve(terms, G, b, c)) return 0;
+        for (int s = 0; s < terms; ++s) table[sg::MOMENTH_OFF_C + s * 16 + r] = (float)c[s];
+    }
+    return terms;
+}

@@ -29,8 +29,20 @@ x = (torch.zeros if a.zeros else torch.randn)((a.channels, a.length), dtype=torc
 y = torch.empty_like(x)
 st = torch.cuda.current_stream().cuda_stream
 libs = []
-for path in a.libs:
-    L = C.CDLL(path)
+for spec in a.libs:
+    # path@VAR=VAL[,VAR=VAL]: the library is copied to a temporary name (so the same file can load twice) and loaded -- and run once, so that
+    # switches it reads once per process are read -- under those environment variables
+    import os, shutil, tempfile
+    path, _, envs = spec.partition("@")
+    envs = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
+    lib_file = path
+    if envs:
+        lib_file = tempfile.NamedTemporaryFile(suffix=".so", delete=False).name
+        shutil.copy(path, lib_file)
+    saved = {k: os.environ.get(k) for k in envs}
+    os.environ.update(envs)
+    path = spec
+    L = C.CDLL(lib_file)
     L.savgol_create.restype = C.c_void_p
     L.savgol_create.argtypes = [C.POINTER(Cfg)]
     fn = L.savgol_apply_batch_f64 if a.f64 else L.savgol_apply_batch_f32
@@ -39,6 +51,9 @@ for path in a.libs:
     f = L.savgol_create(C.byref(cfg))
     run = lambda fn=fn, f=f: fn(f, x.data_ptr(), y.data_ptr(), a.channels, a.length, a.length, a.length, st)
     assert run() == 0
+    for k, v in saved.items():
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
     libs.append((path, run, []))
 torch.cuda.synchronize()
 for r in range(a.rounds):

@@ -27,7 +27,7 @@ for i in range(1, 6):
     line = last_json(os.path.join(O, f"repro{i}.json"))
     rp = None
     for row in csv.DictReader(open(stats[0])):
-        if "sg1d_center_moment_kernel" in row["Name"]:
+        if "sg1d_center_momenth_kernel" in row["Name"]:
             rp = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6, "min_ms": float(row["MinNs"]) / 1e6, "max_ms": float(row["MaxNs"]) / 1e6}
     r = line["roofline"]
     runs.append({"run": i, "rocprofv3_kernel_stats": rp, "bench_py_events": {k: r.get(k) for k in ("avg_launch_ms", "median_launch_ms", "min_launch_ms", "max_launch_ms", "launches_timed", "frac", "frac_at_median")},
@@ -40,7 +40,7 @@ if runs:
     ev = [r["bench_py_events"]["avg_launch_ms"] for r in runs]
     med = [r["bench_py_events"]["median_launch_ms"] for r in runs]
     summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-extra   (five fresh processes, one after the other, one box)",
-               "kernel": "sg1d_center_moment_kernel<32, 5>", "algorithmic_bytes_per_launch": alg, "runs": runs,
+               "kernel": "sg1d_center_momenth_kernel<32, 5>", "algorithmic_bytes_per_launch": alg, "runs": runs,
                "rocprofv3_avg_ms": {"min": min(rp), "median": float(np.median(rp)), "max": max(rp)},
                "bench_py_avg_ms": {"min": min(ev), "median": float(np.median(ev)), "max": max(ev)},
                "bench_py_median_ms": {"min": min(med), "median": float(np.median(med)), "max": max(med)},
@@ -53,7 +53,7 @@ if os.path.exists(os.path.join(O, "bench_line.json")):
 
 SRC_2D = ["sg_2d_roll.hip", "sg_2d.hpp", "sg_2d.hip"]
 SRC_STREAM = ["sg_stream_dma.hip", "sg_stream_roll.hip", "sg_stream_roll.hpp", "sg_stream.hpp", "sg_pk.hpp"]
-jobs = [("f32", "sg1d_center_moment_kernel<32, 5>", 8.0 * 4096 * (1 << 20), None, "r05_1d_f32_n32_pmc_summary.json", "bench.py --no-cpu --no-extra --steps 2 --warmup 1", "BASELINE config 2: 4096 x 2^20 fp32, n=32, m=4"),
+jobs = [("f32", "sg1d_center_momenth_kernel<32, 5>", 8.0 * 4096 * (1 << 20), None, "r05_1d_f32_n32_pmc_summary.json", "bench.py --no-cpu --no-extra --steps 2 --warmup 1", "BASELINE config 2: 4096 x 2^20 fp32, n=32, m=4"),
         ("f64", "sg1d_center_kernel<double, 32", 16.0 * 1024 * (1 << 22), None, "r05_1d_f64_n32_pmc_summary.json", "bench.py --workload batch1d_f64 --c5-channels 1024 --no-cpu --steps 2 --warmup 1", "BASELINE config 5 chunk: 1024 x 2^22 fp64, n=32, m=4, d=2"),
         ("f64m", "sg1d_center_moment64_kernel<32, 5>", 16.0 * 1024 * (1 << 22), None, "r05_1d_f64m_n32_pmc_summary.json", "bench.py --workload batch1d_f64 --c5-channels 1024 --no-cpu --steps 2 --warmup 1 --f64-moment", "BASELINE config 5 chunk, OPT-IN block moments (SAVGOL_BATCH_MOMENT_F64): 1024 x 2^22 fp64, n=32, m=4, d=2"),
         ("stream", "sg_bank_dma_kernel<16, true", 8.0 * 65536 * 4096, SRC_STREAM, "r05_stream_block_pmc_summary.json", "bench.py --workload stream --no-cpu --no-extra --steps 3 --warmup 1", "BASELINE config 3 block push: 65536 streams x 4096 ticks, n=16, m=2, d=1, SAVGOL_STREAMBANK_FMA"),
