@@ -251,7 +251,8 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     // shows: 1.5-2.9 x the reference's own fp32 error there, <= 1.3 x for poly_order >= 2 with derivative <= 1 (every half window
     // 24..32, all boundary modes; the plain three-chain kernel: 0.7-1.3 x everywhere).  Those filters take the plain kernel (8 % slower).
     const bool moment_safe = f->config.poly_order >= 2 && f->config.derivative <= 1;
-    const bool want_moment = sizeof(T) == 4 && !reference_order && n >= sg::MOMENT_MIN_N && n <= sg::MOMENT_MAX_N && !(flags & SAVGOL_BATCH_PLAIN_SUMMATION) && moment_safe;
+    const bool want_moment = sizeof(T) == 4 && !reference_order && n >= (moment_form_half() ? sg::MOMENTH_MIN_N : sg::MOMENT_MIN_N) && n <= sg::MOMENT_MAX_N &&
+                             !(flags & SAVGOL_BATCH_PLAIN_SUMMATION) && moment_safe;
     // fp64, half windows 24..32, on request only: block moments (sg_k1d_moment64.hpp) -- within ~1e-7 of the default path, not its 1e-12
     const bool want_moment64 = sizeof(T) == 8 && (flags & SAVGOL_BATCH_MOMENT_F64) && n >= sg::MOMENT_MIN_N && n <= sg::MOMENT_MAX_N;
     if (inplace && reference_order) {
@@ -303,7 +304,8 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     int vpl = sg::vectors_per_lane(sizeof(T), f->config.half_window);
     const int vpl_wide = sg::wide_vectors_per_lane(sizeof(T), f->config.half_window);
     const int tile_mode = (flags & SAVGOL_BATCH_TILE_NARROW) ? 1 : ((flags & SAVGOL_BATCH_TILE_WIDE) ? 2 : 0);
-    const int wide = vpl_wide != vpl && tile_mode != 1 && !(want_moment64 && plan->moment64_terms > 0 && plan->sym) &&       // (the fp64 moment kernel is laid out for 8 vectors per lane)
+    const int wide = vpl_wide != vpl && tile_mode != 1 && !(want_moment64 && plan->moment64_terms > 0 && plan->sym) &&       // (the moment kernels are laid out for 8 vectors per lane)
+                     !(want_moment && plan->moment_terms > 0) &&
                      (tile_mode == 2 || (unsigned long long)channels * ((length + 64u * vpl_wide * E - 1) / (64u * vpl_wide * E)) >= sg::WIDE_TILE_MIN_TILES);
     if (wide) vpl = vpl_wide;
     const unsigned TW = 64u * (unsigned)vpl * E;

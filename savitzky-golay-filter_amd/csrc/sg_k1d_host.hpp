@@ -140,6 +140,7 @@ struct MomentArgs { const float *table; };
 //   floats [0, 132)    tap pairs (w[k], w[k-1]), k = 0 .. 2n+1, w[-1] = w[2n+1] = 0   (what one broadcast sample feeds into an output pair)
 //   floats [132, 276)  phi pairs [u][s-1] = (phi_s(2u), phi_s(2u+1)), u = 0 .. BK/4-1 (<= 12 steps), s = 1..6: six pairs per step
 //   floats [276, 388)  c pairs [s][j] = (c_s(2j), c_s(2j+1)), s = 0..6, j = 0..7
+constexpr int MOMENTH_MIN_N = 20;                           // A/B in one process (profiles/r05_ab_momenth.txt): n = 18 the plain sum wins by 3 %, 20 / 22 / 23 this form by 0.6 / 1.1 / 1.4 %, 32 by 2.3-4 %
 constexpr int MOMENTH_MAX_STEPS = 12;
 constexpr int MOMENTH_OFF_W = 0, MOMENTH_OFF_PHI = 132, MOMENTH_OFF_C = MOMENTH_OFF_PHI + MOMENTH_MAX_STEPS * 12;
 constexpr int MOMENTH_TABLE_FLOATS = MOMENTH_OFF_C + MOMENT_MAX_TERMS * 16;

@@ -182,7 +182,7 @@ extern "C" int sg1d_moment64_prepare(int n, const float *w, double *table)
 // Round 5's fp32 half-lane form (sg_k1d_momenth.hpp): 16 outputs per group, the block X[LO .. HI) of the group's window, front / back pairing.
 extern "C" int sg1d_momenth_prepare(int n, const float *w, float *table)
 {
-    if (n < sg::MOMENT_MIN_N || n > sg::MOMENT_MAX_N) return 0;
+    if (n < sg::MOMENTH_MIN_N || n > sg::MOMENT_MAX_N) return 0;
     const int WS = 2 * n + 1, OFF = sg::moment_off(n), LO = sg::momenth_lo(n), HI = sg::momenth_hi(n), BLOCK = HI - LO;
     double zk[MAXWS], wk[MAXWS], wmax = 0.0;
     for (int k = 0; k < WS; ++k) {

@@ -29,7 +29,7 @@ extern "C" int SG_MOMENT_FN(int n, const sg::Job1D *job, const float *d_table, u
     const sg::MomentArgs args{d_table};
     static const bool debug = getenv("SAVGOL_HIP_DEBUG") != nullptr;
     if (debug) fprintf(stderr, "[savgol-hip] sg1d_center_momenth_kernel<%d,%d>: grid %u x 256\n", n, SG_MOMENT_TERMS, grid);
-    if (sg::launch_momenth<sg::MOMENT_MIN_N>(n, *job, args, grid, static_cast<hipStream_t>(stream)) != 0) {
+    if (sg::launch_momenth<sg::MOMENTH_MIN_N>(n, *job, args, grid, static_cast<hipStream_t>(stream)) != 0) {
         sg_set_error("no half-lane moment kernel for half_window %d", n);
         return -1;
     }

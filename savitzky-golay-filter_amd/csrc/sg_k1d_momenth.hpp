@@ -76,11 +76,11 @@ __device__ __forceinline__ void pk_fma_cb(f32x2 &acc, const f32x2 c, const f32x2
 
 template <int N, int M1>
 struct MomentHConv {
-    typedef K1D<float, N> K;
+    typedef K1D<float, N, 8> K;                              // 8 vectors per lane whatever the plain kernel of this half window uses
     typedef MomentArgs Args;
     static constexpr int OFF = K::OFF, LO = momenth_lo(N), HI = momenth_hi(N), BK = HI - LO, STEPS = BK / 4;      // packed steps: two sample pairs each
     static constexpr int WS = 2 * N + 1, CH = 3;
-    static_assert(N >= MOMENT_MIN_N && N <= MOMENT_MAX_N && K::R == 32 && K::VPL == 8, "32 outputs per lane as two groups of 16");
+    static_assert(N >= MOMENTH_MIN_N && N <= MOMENT_MAX_N && K::R == 32 && K::VPL == 8, "32 outputs per lane as two groups of 16");
     static_assert(LO % 2 == 0 && HI % 2 == 0 && BK % 4 == 0 && LO >= 15 + OFF && HI <= OFF + 2 * N + 1 && STEPS <= MOMENTH_MAX_STEPS, "block geometry");
     static_assert(M1 >= 1 && M1 <= MOMENT_MAX_TERMS, "1..7 moments");
     // tap pairs (w[k], w[k-1]) the head uses: k = 0 .. LO-1-OFF; the tail: k = HI-OFF-14 .. 2n+1

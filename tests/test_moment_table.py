@@ -200,15 +200,17 @@ def emulate_h(tab, terms, x, n):
     return (a0 + B).astype(f32).T.reshape(-1)
 
 
-@pytest.mark.parametrize("n", [32, 31, 30, 29, 28, 27, 26, 25, 24])
+@pytest.mark.parametrize("n", [32, 31, 30, 29, 28, 27, 26, 25, 24, 23, 22, 21, 20])
 @pytest.mark.parametrize("m,d,terms_expected,tol", [(4, 0, 5, 1e-6), (2, 0, 3, 1e-6), (3, 0, 3, 1e-6), (6, 0, 7, 1e-6), (4, 1, 5, 2e-6), (5, 1, 7, 2e-6)])
 def test_half_lane_table_reproduces_the_filter(sg, n, m, d, terms_expected, tol):
     """the table of round 5's fp32 kernel (savgol_hip_momenth_table), rebuilt into outputs with the kernel's own arithmetic in numpy and compared with
     the double-precision convolution of the same fp32 taps; geometry and layout as csrc/sg_k1d_host.hpp states them"""
     terms, tab, w = table_h(sg, n, m, d)
+    if terms == 0 and n < 24:
+        pytest.skip("the fit does not reproduce this table to 3e-7 of its largest tap (n = 21, m = 5, d = 1): the filter keeps the plain sum")
     assert terms == terms_expected
     off, lo, hi = geometry_h(n)
-    assert lo % 2 == 0 and hi % 2 == 0 and (hi - lo) % 4 == 0 and lo >= 15 + off and hi <= off + 2 * n + 1 and 32 <= hi - lo <= 48
+    assert lo % 2 == 0 and hi % 2 == 0 and (hi - lo) % 4 == 0 and lo >= 15 + off and hi <= off + 2 * n + 1 and 20 <= hi - lo <= 48
     wp = tab[H_OFF_W:H_OFF_W + 2 * (2 * n + 2)].reshape(-1, 2)
     assert np.array_equal(wp[:2 * n + 1, 0], w) and wp[2 * n + 1, 0] == 0 and wp[0, 1] == 0 and np.array_equal(wp[1:, 1], w)
     x = sgo.synth_f32(5, 1, 16 * 128 + 2 * n)[0]

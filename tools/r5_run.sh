@@ -1,5 +1,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r5
-python -m pytest tests/test_gpu_1d.py -q -m gpu -k "many_short or every_half_window or golden or in_place" 2>&1 | tail -4 > gpurun_out/r5/tests1d.txt
+rm -f gpurun_out/r5/parity.jsonl
+SAVGOL_PARITY_LOG=$PWD/gpurun_out/r5/parity.jsonl timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -30 > gpurun_out/r5/gputests.txt
+python tools/parity_margins.py gpurun_out/r5/parity.jsonl > gpurun_out/r5/parity_margins.txt 2>&1
 L=savitzky-golay-filter_amd/lib/libsavgol_hip.so
-{ for n in 32 32 28 24; do python tools/ab_1d.py $L $L@SAVGOL_HIP_MOMENT_FORM=32 --n $n --rounds 20 2>&1 | grep -v amdgpu.ids | tail -3; done; python tools/ab_1d.py $L $L@SAVGOL_HIP_MOMENT_FORM=32 --n 32 --deriv 1 --rounds 10 2>&1 | tail -2; } > gpurun_out/r5/ab_momenth.txt 2>&1
-tail -3 gpurun_out/r5/tests1d.txt; cat gpurun_out/r5/ab_momenth.txt
+{ for n in 32 18 20 22 23 24 16; do python tools/ab_1d.py $L $L@SAVGOL_HIP_MOMENT_FORM=32 --n $n --rounds 12 2>&1 | grep -v amdgpu.ids | tail -2; done; } > gpurun_out/r5/ab_momenth2.txt 2>&1
+tail -6 gpurun_out/r5/gputests.txt; grep -c OVER gpurun_out/r5/parity_margins.txt; cat gpurun_out/r5/ab_momenth2.txt
