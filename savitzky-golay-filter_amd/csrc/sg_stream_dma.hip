@@ -160,6 +160,9 @@ __global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job
                 constexpr int m = mlo + decltype(ic)::value, k = r - m;
                 // two chains (even taps, odd taps), one v_pk_fma_f32 per tap: bank_roll_item's fast form, bit for bit -- or ONE chain in the
                 // reference's order (taller tiles fit the registers; each term rounds once where the reference rounds twice)
+#ifdef SG_DMA_SKIP_TAPS           // timing experiment only (wrong results): how much of a tile's time the multiply-adds are (profiles/EXPERIMENTS.md R5.8)
+                if constexpr (k >= CH && k >= N - SG_DMA_SKIP_TAPS && k <= N + SG_DMA_SKIP_TAPS) return true;
+#endif
                 if constexpr (k < CH) acc[k][m] = pk_mul_sgpr<k>(taps.w[0], x);
                 else pk_fma_sgpr<(k & 1)>(acc[(k & 1) % CH][m], taps.w[k >> 1], x);
                 return true;
@@ -272,6 +275,7 @@ static int launch_bank_dma_shape(const float *center, const BankJob &job, hipStr
     static const int fch = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_CHAINS"); return e ? atoi(e) : 2; }();
 #define SG_DMA_TRY(T, W, P) if (tr == T && wpb == W && dp == P && fch == 2) return launch_bank_dma<N, FMA, T, W, P, 2>(center, job, st);
 #define SG_DMA_TRY1(T, W, P) if (tr == T && wpb == W && dp == P && fch == 1) return launch_bank_dma<N, FMA, T, W, P, 1>(center, job, st);
+    SG_DMA_TRY(32, 4, 24) SG_DMA_TRY(32, 4, 32) SG_DMA_TRY(32, 2, 24) SG_DMA_TRY(32, 2, 32) SG_DMA_TRY(32, 8, 12) SG_DMA_TRY(32, 8, 16)
     SG_DMA_TRY(32, 4, 16) SG_DMA_TRY(32, 4, 8) SG_DMA_TRY(32, 4, 12) SG_DMA_TRY(32, 8, 8) SG_DMA_TRY(64, 4, 16) SG_DMA_TRY(64, 4, 8) SG_DMA_TRY(64, 4, 12)
     SG_DMA_TRY(48, 4, 8) SG_DMA_TRY(48, 4, 12) SG_DMA_TRY(96, 4, 12) SG_DMA_TRY(64, 8, 8) SG_DMA_TRY(64, 2, 12) SG_DMA_TRY(128, 4, 12)
     SG_DMA_TRY1(32, 4, 8) SG_DMA_TRY1(32, 4, 12) SG_DMA_TRY1(64, 4, 8) SG_DMA_TRY1(64, 4, 12) SG_DMA_TRY1(64, 4, 16) SG_DMA_TRY1(96, 4, 12) SG_DMA_TRY1(64, 8, 8)

@@ -408,12 +408,18 @@ def test_randomized_configurations_within_the_dot_product_error_bound(sg, sgo, t
         length = int(rng.integers(2 * n + 1, 7000))
         ch = int(rng.integers(1, 4))
         ld_in, ld_out = length + int(rng.integers(0, 5)), length + int(rng.integers(0, 5))
+        # round 5: a third of the draws in place (halo stash), and the per-call summation flags
+        inplace = rng.random() < 0.33
+        flags = int(rng.choice([0, 0, sg.SAVGOL_BATCH_PLAIN_SUMMATION, sg.SAVGOL_BATCH_REFERENCE_SUMMATION]))
         xh = signal(rng, (ch, length)).astype(ndt)
-        xin = torch.zeros((ch, ld_in), dtype=tdt, device="cuda")
+        xin = torch.full((ch, ld_in), -7.0, dtype=tdt, device="cuda")
         xin[:, :length] = torch.from_numpy(xh).cuda()
-        out = torch.full((ch, ld_out), -7.0, dtype=tdt, device="cuda")
+        if inplace:
+            ld_out, out = ld_in, xin
+        else:
+            out = torch.full((ch, ld_out), -7.0, dtype=tdt, device="cuda")
         f = sg.Filter(n, m, d, dt, mode)
-        f.apply_batch(xin, out, ch, length, ld_in, ld_out, dtype=dtype)
+        f.apply_batch(xin, out, ch, length, ld_in, ld_out, dtype=dtype, flags=flags)
         torch.cuda.synchronize()
         o = sgo.Filter(n, m, d, dt, mode)
         ref = o.apply_f64(xh.astype(np.float64))
@@ -421,7 +427,7 @@ def test_randomized_configurations_within_the_dot_product_error_bound(sg, sgo, t
         bound = (2 * n + 2) * eps * np.abs(rows).sum(axis=1).max() * np.abs(xh).max() / (np.float32(dt) ** d)
         got = out.cpu().numpy()
         err = np.abs(got[:, :length] - ref).max()
-        assert err <= bound, (n, m, d, dt, mode, length, err, bound)
+        assert err <= bound, (n, m, d, dt, mode, length, inplace, flags, err, bound)
         assert np.all(got[:, length:] == -7.0)
 
 

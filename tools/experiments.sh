@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/experiments.sh NAME -- the GPU calls behind profiles/EXPERIMENTS.md, round 4, one function each (rounds 1-3 ran ~60 one-off
+# tools/experiments.sh NAME -- the GPU calls behind profiles/EXPERIMENTS.md, rounds 4 and 5, one function each (rounds 1-3 ran ~60 one-off
 # scripts under tools/r3/; their recipes are the command column of profiles/README.md).  Run on the GPU box from the repository root:
 #     gpurun --timeout 1500 -- 'bash tools/experiments.sh tile2d_knobs'
 # A/B libraries are built beforehand, on the CPU box, with tools/build_variant.sh (the lines marked "build:").
@@ -50,5 +50,31 @@ small_fixes() {                # R4.5: pool repro, pool trim probe, RCCL exchang
 }
 evidence() {                   # the committed r04_* evidence: tools/run_profiles_r4.sh here, then python tools/summarise_profiles_r4.py on the CPU box
     bash tools/run_profiles_r4.sh; IMAGES=256 bash tools/run_profiles_c4_r4.sh
+}
+# ---- round 5 (tools/r5_run.sh was rewritten per call; these are the calls that produced the committed r05_* files) ----
+membench_streamtile() {        # R5.1  build: hipcc --offload-arch=gfx950 -O3 -o tools/membench_streamtile tools/membench_streamtile.hip
+    tools/membench_streamtile
+}
+stream_dma() {                 # R5.1: LDS-DMA tiles against the walk, ring depth / tile height / waves per block / chains (build: make EXTRA=-DSG_DMA_EXPERIMENT ... sg_stream_dma_lo.o into tools/ab/lib_dmaexp.so)
+    echo "## default"; HALF_WINDOWS=4,8,16 python tools/time_stream_block.py 2>&1 | clean
+    echo "## walk"; SAVGOL_HIP_STREAM_DMA=0 HALF_WINDOWS=4,8,16 python tools/time_stream_block.py 2>&1 | clean
+    for cfg in "32 4 8" "32 4 12" "32 4 16" "64 4 12" "48 4 12" "96 4 12" "128 4 12" "64 2 12" "64 8 8"; do set -- $cfg
+        echo "## TR=$1 WPB=$2 PAIRS=$3"; SAVGOL_HIP_LIB=$PWD/$A/lib_dmaexp.so SAVGOL_HIP_STREAM_DMA_TR=$1 SAVGOL_HIP_STREAM_DMA_WPB=$2 SAVGOL_HIP_STREAM_DMA_PAIRS=$3 HALF_WINDOWS=16 python tools/time_stream_block.py 2>&1 | clean; done
+    for g in 32 64 256; do echo "## group $g"; SAVGOL_HIP_STREAM_DMA_GROUP=$g HALF_WINDOWS=16 python tools/time_stream_block.py 2>&1 | clean; done
+    echo "## half windows 17-32"; HALF_WINDOWS=17,20,24,32 python tools/time_stream_block.py 2>&1 | clean
+}
+parity_margins() {             # R5.2: every comparison of the GPU suite with its bar
+    rm -f gpurun_out/r5/parity.jsonl; mkdir -p gpurun_out/r5
+    SAVGOL_PARITY_LOG=$PWD/gpurun_out/r5/parity.jsonl python -m pytest tests -q -m gpu 2>&1 | tail -3
+    python tools/parity_margins.py gpurun_out/r5/parity.jsonl
+}
+momenth() {                    # R5.7: the half-lane fp32 block moments against round 4's form / the plain sum, one process
+    for n in 32 28 24 23 22 20 18 16; do python tools/ab_1d.py $L $L@SAVGOL_HIP_MOMENT_FORM=32 --n $n --rounds 12 2>&1 | clean | tail -2; done
+}
+tick_latency() {               # R5.4: per-tick paths from C (launch + synchronise, push_wait, resident service, back-to-back device time)
+    savitzky-golay-filter_amd/lib/c_api_demo
+}
+evidence_r5() {                # the committed r05_* evidence: this, then python tools/summarise_profiles_r5.py on the CPU box
+    bash tools/run_profiles_r5.sh
 }
 "$@"

@@ -2,7 +2,7 @@
 """Turns gpurun_out/r5_prof (tools/run_profiles_r5.sh) into the files under profiles/:
    r05_headline_repro.json        per fresh process: rocprofv3's average for the headline kernel AND bench.py's own HIP-event average /
                                   median of the same run, the buffer addresses; min / median / max over the runs
-   r05_bench_kernel_stats.csv     rocprofv3 --stats of run 1, verbatim
+   r05_bench_kernel_stats.csv     rocprofv3 --stats of the median process, verbatim
    r05_*_pmc_summary.json         FETCH x2 + WRITE traffic and the SQ counters of the four dominant kernels (tools/pmc_summary.py)
    r05_bench_line.json            the un-profiled driver-format line of the same box"""
 import csv, glob, json, os, shutil, subprocess, sys
@@ -32,22 +32,27 @@ for i in range(1, 6):
     r = line["roofline"]
     runs.append({"run": i, "rocprofv3_kernel_stats": rp, "bench_py_events": {k: r.get(k) for k in ("avg_launch_ms", "median_launch_ms", "min_launch_ms", "max_launch_ms", "launches_timed", "frac", "frac_at_median")},
                  "ms_per_step": line["ms_per_step"], "value_Msamples_per_s": line["value"], "buffers": line.get("buffers")})
-    if i == 1:
-        shutil.copy(stats[0], os.path.join(P, "r05_bench_kernel_stats.csv"))
+    runs[-1]["_stats_csv"] = stats[0]
 alg = 8.0 * 4096 * (1 << 20)
 if runs:
     rp = [r["rocprofv3_kernel_stats"]["avg_ms"] for r in runs if r["rocprofv3_kernel_stats"]]
     ev = [r["bench_py_events"]["avg_launch_ms"] for r in runs]
     med = [r["bench_py_events"]["median_launch_ms"] for r in runs]
+    order = sorted((r for r in runs if r["rocprofv3_kernel_stats"]), key=lambda r: r["rocprofv3_kernel_stats"]["avg_ms"])
+    pick = order[len(order) // 2]                                         # the MEDIAN process's --stats file is the one committed (round 4 kept process 1, its slowest)
+    shutil.copy(pick["_stats_csv"], os.path.join(P, "r05_bench_kernel_stats.csv"))
+    for r in runs:
+        r.pop("_stats_csv", None)
     summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-extra   (five fresh processes, one after the other, one box)",
                "kernel": "sg1d_center_momenth_kernel<32, 5>", "algorithmic_bytes_per_launch": alg, "runs": runs,
                "rocprofv3_avg_ms": {"min": min(rp), "median": float(np.median(rp)), "max": max(rp)},
                "bench_py_avg_ms": {"min": min(ev), "median": float(np.median(ev)), "max": max(ev)},
                "bench_py_median_ms": {"min": min(med), "median": float(np.median(med)), "max": max(med)},
                "roofline_frac_from_rocprofv3": {"min": alg / (max(rp) * 1e-3) / 8e12, "median": alg / (float(np.median(rp)) * 1e-3) / 8e12, "max": alg / (min(rp) * 1e-3) / 8e12},
-               "check_profile_median_x4_over_ms_per_step": [4 * float(np.median(rp)) / r["ms_per_step"] for r in runs]}
+               "kernel_stats_csv_is_run": pick["run"],
+               "check_profile_avg_x4_over_ms_per_step": [4 * r["rocprofv3_kernel_stats"]["avg_ms"] / r["ms_per_step"] for r in runs if r["rocprofv3_kernel_stats"]]}
     json.dump(summary, open(os.path.join(P, "r05_headline_repro.json"), "w"), indent=1)
-    print(json.dumps({k: summary[k] for k in ("rocprofv3_avg_ms", "bench_py_avg_ms", "roofline_frac_from_rocprofv3", "check_profile_median_x4_over_ms_per_step")}, indent=1))
+    print(json.dumps({k: summary[k] for k in ("rocprofv3_avg_ms", "bench_py_avg_ms", "roofline_frac_from_rocprofv3", "kernel_stats_csv_is_run", "check_profile_avg_x4_over_ms_per_step")}, indent=1))
 if os.path.exists(os.path.join(O, "bench_line.json")):
     shutil.copy(os.path.join(O, "bench_line.json"), os.path.join(P, "r05_bench_line.json"))
 
