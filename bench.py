@@ -32,7 +32,7 @@ from __graft_entry__ import load_package  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 N, M, D = 32, 4, 0
 # the dominant kernels of configs 3 / 4 as rocprofv3 names them (profiles/r05_*_kernel_stats.csv)
-STREAM_KERNEL_FMA = "sg_bank_dma_kernel<16,true,...> (LDS-DMA tiles; SAVGOL_HIP_STREAM_DMA=0: sg_bank_roll_kernel<16,true>)"
+STREAM_KERNEL_FMA = "sg_bank_dma_kernel<16,true,32,8,16,1,2,MomTaps<16,2>> (LDS-DMA tiles, 8-tick block moments; SAVGOL_HIP_STREAM_MOMENT=0: tap by tap; SAVGOL_HIP_STREAM_DMA=0: sg_bank_roll_kernel<16,true>)"
 STREAM_KERNEL_REF = "sg_bank_dma_kernel<16,false,...> (SAVGOL_HIP_STREAM_DMA=0: sg_bank_roll_kernel<16,false>)"
 IMAGE_KERNEL = "sg2d_rolling_kernel<7,2,1,true,false,16>"
 
@@ -375,7 +375,7 @@ def bench_stream(sg, a):
                                     "kernel trace); from_c.us_per_tick_back_to_back is the same loop from plain C"},
         "block_push": {"ticks_per_launch": T, "ms": round(ms, 3), "ns_per_sample": round(ms * 1e6 / samples, 5),
                        "Msamples_per_s": round(samples / ms / 1e3, 1),
-                       "summation": "SAVGOL_STREAMBANK_FMA (one v_pk_fma_f32 per tap and stream pair, two chains; parity below)",
+                       "summation": "SAVGOL_STREAMBANK_FMA (fused multiply-adds; config 3's taps are linear in the tap index: whole 8-tick blocks of a window through two block moments, the <= 14 taps at its ends one by one; parity below)",
                        "roofline": add_ceiling(with_traffic(roofline(8.0 * samples, ms, kernel=STREAM_KERNEL_FMA, algorithmic_bytes_per_sample=8),
                                                             "r*_stream_block_pmc_summary.json", SOURCES_STREAM), ceil)},
         "block_push_reference_order": {"ms": round(ms_ref, 3), "Msamples_per_s": round(samples / ms_ref / 1e3, 1),
@@ -668,7 +668,7 @@ def kernel_source_sha(files=None):
 
 
 SOURCES_2D = ["sg_2d_roll.hip", "sg_2d.hpp", "sg_2d.hip"]            # what profiles/r*_2d_config4_pmc_summary.json is stamped with
-SOURCES_STREAM = ["sg_stream_dma.hip", "sg_stream_roll.hip", "sg_stream_roll.hpp", "sg_stream.hpp", "sg_pk.hpp"]   # ... r*_stream_block_pmc_summary.json
+SOURCES_STREAM = ["sg_stream_dma.hip", "sg_stream_roll.hip", "sg_stream_roll.hpp", "sg_stream_host.hpp", "sg_stream_moment_fit.cpp", "sg_stream.hpp", "sg_pk.hpp"]   # ... r*_stream_block_pmc_summary.json
 
 
 def pmc_traffic(alg_bytes, pattern="r*_1d_f32_n32_pmc_summary.json", files=None):

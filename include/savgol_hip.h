@@ -113,6 +113,12 @@ int         savgol_hip_moment_table(const SavgolFilter *filter, float *table);
 /* the table of the form the fp32 batch calls run since round 5 (csrc/sg_k1d_momenth.hpp: a lane's 32 outputs as two groups of 16; layout in
  * csrc/sg_k1d_host.hpp, at most 400 floats); same return value: the number of block moments (3, 5, 7), 0 = this filter keeps the plain sum */
 int         savgol_hip_momenth_table(const SavgolFilter *filter, float *table);
+/* Diagnostic (host only): the fit behind the fused stream bank's block-moment tiles (csrc/sg_stream_dma.hip, half windows 12..20).  `center_weights`:
+ * the 2n+1 fp32 taps a bank applies; `coefficients`: 3 x SAVGOL_HIP_STREAM_MOMENT_OFFSETS floats, [s][off] = weight of moment s (basis 1, t - 3.5,
+ * (t - 3.5)^2 - 5.25 on t = 0..7) of the 8-tick block that starts `off` taps into a window.  Returns the number of moments (1..3), 0 when the
+ * table is not a polynomial of degree <= 2 to 3e-7 of its largest tap (the bank then runs tap by tap), -1 on NULL.                              */
+#define SAVGOL_HIP_STREAM_MOMENT_OFFSETS 34
+int         savgol_hip_stream_moment_table(int half_window, const float *center_weights, float *coefficients);
 
 /* ---------------------------------------------------------------- table export ------- *
  * The reference's on-disk format for a filter's tables: the C header its savgol_export tool writes

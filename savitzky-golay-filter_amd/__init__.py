@@ -109,6 +109,7 @@ SIGNATURES = {
     "savgol_hip_set_option": (C.c_int, [C.c_int, C.c_int]),
     "savgol_hip_moment_table": (C.c_int, [_F, _fp]),
     "savgol_hip_momenth_table": (C.c_int, [_F, _fp]),
+    "savgol_hip_stream_moment_table": (C.c_int, [C.c_int, _fp, _fp]),
     "savgol_export_header": (C.c_long, [_F, C.c_char_p, C.c_char_p, C.c_char_p, _sz]),
     # savgol_hip.h: 1-D batch
     "savgol_apply_batch_f32": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),

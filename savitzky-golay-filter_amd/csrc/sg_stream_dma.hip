@@ -95,8 +95,31 @@ template <int N, int TR, int DP> struct DmaQueue {
     }
 };
 
-template <int N, bool FMA, int TRT, int WPB, int DP, int FCH = 2>
-__global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job, const SRollTaps<N> taps, const TileGeom geo)
+// ---- block moments down the tick axis (round 5, profiles/EXPERIMENTS.md R5.9) ----
+// The fused bank's taps are a polynomial in the tap index for the filters streams are made of (config 3: m = 2, d = 1 -- LINEAR taps).  A tile's rows
+// are cut into blocks of 8 ticks (tile-relative rows 8j .. 8j + 7); output m = 8a + p takes the rows of its window that fill whole blocks through the
+// blocks' M moments (M coefficients per block, the same for both streams of the lane) and only the rows before its first / after its last whole block
+// tap by tap: at n = 16, 7 direct taps + 3.25 blocks x M per output on average, plus M operations per input row for the moments -- 17.5 (M = 2)
+// instead of 33 packed multiply-adds per output pair.  Same idea as sg_k1d_momenth.hpp, along the other axis.
+template <int N> struct MomGeom {
+    static constexpr int BK = 8;
+    static constexpr int NOFF = 2 * N - (BK - 1) + 1;                                    // block offsets 8j - m = 0 .. 2N - 7
+    static constexpr int jf(int m) { return m / BK + (m % BK ? 1 : 0); }                 // first / last block that lies wholly inside the window m .. m + 2N
+    static constexpr int jl(int m) { return (m + 2 * N - (BK - 1)) / BK; }
+    static constexpr bool whole(int m, int r) { return r >= m && r <= m + 2 * N && r / BK >= jf(m) && r / BK <= jl(m); }
+    static constexpr bool direct(int m, int r) { return r >= m && r <= m + 2 * N && !whole(m, r); }
+    static_assert(N >= BK / 2, "a window holds at least one whole block");
+};
+// q_0 = 1, q_1(t) = t - 3.5, q_2(t) = (t - 3.5)^2 - 5.25 on t = 0..7 (orthogonal; every value exact in fp32)
+template <int N, int M> struct MomTaps {
+    f32x2 head[4];                                   // w[0 .. 7]        (direct taps before the first whole block: k <= 6)
+    f32x2 tail[4];                                   // w[2N - 7 .. 2N]  (direct taps after the last whole block: k >= 2N - 6)
+    f32x2 c[M][(MomGeom<N>::NOFF + 1) / 2];          // c[s][off]: the block at offset off = 8j - m contributes sum_s c[s][off] * moment_s
+    f32x2 q[M > 1 ? M - 1 : 1][4];                   // q_s(t), s = 1 .. M - 1
+};
+
+template <int N, bool FMA, int TRT, int WPB, int DP, int FCH = 2, int MOM = 0, class TAPS = SRollTaps<N>>
+__global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job, const TAPS taps, const TileGeom geo)
 {
     typedef SRoll<N> R;
     typedef DmaShape<N, TRT> D;
@@ -146,8 +169,9 @@ __global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job
     const char *mine = lds + (size_t)wv * RING + lane * 8;
     const int row_bytes = (int)(job.streams * 4);
     const unsigned voff = (strip * 128u + 2u * (unsigned)lane) * 4u;                              // byte offset of this lane's streams in a row
-    constexpr int CH = FMA ? FCH : 1;                                                             // FMA bank: two chains (even / odd taps) or one
+    constexpr int CH = MOM ? 1 : (FMA ? FCH : 1);                                                 // FMA bank: two chains (even / odd taps) or one; block moments: one (an output is ~14 terms)
     f32x2 acc[CH][TR];
+    f32x2 mom[MOM > 0 ? MOM : 1];                                                                 // block moments of the block being filled (MOM > 0)
     auto row_in = [&](auto rc) -> f32x2 {
         constexpr int r = decltype(rc)::value;
         return *reinterpret_cast<const f32x2 *>(mine + ((r / 2) % DP) * 1024 + (r & 1) * RB);
@@ -155,7 +179,49 @@ __global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job
     auto feed = [&](auto rc, const f32x2 x) {
         constexpr int r = decltype(rc)::value;
         constexpr int mlo = r - 2 * N > 0 ? r - 2 * N : 0, mhi = r < TR - 1 ? r : TR - 1;
-        if constexpr (FMA) {
+        if constexpr (MOM > 0) {
+            typedef MomGeom<N> G;
+            static_assert(N >= 8, "head taps (k <= 6) and tail taps (k >= 2N - 6) must not meet");
+            constexpr int j = r / G::BK, t = r % G::BK;
+            // the block's moments (tap-free: shared by every output that takes this block whole)
+            if constexpr (t == 0) {
+                mom[0] = x;
+                static_for<MOM - 1>([&](auto sc) -> bool { constexpr int sm = decltype(sc)::value; mom[sm + 1] = pk_mul_sgpr<(t & 1)>(taps.q[sm][t >> 1], x); return true; });
+            } else {
+                mom[0] = mom[0] + x;
+                static_for<MOM - 1>([&](auto sc) -> bool { constexpr int sm = decltype(sc)::value; pk_fma_sgpr<(t & 1)>(mom[sm + 1], taps.q[sm][t >> 1], x); return true; });
+            }
+            // rows before an output's first / after its last whole block: tap by tap
+            static_for<mhi - mlo + 1>([&](auto ic) -> bool {
+                constexpr int m = mlo + decltype(ic)::value, k = r - m;
+                if constexpr (G::direct(m, r)) {
+                    constexpr bool is_head = k < G::BK;
+                    constexpr int kk = is_head ? k : k - (2 * N - (G::BK - 1));
+                    static_assert(kk >= 0 && kk < 8, "direct taps sit within 7 of either end of the window");
+                    if constexpr (k == 0) acc[0][m] = pk_mul_sgpr<(kk & 1)>(taps.head[kk >> 1], x);                    // m % 8 != 0: the output's first term
+                    else if constexpr (is_head) pk_fma_sgpr<(kk & 1)>(acc[0][m], taps.head[kk >> 1], x);
+                    else pk_fma_sgpr<(kk & 1)>(acc[0][m], taps.tail[kk >> 1], x);
+                }
+                return true;
+            });
+            // a block is complete: its share of every output that takes it whole
+            if constexpr (t == G::BK - 1) {
+                static_for<mhi - mlo + 1>([&](auto ic) -> bool {
+                    constexpr int m = mlo + decltype(ic)::value;
+                    if constexpr (G::whole(m, r)) {
+                        constexpr int off = G::BK * j - m;
+                        static_assert(off >= 0 && off < G::NOFF, "block offset");
+                        static_for<MOM>([&](auto sc) -> bool {
+                            constexpr int sm = decltype(sc)::value;
+                            if constexpr (sm == 0 && off == 0) acc[0][m] = pk_mul_sgpr<(off & 1)>(taps.c[0][off >> 1], mom[0]);  // m % 8 == 0: the output's first term
+                            else pk_fma_sgpr<(off & 1)>(acc[0][m], taps.c[sm][off >> 1], mom[sm]);
+                            return true;
+                        });
+                    }
+                    return true;
+                });
+            }
+        } else if constexpr (FMA) {
             static_for<mhi - mlo + 1>([&](auto ic) -> bool {
                 constexpr int m = mlo + decltype(ic)::value, k = r - m;
                 // two chains (even taps, odd taps), one v_pk_fma_f32 per tap: bank_roll_item's fast form, bit for bit -- or ONE chain in the
@@ -232,7 +298,7 @@ __global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job
 }
 
 template <int N, bool FMA, int TRT, int WPB, int DPR, int FCH = 2>
-static int launch_bank_dma(const float *center, BankJob job, hipStream_t st)
+[[maybe_unused]] static int launch_bank_dma(const float *center, BankJob job, hipStream_t st)
 {
     typedef SRoll<N> R;
     typedef DmaShape<N, TRT> D;
@@ -265,6 +331,7 @@ static int launch_bank_dma(const float *center, BankJob job, hipStream_t st)
     return 0;
 }
 
+#ifndef SG_DMA_MOM_BUILD
 template <int N, bool FMA>
 static int launch_bank_dma_shape(const float *center, const BankJob &job, hipStream_t st)
 {
@@ -275,14 +342,27 @@ static int launch_bank_dma_shape(const float *center, const BankJob &job, hipStr
     static const int fch = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_CHAINS"); return e ? atoi(e) : 2; }();
 #define SG_DMA_TRY(T, W, P) if (tr == T && wpb == W && dp == P && fch == 2) return launch_bank_dma<N, FMA, T, W, P, 2>(center, job, st);
 #define SG_DMA_TRY1(T, W, P) if (tr == T && wpb == W && dp == P && fch == 1) return launch_bank_dma<N, FMA, T, W, P, 1>(center, job, st);
+#if SG_DMA_EXPERIMENT == 2      // the short list (several half windows in one build)
+    SG_DMA_TRY(32, 4, 12) SG_DMA_TRY(32, 8, 12) SG_DMA_TRY(32, 8, 16) SG_DMA_TRY(32, 4, 16) SG_DMA_TRY(32, 8, 8) SG_DMA_TRY(32, 16, 8)
+#else
     SG_DMA_TRY(32, 4, 24) SG_DMA_TRY(32, 4, 32) SG_DMA_TRY(32, 2, 24) SG_DMA_TRY(32, 2, 32) SG_DMA_TRY(32, 8, 12) SG_DMA_TRY(32, 8, 16)
     SG_DMA_TRY(32, 4, 16) SG_DMA_TRY(32, 4, 8) SG_DMA_TRY(32, 4, 12) SG_DMA_TRY(32, 8, 8) SG_DMA_TRY(64, 4, 16) SG_DMA_TRY(64, 4, 8) SG_DMA_TRY(64, 4, 12)
     SG_DMA_TRY(48, 4, 8) SG_DMA_TRY(48, 4, 12) SG_DMA_TRY(96, 4, 12) SG_DMA_TRY(64, 8, 8) SG_DMA_TRY(64, 2, 12) SG_DMA_TRY(128, 4, 12)
     SG_DMA_TRY1(32, 4, 8) SG_DMA_TRY1(32, 4, 12) SG_DMA_TRY1(64, 4, 8) SG_DMA_TRY1(64, 4, 12) SG_DMA_TRY1(64, 4, 16) SG_DMA_TRY1(96, 4, 12) SG_DMA_TRY1(64, 8, 8)
     SG_DMA_TRY1(48, 4, 12) SG_DMA_TRY1(128, 4, 12) SG_DMA_TRY1(64, 2, 12)
+#endif
 #undef SG_DMA_TRY1
 #undef SG_DMA_TRY
 #endif
+    // (waves per block, ring pairs) by half window and bank -- interleaved A/B on config 3's shape (profiles/r05_stream_shapes_ab.txt): light tiles run
+    // best on fewer, deeper waves -- fused bank n = 8: (8, 12) 0.387 against (4, 12) 0.414 ms; bit-exact bank n = 8: (4, 16) 0.364 against 0.387.  The whole
+    // library before / after this table, both banks: n = 4 / 6 / 8 2.5-6.5 % faster, fused n = 11 8.6 %, n = 2 and 10 level; the bit-exact bank from n = 11
+    // (66 instructions per output pair at n = 16) keeps (4, 12): (8, 8) and (4, 16) measured 1-3 % slower there
+    if constexpr (SG_DMA_WPB == 4 && SG_DMA_PAIRS == 12 && SG_DMA_TR == 32) {
+        if constexpr (N <= 5) return launch_bank_dma<N, FMA, 32, 4, 16>(center, job, st);
+        else if constexpr (N <= 11 && FMA) return launch_bank_dma<N, FMA, 32, 8, 12>(center, job, st);
+        else if constexpr (N <= 10) return launch_bank_dma<N, FMA, 32, 4, 16>(center, job, st);
+    }
     return launch_bank_dma<N, FMA, SG_DMA_TR, SG_DMA_WPB, SG_DMA_PAIRS>(center, job, st);
 }
 
@@ -311,5 +391,97 @@ int SG_DMA_FN(int n, int fma, const float *center, const BankJob &job, int /*cu_
     if (job.ticks < 64) return 1;
     return dispatch_bank_dma<SG_DMA_MIN_N>(n, fma, center, job, st);
 }
+
+#else      // SG_DMA_MOM_BUILD: the third object, block-moment tiles of the fused bank
+#ifndef SG_DMA_MOM_WPB
+#define SG_DMA_MOM_WPB 8                                     // (waves per block, ring pairs) of the block-moment tiles: with a third of the arithmetic gone the tiles
+#define SG_DMA_MOM_PAIRS 16                                  // want FEWER resident waves with deeper rings -- 8 waves per CU, 16 KiB in flight each (R5.9)
+#endif
+
+template <int N, int M, int TRT, int WPB, int DPR>
+static int launch_bank_dma_mom(const StreamMomentFit &fit, const float *center, BankJob job, hipStream_t st)
+{
+    typedef DmaShape<N, TRT> D;
+    typedef MomGeom<N> G;
+    MomTaps<N, M> taps;
+    memset(&taps, 0, sizeof(taps));
+    auto put = [](f32x2 *v, int i, float x) { if (i & 1) v[i >> 1].y = x; else v[i >> 1].x = x; };
+    for (int k = 0; k < 8; ++k) { put(taps.head, k, center[k]); put(taps.tail, k, center[2 * N - 7 + k]); }
+    for (int sm = 0; sm < M; ++sm)
+        for (int off = 0; off < G::NOFF; ++off) put(taps.c[sm], off, fit.c[sm][off]);
+    for (int t = 0; t < 8; ++t) {
+        const float q1 = (float)t - 3.5f;
+        if (M > 1) put(taps.q[0], t, q1);
+        if (M > 2) put(taps.q[M > 2 ? 1 : 0], t, q1 * q1 - 5.25f);
+    }
+    TileGeom geo;
+    geo.strips = (unsigned)(job.streams / 128);
+    geo.bands = (unsigned)((job.ticks + D::TR - 1) / D::TR);
+    static const int group_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_GROUP"); return e ? atoi(e) : 0; }();
+    geo.group = group_env > 0 ? (unsigned)group_env : 128u;
+    if (geo.group > geo.strips) geo.group = geo.strips;
+    const unsigned groups = (geo.strips + geo.group - 1) / geo.group;
+    geo.total = (unsigned long long)groups * geo.group * geo.bands;
+    const unsigned long long blocks = (geo.total + WPB - 1) / WPB;
+    if (geo.total >= 0x7fffff00ull) return 1;
+    const unsigned grid = ((unsigned)blocks + 7u) & ~7u;
+    static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_XCD"); return e ? atoi(e) : 1; }();
+    job.aligned = 1 | (xcd_env ? 0 : 2);
+    constexpr int DP = DPR < D::NI ? DPR : D::NI;
+    constexpr size_t lds = (size_t)WPB * DP * 1024;
+    static_assert(lds <= 160 * 1024, "slabs of one block must fit the CU's LDS");
+    auto kernel = sg_bank_dma_kernel<N, true, TRT, WPB, DP, 1, M, MomTaps<N, M>>;
+    static const bool attr_ok = [&] {
+        return lds <= 65536 || hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    }();
+    if (!attr_ok) return 1;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * WPB), lds, st, job, taps, geo);
+    return 0;
+}
+
+template <int N, int M>
+static int launch_bank_dma_mom_shape(const StreamMomentFit &fit, const float *center, const BankJob &job, hipStream_t st)
+{
+#ifdef SG_DMA_EXPERIMENT        // A/B build: waves per block and ring depth picked per process
+    static const int wpb = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_WPB"); return e ? atoi(e) : SG_DMA_MOM_WPB; }();
+    static const int dp = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_PAIRS"); return e ? atoi(e) : SG_DMA_MOM_PAIRS; }();
+#define SG_DMA_TRY(W, P) if (wpb == W && dp == P) return launch_bank_dma_mom<N, M, SG_DMA_TR, W, P>(fit, center, job, st);
+    SG_DMA_TRY(4, 12) SG_DMA_TRY(4, 16) SG_DMA_TRY(4, 24) SG_DMA_TRY(8, 8) SG_DMA_TRY(8, 12) SG_DMA_TRY(8, 16) SG_DMA_TRY(8, 20) SG_DMA_TRY(16, 8) SG_DMA_TRY(2, 32)
+#undef SG_DMA_TRY
+#endif
+    return launch_bank_dma_mom<N, M, SG_DMA_TR, SG_DMA_MOM_WPB, SG_DMA_MOM_PAIRS>(fit, center, job, st);
+}
+
+#ifndef SG_DMA_MOM_MIN_N
+#define SG_DMA_MOM_MIN_N STREAM_MOMENT_MIN_N
+#define SG_DMA_MOM_MAX_N STREAM_MOMENT_MAX_N
+#endif
+template <int N>
+static int dispatch_bank_dma_mom(int n, const StreamMomentFit &fit, const float *center, const BankJob &job, hipStream_t st)
+{
+    if (n == N) {
+        if (fit.terms == 1) return launch_bank_dma_mom_shape<N, 1>(fit, center, job, st);
+        if (fit.terms == 2) return launch_bank_dma_mom_shape<N, 2>(fit, center, job, st);
+        return launch_bank_dma_mom_shape<N, 3>(fit, center, job, st);
+    }
+    if constexpr (N < SG_DMA_MOM_MAX_N) return dispatch_bank_dma_mom<N + 1>(n, fit, center, job, st);
+    else return 1;
+}
+
+// 0 = launched; 1 = not covered: half window outside 12..20, taps not a polynomial of degree <= 2 (stream_moment_fit), or a shape the tiles do not take
+// (see below).  SAVGOL_HIP_STREAM_MOMENT=0: never (A/B runs against the tap-by-tap tiles).
+int sg_bank_dma_launch_mom(int n, const float *center, const BankJob &job, int /*cu_count*/, hipStream_t st)
+{
+    static const int env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_MOMENT"); return e ? atoi(e) : 1; }();
+    if (!env || n < SG_DMA_MOM_MIN_N || n > SG_DMA_MOM_MAX_N) return 1;
+    if (job.streams % 128 != 0 || job.streams * 4 >= 0x7fffff00ull) return 1;
+    if (((reinterpret_cast<uintptr_t>(job.samples) | reinterpret_cast<uintptr_t>(job.out) | reinterpret_cast<uintptr_t>(job.ring)) & 15u) != 0) return 1;
+    if (job.ticks < 64) return 1;
+    StreamMomentFit fit;
+    if (stream_moment_fit(n, center, &fit) == 0) return 1;
+    return dispatch_bank_dma_mom<SG_DMA_MOM_MIN_N>(n, fit, center, job, st);
+}
+
+#endif
 
 }  // namespace sg

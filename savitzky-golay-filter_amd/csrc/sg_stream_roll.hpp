@@ -7,6 +7,7 @@
 
 #include "sg_pk.hpp"
 #include "sg_stream.hpp"
+#include "sg_stream_host.hpp"
 
 namespace sg {
 
@@ -52,8 +53,11 @@ int sg_bank_dma_launch_hi(int n, int fma, const float *center, const BankJob &jo
 // Which half windows take the LDS-DMA tiles (profiles/r05_stream_dma.txt, config 3's shape, sustained): every n <= 16; above 16 the FMA bank gains
 // 6 % (n = 17) ... 15 % (n = 32) over the accumulator-ring walk and the bit-exact bank 10-19 % from n = 24, while at n = 17 its sustained time is
 // 10 % worse (0.603 against 0.548 ms: twice the vector instructions, and the chip lowers its clock under them) -- it keeps the walk below 20.
+// the fused bank where its taps are a polynomial of degree <= 2 (config 3: linear): blocks of 8 ticks through their moments; 1 = not covered
+int sg_bank_dma_launch_mom(int n, const float *center, const BankJob &job, int cu_count, hipStream_t st);              // half windows 12..20
 inline int sg_bank_dma_launch(int n, int fma, const float *center, const BankJob &job, int cu_count, hipStream_t st)
 {
+    if (fma && n >= STREAM_MOMENT_MIN_N && n <= STREAM_MOMENT_MAX_N && sg_bank_dma_launch_mom(n, center, job, cu_count, st) == 0) return 0;
     if (n <= 16) return sg_bank_dma_launch_lo(n, fma, center, job, cu_count, st);
     if (!fma && n < 20) return 1;
     return sg_bank_dma_launch_hi(n, fma, center, job, cu_count, st);

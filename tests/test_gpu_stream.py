@@ -473,7 +473,9 @@ def test_opt_in_boundary_aware_streams_match_the_batch_filter(sg, sgo, torch_gpu
         L.savgol_hip_set_option(sg.SAVGOL_HIP_OPT_BOUNDARY_AWARE, 0)
 
 
-@pytest.mark.parametrize("n,m,d,dt", [(16, 2, 1, 1e-3), (5, 3, 0, 1.0), (1, 0, 0, 1.0), (17, 4, 2, 0.5), (32, 4, 0, 1.0), (24, 3, 1, 2.0)])
+@pytest.mark.parametrize("n,m,d,dt", [(16, 2, 1, 1e-3), (5, 3, 0, 1.0), (1, 0, 0, 1.0), (17, 4, 2, 0.5), (32, 4, 0, 1.0), (24, 3, 1, 2.0),
+                                      # round 5: taps that are a polynomial of degree <= 2 take the block-moment tiles from n = 12 (1, 2, 3 moments)
+                                      (12, 2, 0, 1.0), (13, 1, 0, 1.0), (20, 2, 2, 0.5), (32, 2, 1, 1e-3), (31, 3, 0, 1.0), (28, 1, 1, 2.0), (16, 3, 2, 1.0)])
 def test_fma_bank_is_within_the_fp32_bar_of_the_fp64_oracle(sg, sgo, torch_gpu, n, m, d, dt):
     """SAVGOL_STREAMBANK_FMA (savgol_streambank_create_ex): block push (sample ring n <= 16, accumulator ring above) and the
     per-tick kernel with fused multiply-adds.  Not the reference's bits; the bar is 1e-6 normwise of the double-accumulation oracle, or

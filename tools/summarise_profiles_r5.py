@@ -57,7 +57,7 @@ if os.path.exists(os.path.join(O, "bench_line.json")):
     shutil.copy(os.path.join(O, "bench_line.json"), os.path.join(P, "r05_bench_line.json"))
 
 SRC_2D = ["sg_2d_roll.hip", "sg_2d.hpp", "sg_2d.hip"]
-SRC_STREAM = ["sg_stream_dma.hip", "sg_stream_roll.hip", "sg_stream_roll.hpp", "sg_stream.hpp", "sg_pk.hpp"]
+SRC_STREAM = ["sg_stream_dma.hip", "sg_stream_roll.hip", "sg_stream_roll.hpp", "sg_stream_host.hpp", "sg_stream_moment_fit.cpp", "sg_stream.hpp", "sg_pk.hpp"]
 jobs = [("f32", "sg1d_center_momenth_kernel<32, 5>", 8.0 * 4096 * (1 << 20), None, "r05_1d_f32_n32_pmc_summary.json", "bench.py --no-cpu --no-extra --steps 2 --warmup 1", "BASELINE config 2: 4096 x 2^20 fp32, n=32, m=4"),
         ("f64", "sg1d_center_kernel<double, 32", 16.0 * 1024 * (1 << 22), None, "r05_1d_f64_n32_pmc_summary.json", "bench.py --workload batch1d_f64 --c5-channels 1024 --no-cpu --steps 2 --warmup 1", "BASELINE config 5 chunk: 1024 x 2^22 fp64, n=32, m=4, d=2"),
         ("f64m", "sg1d_center_moment64_kernel<32, 5>", 16.0 * 1024 * (1 << 22), None, "r05_1d_f64m_n32_pmc_summary.json", "bench.py --workload batch1d_f64 --c5-channels 1024 --no-cpu --steps 2 --warmup 1 --f64-moment", "BASELINE config 5 chunk, OPT-IN block moments (SAVGOL_BATCH_MOMENT_F64): 1024 x 2^22 fp64, n=32, m=4, d=2"),
