@@ -71,6 +71,21 @@ parity_margins() {             # R5.2: every comparison of the GPU suite with it
 momenth() {                    # R5.7: the half-lane fp32 block moments against round 4's form / the plain sum, one process
     for n in 32 28 24 23 22 20 18 16; do python tools/ab_1d.py $L $L@SAVGOL_HIP_MOMENT_FORM=32 --n $n --rounds 12 2>&1 | clean | tail -2; done
 }
+stream_skip_taps() {           # R5.8: what the fused tile's multiply-adds cost (build: sg_stream_dma.hip with -DSG_DMA_SKIP_TAPS=k [-DSG_DMA_EXPERIMENT] into tools/ab/lib_skip$k.so / lib_exp$k.so)
+    for sk in 3 6 10 14; do SAVGOL_HIP_LIB=$PWD/$A/lib_skip$sk.so HALF_WINDOWS=16 python tools/time_stream_block.py 2>&1 | clean; done
+    for sk in 0 6 14; do for cfg in "4 12" "4 16" "4 24" "4 32" "2 24" "2 32" "8 12" "8 16"; do set -- $cfg
+        SAVGOL_HIP_LIB=$PWD/$A/lib_exp$sk.so SAVGOL_HIP_STREAM_DMA_TR=32 SAVGOL_HIP_STREAM_DMA_WPB=$1 SAVGOL_HIP_STREAM_DMA_PAIRS=$2 HALF_WINDOWS=16 python tools/time_stream_block.py 2>&1 | grep "fma=1"; done; done
+}
+stream_moment() {              # R5.8: block-moment tiles against the tap-by-tap tiles and the walk, interleaved in one process; then process to process
+    for n in 12 14 16 20; do python tools/ab_stream.py $L $L@SAVGOL_HIP_STREAM_MOMENT=0 --n $n 2>&1 | clean; done
+    python tools/ab_stream.py $L $L@SAVGOL_HIP_STREAM_MOMENT=0 --n 16 --m 2 --d 0 2>&1 | clean
+    for i in 1 2 3 4 5 6 7 8; do python tools/ab_stream.py $L $L@SAVGOL_HIP_STREAM_MOMENT=0 $L@SAVGOL_HIP_STREAM_DMA=0 --n 16 --rounds 6 2>&1 | clean; done
+}
+stream_shapes() {              # R5.8: (waves per block, ring pairs) per half window and bank (build: -DSG_DMA_EXPERIMENT=2 -DSG_DMA_MIN_N=$N -DSG_DMA_MAX_N=$N into tools/ab/lib_few$N.so)
+    V="SAVGOL_HIP_STREAM_DMA_TR=32,SAVGOL_HIP_STREAM_DMA_WPB"
+    for N in 4 8; do X=$A/lib_few$N.so; for fma in 1 0; do
+        python tools/ab_stream.py $X@$V=4,SAVGOL_HIP_STREAM_DMA_PAIRS=12 $X@$V=8,SAVGOL_HIP_STREAM_DMA_PAIRS=12 $X@$V=8,SAVGOL_HIP_STREAM_DMA_PAIRS=16 $X@$V=4,SAVGOL_HIP_STREAM_DMA_PAIRS=16 --n $N --fma $fma 2>&1 | clean; done; done
+}
 tick_latency() {               # R5.4: per-tick paths from C (launch + synchronise, push_wait, resident service, back-to-back device time)
     savitzky-golay-filter_amd/lib/c_api_demo
 }

@@ -1,6 +1,11 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r5
-L=savitzky-golay-filter_amd/lib/libsavgol_hip.so
-{ for i in 1 2 3 4 5 6 7 8; do python tools/ab_stream.py $L $L@SAVGOL_HIP_STREAM_MOMENT=0 $L@SAVGOL_HIP_STREAM_DMA=0 --n 16 --rounds 6 2>&1 | grep -v amdgpu.ids; done
-  for i in 1 2 3; do python tools/ab_stream.py $L $L@SAVGOL_HIP_STREAM_DMA=0 --n 16 --fma 0 --rounds 6 2>&1 | grep -v amdgpu.ids; done
-} > gpurun_out/r5/stream_processes.txt 2>&1
-cat gpurun_out/r5/stream_processes.txt | cut -c30-220
+timeout 900 python -m pytest tests/test_gpu_bench_contract.py -x -q -m gpu 2>&1 | tail -3
+S=$(date +%s); python bench.py > gpurun_out/r5/bench_line.json 2> gpurun_out/r5/bench_line.err; echo "bench rc $? in $(( $(date +%s) - S )) s"
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r5/bench_line.json').read().split('\n')[0])
+e=d['extra']
+print(d['value'], d['roofline']['frac'], d['roofline']['traffic'])
+print('c3', e['config3']['block_push']['roofline']['frac'], e['config3']['block_push']['roofline']['traffic'], e['config3']['block_push_reference_order']['roofline_frac'])
+print('c5', e['config5_slice']['roofline']['frac'], e['config5_slice']['opt_in_block_moments']['roofline']['frac'], e['config5_slice'].get('in_place'))
+PY
