@@ -358,11 +358,13 @@ static int launch_bank_dma_shape(const float *center, const BankJob &job, hipStr
     // best on fewer, deeper waves -- fused bank n = 8: (8, 12) 0.387 against (4, 12) 0.414 ms; bit-exact bank n = 8: (4, 16) 0.364 against 0.387.  The whole
     // library before / after this table, both banks: n = 4 / 6 / 8 2.5-6.5 % faster, fused n = 11 8.6 %, n = 2 and 10 level; the bit-exact bank from n = 11
     // (66 instructions per output pair at n = 16) keeps (4, 12): (8, 8) and (4, 16) measured 1-3 % slower there
+#ifndef SG_DMA_FLAT_SHAPES        // (A/B builds: every tile on the default shape)
     if constexpr (SG_DMA_WPB == 4 && SG_DMA_PAIRS == 12 && SG_DMA_TR == 32) {
         if constexpr (N <= 5) return launch_bank_dma<N, FMA, 32, 4, 16>(center, job, st);
         else if constexpr (N <= 11 && FMA) return launch_bank_dma<N, FMA, 32, 8, 12>(center, job, st);
         else if constexpr (N <= 10) return launch_bank_dma<N, FMA, 32, 4, 16>(center, job, st);
     }
+#endif
     return launch_bank_dma<N, FMA, SG_DMA_TR, SG_DMA_WPB, SG_DMA_PAIRS>(center, job, st);
 }
 
@@ -418,7 +420,14 @@ static int launch_bank_dma_mom(const StreamMomentFit &fit, const float *center, 
     geo.strips = (unsigned)(job.streams / 128);
     geo.bands = (unsigned)((job.ticks + D::TR - 1) / D::TR);
     static const int group_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_GROUP"); return e ? atoi(e) : 0; }();
-    geo.group = group_env > 0 ? (unsigned)group_env : 128u;
+    // strips per group: 32 KiB of a tick row (64 strips), a quarter of the row for narrow banks.  Measured over FRESH ALLOCATIONS inside one process
+    // (tools/placement_stream.py, profiles/r05_placement_stream.txt): with 128-strip groups config 3's launch is 0.364-0.367 ms on some placements of
+    // the two buffers and 0.40-0.42 on others (7 of 12), with 64-strip groups 0.360-0.381 on 23 of 24 -- median 0.368 against 0.398; 32 768 / 131 072
+    // streams: 0.367 / 0.389 against 0.383 / 0.418; 16 384 streams: 32-strip groups 0.362 against 0.374.  Group sizes that do not divide an XCD's
+    // eighth of the tile order (48, 80, 96) cost 10-18 %.  (The tap-by-tap tiles keep 128: the bit-exact bank is 5 % slower on 64.)
+    unsigned want = geo.strips / 4;
+    want = want < 16u ? 16u : (want > 64u ? 64u : want);
+    geo.group = group_env > 0 ? (unsigned)group_env : want;
     if (geo.group > geo.strips) geo.group = geo.strips;
     const unsigned groups = (geo.strips + geo.group - 1) / geo.group;
     geo.total = (unsigned long long)groups * geo.group * geo.bands;
