@@ -597,7 +597,17 @@ __global__ __launch_bounds__(64 * roll_wpb(N, TR), TR > 0 ? roll_tile_waves(N, N
     // one item per wave by default (the loop runs once), or persistent waves striding over the items; blocks that share an XCD
     // (blockIdx % 8) take neighbouring items (halo columns meet in L2)
     const unsigned nblk = gridDim.x;
-    const unsigned blk = (aligned & 8) ? blockIdx.x : (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);      // bit 3: blocks in launch order (A/B: SAVGOL_HIP_ROLL_XCD=0)
+    // bit 3: blocks in launch order (A/B: SAVGOL_HIP_ROLL_XCD=0).  Bits 8..: blocks per XCD CHUNK -- chunks are dealt to the XCDs round robin, so the eight
+    // fronts stay within eight chunks of each other; 0 = every XCD sweeps one contiguous eighth of the launch (rounds 3-5)
+    unsigned blk = blockIdx.x;
+    if (!(aligned & 8)) {
+        const unsigned chunk = (unsigned)aligned >> 8;
+        if (chunk == 0) blk = (blk & 7u) * (nblk >> 3) + (blk >> 3);
+        else {
+            const unsigned span = 8u * chunk, q = blk / span;
+            if ((q + 1u) * span <= nblk) { const unsigned r = blk - q * span; blk = (q * 8u + (r & 7u)) * chunk + (r >> 3); }    // the last, partial span keeps launch order
+        }
+    }
     constexpr unsigned WPB = (unsigned)roll_wpb(N, TR);
     const unsigned nwaves = nblk * WPB;
 
@@ -795,9 +805,20 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
         Job2D part = job;
         part.in = job.in + (long long)i0 * job.in_pitch;
         part.out = job.out + (long long)i0 * job.out_pitch;
+        // XCD chunk (round 5): whole frames, at least 128 bands of every strip, dealt to the XCDs round robin -- the eight fronts stay within a few frames of
+        // each other instead of an eighth of the stack apart, and no halo row crosses a chunk.  Sampled over fresh buffer pairs in one process, columns
+        // rotated (tools/placement_2d.py, profiles/r05_placement_2d.txt; 64 frames of 4096^2, n = 7): 1.624 against 1.632 ms median for contiguous eighths
+        // (first pass over a fresh pair 1.641 / 1.669) -- level to slightly ahead; 64-band chunks 1.645.  SAVGOL_HIP_ROLL_XCD_CHUNK_BANDS=k forces k bands, 0 the old order.
+        static const int chunk_bands_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_XCD_CHUNK_BANDS"); return e ? atoi(e) : -1; }();
+        int aligned_launch = aligned;
+        const int chunk_bands = chunk_bands_env >= 0 ? chunk_bands_env : (int)(bands * ((128u + bands - 1u) / bands));
+        if (chunk_bands > 0 && !persistent && TR > 0) {
+            const unsigned long long chunk_items = (unsigned long long)chunk_bands * strips;
+            if (chunk_items % WPB == 0 && chunk_items / WPB < (1u << 22) && chunk_items / WPB * 8u <= grid) aligned_launch |= (int)((unsigned)(chunk_items / WPB) << 8);
+        }
         hipLaunchKernelGGL((sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC, TR>), dim3(grid), dim3(64 * WPB), lds, st, part, taps,
                            out1 ? out1 + (long long)i0 * job.out_pitch : nullptr, out2 ? out2 + (long long)i0 * job.out_pitch : nullptr, strips, bands,
-                           band_rows, (unsigned)total, aligned);
+                           band_rows, (unsigned)total, aligned_launch);
     }
     return 0;
 }

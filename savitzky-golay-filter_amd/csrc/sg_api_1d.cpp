@@ -312,6 +312,12 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
 
     sg::Job1D job;
     memset(&job, 0, sizeof(job));
+    // Tile order: chunks of 64 blocks dealt to the XCDs round robin (round 5; until then every XCD swept one contiguous eighth of the tiles, its
+    // front gigabytes away from the other seven).  Sampled over fresh placements of the two buffers inside one process, columns rotated
+    // (tools/placement_1d.py, profiles/r05_placement_1d.txt): headline shape 5.53 against 5.65 ms median, ahead on every one of six buffer pairs; chunks
+    // of 32 / 256 / 1024 blocks 5.64 / 5.60 / 5.60; launch order loses 15 %.  SAVGOL_HIP_1D_XCD_CHUNK_LOG2=0 is the old order.
+    static const unsigned xcd_chunk_env = [] { const char *e = getenv("SAVGOL_HIP_1D_XCD_CHUNK_LOG2"); return e ? (unsigned)atoi(e) : 6u; }();
+    job.xcd_chunk_log2 = xcd_chunk_env;
     job.in_ld = (long long)in_ld;
     job.out_ld = (long long)out_ld;
     job.length = (unsigned)length;

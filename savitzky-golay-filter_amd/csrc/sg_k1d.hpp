@@ -373,7 +373,14 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
 
     const unsigned nb8 = gridDim.x >> 3;
     unsigned blk = blockIdx.x;
-    if (blk < nb8 * 8u) blk = (blk & 7u) * nb8 + (blk >> 3);
+    if (blk < nb8 * 8u) {
+        const unsigned cs = job.xcd_chunk_log2;
+        if (cs == 0) blk = (blk & 7u) * nb8 + (blk >> 3);
+        else if (cs < 32u) {
+            const unsigned span = 8u << cs, q = blk >> (cs + 3u);
+            if ((q + 1u) * span <= nb8 * 8u) { const unsigned r = blk & (span - 1u); blk = (((q << 3) + (r & 7u)) << cs) + (r >> 3); }   // the last, partial span keeps launch order
+        }
+    }
     const unsigned tile = blk * K::WAVES + wave;
     if (tile >= job.total_tiles) {                                        // wave-uniform: past the tiles come the edge items, if any
         if (tile - job.total_tiles < job.edge_items) sg1d_edge_item<T, N>(job, tile - job.total_tiles, lane);

@@ -83,6 +83,9 @@ struct Job1D {
     // ([channel][end][2n+1]).  NULL = out of place: halos and edge samples come from the rows themselves.
     const void *stash;
     const void *edge_stash;
+    // tile order (sg1d_tile_body): 0 = each XCD sweeps one contiguous eighth of the tiles; s in 1..31 = chunks of 2^s blocks dealt to the XCDs round
+    // robin (the eight fronts stay within 8 * 2^s blocks of each other); >= 32 = launch order.  SAVGOL_HIP_1D_XCD_CHUNK_LOG2, tools/placement_1d.py
+    unsigned    xcd_chunk_log2;
 };
 // The fused strided (array-of-structs) kernel, sg1d_strided_kernel<N> (reference savgol_apply_strided, src/savgolFilter.c:877-934):
 // sample i of channel c is the float at in + c * in_pitch + i * in_stride (bytes; the field offset is folded into `in`), all

@@ -421,10 +421,10 @@ static int launch_bank_dma_mom(const StreamMomentFit &fit, const float *center, 
     geo.bands = (unsigned)((job.ticks + D::TR - 1) / D::TR);
     static const int group_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_GROUP"); return e ? atoi(e) : 0; }();
     // strips per group: 32 KiB of a tick row (64 strips), a quarter of the row for narrow banks.  Measured over FRESH ALLOCATIONS inside one process
-    // (tools/placement_stream.py, profiles/r05_placement_stream.txt): with 128-strip groups config 3's launch is 0.364-0.367 ms on some placements of
-    // the two buffers and 0.40-0.42 on others (7 of 12), with 64-strip groups 0.360-0.381 on 23 of 24 -- median 0.368 against 0.398; 32 768 / 131 072
-    // streams: 0.367 / 0.389 against 0.383 / 0.418; 16 384 streams: 32-strip groups 0.362 against 0.374.  Group sizes that do not divide an XCD's
-    // eighth of the tile order (48, 80, 96) cost 10-18 %.  (The tap-by-tap tiles keep 128: the bit-exact bank is 5 % slower on 64.)
+    // (tools/placement_stream.py, profiles/r05_placement_stream.txt): with 128-strip groups config 3's launch is 0.363-0.370 ms on most placements of the
+    // two buffers and 0.405-0.414 on the rest (3 of 12 to 7 of 12 from call to call); with 64-strip groups 0.373-0.397 on all of them -- the same mean, a
+    // third of the spread; 32 768 / 131 072 streams: 0.367 / 0.389 against 0.383 / 0.418; 16 384 streams: 32-strip groups 0.362 against 0.374.  Group sizes
+    // that do not divide an XCD's eighth of the tile order (48, 80, 96) cost 10-18 %.  (The tap-by-tap tiles keep 128: the bit-exact bank is 5 % slower on 64.)
     unsigned want = geo.strips / 4;
     want = want < 16u ? 16u : (want > 64u ? 64u : want);
     geo.group = group_env > 0 ? (unsigned)group_env : want;

@@ -1,9 +1,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r5
-L=savitzky-golay-filter_amd/lib/libsavgol_hip.so; F=tools/ab/lib_flat.so; G=SAVGOL_HIP_STREAM_DMA_GROUP
-{ timeout 600 python -m pytest tests/test_gpu_stream.py -x -q -m gpu 2>&1 | tail -2
-  echo "## n=16 fused: shipped (group by rule) / GROUP=128"; python tools/placement_stream.py $L $L@$G=128 --allocations 10 2>&1 | grep -v amdgpu.ids | tail -5
-  for n in 4 6 8 11; do for fma in 1 0; do echo "## n=$n fma=$fma: shape table / flat (4,12) / shape table GROUP=64 / flat GROUP=64"; python tools/placement_stream.py $L $F $L@$G=64 $F@$G=64 --n $n --fma $fma --allocations 8 2>&1 | grep -v amdgpu.ids | tail -5; done; done
-  echo "## n=16 bit-exact: GROUP 128 / 64 / 256"; python tools/placement_stream.py $L $L@$G=64 $L@$G=256 --n 16 --fma 0 --allocations 8 2>&1 | grep -v amdgpu.ids | tail -5
-  echo "## n=24 fused (tap by tap): GROUP 128 / 64"; python tools/placement_stream.py $L $L@$G=64 --n 24 --fma 1 --allocations 8 2>&1 | grep -v amdgpu.ids | tail -5
-} > gpurun_out/r5/placement_stream3.txt 2>&1
-cat gpurun_out/r5/placement_stream3.txt
+L=savitzky-golay-filter_amd/lib/libsavgol_hip.so
+{ echo "## 1-D headline shape: chunks of 64 blocks (shipped) / old order / chunks of 256 / 32 / 1024"; python tools/placement_1d.py $L $L@SAVGOL_HIP_1D_XCD_CHUNK_LOG2=0 $L@SAVGOL_HIP_1D_XCD_CHUNK_LOG2=8 $L@SAVGOL_HIP_1D_XCD_CHUNK_LOG2=5 $L@SAVGOL_HIP_1D_XCD_CHUNK_LOG2=10 --channels 4096 --allocations 6 2>&1 | grep -v amdgpu.ids
+  echo "## 2-D 64 x 4096^2 n=7: whole-frame chunks (shipped) / old order / 128 bands / 64 bands"; python tools/placement_2d.py $L $L@SAVGOL_HIP_ROLL_XCD_CHUNK_BANDS=0 $L@SAVGOL_HIP_ROLL_XCD_CHUNK_BANDS=128 $L@SAVGOL_HIP_ROLL_XCD_CHUNK_BANDS=64 --allocations 10 2>&1 | grep -v amdgpu.ids
+  echo "## stream n=16 fused: group by rule (64, shipped) / GROUP=128 / GROUP=32 / MOMENT=0 / DMA=0"; python tools/placement_stream.py $L $L@SAVGOL_HIP_STREAM_DMA_GROUP=128 $L@SAVGOL_HIP_STREAM_DMA_GROUP=32 $L@SAVGOL_HIP_STREAM_MOMENT=0 $L@SAVGOL_HIP_STREAM_DMA=0 --allocations 12 2>&1 | grep -v amdgpu.ids
+} > gpurun_out/r5/placement_check.txt 2>&1
+cat gpurun_out/r5/placement_check.txt
