@@ -162,6 +162,12 @@ struct MomentHConv {
         // ---- 4. moments: step u pairs samples (LO + 2u, LO + 2u + 1) with (HI - 1 - 2u, HI - 2 - 2u) ----
         f32x2 M[M1];
         {
+            // Two consecutive steps use the two halves of the same front vector and of the same back vector.  Left to itself hipcc narrows every
+            // half-used load to 8 bytes and pairs them as ds_read2_b64 -- and 8-byte reads at this slab's 36-dword lane stride meet in banks two ways
+            // (lanes l and l + 16): 192 conflict cycles per tile in the counters (31 % of the LDS-active cycles).  So: one 16-byte load per vector,
+            // pinned whole by an empty asm, shared by the two steps -- half the LDS reads of this section and none of the conflicts.
+            typedef float whole4 __attribute__((ext_vector_type(4)));
+            whole4 vf = {0.0f, 0.0f, 0.0f, 0.0f}, vb = {0.0f, 0.0f, 0.0f, 0.0f};
             constexpr int CHUNK = 4;                                         // steps per batch of phi loads (6 pairs per step whatever M1 is)
             static_for<(STEPS + CHUNK - 1) / CHUNK>([&](auto cc) -> bool {
                 constexpr int u0 = CHUNK * decltype(cc)::value, nu = STEPS - u0 < CHUNK ? STEPS - u0 : CHUNK;
@@ -170,7 +176,8 @@ struct MomentHConv {
                 static_for<nu>([&](auto uc) -> bool {
                     constexpr int u = u0 + decltype(uc)::value;
                     constexpr int fi = LO + 2 * u, bi = HI - 2 - 2 * u;        // first sample of the front pair / of the aligned back pair
-                    const float4 vf = vec(win, fi / 4 + VB), vb = vec(win, bi / 4 + VB);
+                    if constexpr (u == 0 || fi % 4 == 0) { vf = *reinterpret_cast<const whole4 *>(win + slab_vec_off<8>(fi / 4 + VB)); asm volatile("" : "+v"(vf)); }
+                    if constexpr (u == 0 || bi % 4 == 2) { vb = *reinterpret_cast<const whole4 *>(win + slab_vec_off<8>(bi / 4 + VB)); asm volatile("" : "+v"(vb)); }
                     const f32x2 f = (fi % 4) ? f32x2{vf.z, vf.w} : f32x2{vf.x, vf.y};
                     const f32x2 b = (bi % 4) ? f32x2{vb.z, vb.w} : f32x2{vb.x, vb.y};
                     const f32x2 ev = pk_add_swapped(f, b), od = pk_sub_swapped(f, b);

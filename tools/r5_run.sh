@@ -1,6 +1,8 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r5
-rm -f gpurun_out/r5/parity.jsonl
-SAVGOL_PARITY_LOG=$PWD/gpurun_out/r5/parity.jsonl timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -30 > gpurun_out/r5/gputests.txt
-python tools/parity_margins.py gpurun_out/r5/parity.jsonl > gpurun_out/r5/parity_margins.txt 2>&1
-bash tools/run_profiles_r5.sh > gpurun_out/r5_prof.log 2>&1
-tail -4 gpurun_out/r5/gputests.txt; grep -c OVER gpurun_out/r5/parity_margins.txt; tail -2 gpurun_out/r5_prof.log
+L=savitzky-golay-filter_amd/lib/libsavgol_hip.so; B=tools/ab/lib_before.so
+{ timeout 1200 python -m pytest tests/test_gpu_1d.py -x -q -m gpu 2>&1 | tail -2
+  python tools/placement_1d.py $L $B --channels 4096 --allocations 6 2>&1 | grep -v amdgpu.ids
+  python tools/placement_1d.py $L $B --channels 2048 --n 24 --allocations 6 2>&1 | grep -v amdgpu.ids | tail -6
+} > gpurun_out/r5/momenth_b128.txt 2>&1
+ONLY=f32 bash tools/run_profiles_r5.sh > gpurun_out/r5_prof_f32.log 2>&1
+cat gpurun_out/r5/momenth_b128.txt
