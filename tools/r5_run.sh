@@ -1,4 +1,6 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r5
-bash tools/soak_gpu.sh 8 3 90 > gpurun_out/r5/soak.txt 2>&1
-bash tools/check_multirank_plumbing.sh > gpurun_out/r5/multirank.txt 2>&1
-grep -c passed gpurun_out/r5/soak.txt; grep -i "fail\|error" gpurun_out/r5/soak.txt | head -5; grep '^==\|exit code' gpurun_out/r5/multirank.txt; grep -c '^{"metric"' gpurun_out/r5/multirank.txt
+rm -f gpurun_out/r5/parity.jsonl
+SAVGOL_PARITY_LOG=$PWD/gpurun_out/r5/parity.jsonl timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -30 > gpurun_out/r5/gputests.txt
+python tools/parity_margins.py gpurun_out/r5/parity.jsonl > gpurun_out/r5/parity_margins.txt 2>&1
+bash tools/run_profiles_r5.sh > gpurun_out/r5_prof.log 2>&1
+tail -4 gpurun_out/r5/gputests.txt; grep -c OVER gpurun_out/r5/parity_margins.txt; tail -2 gpurun_out/r5_prof.log
