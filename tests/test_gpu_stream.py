@@ -481,7 +481,8 @@ def test_fma_bank_is_within_the_fp32_bar_of_the_fp64_oracle(sg, sgo, torch_gpu, 
     per-tick kernel with fused multiply-adds.  Not the reference's bits; the bar is 1e-6 normwise of the double-accumulation oracle, or
     1.1 x the error of the reference-order bank (= the reference's own arithmetic) on the same samples where that is larger.  Edge rows keep the reference's order: push_full's burst and the flushes stay bit-exact."""
     torch = torch_gpu
-    for S, off in ((65536 if n == 16 else 4096, 0), (777, 1)):
+    # 8960 streams = 70 strips of 128: tile groups that do not divide the strips (the last group of the LDS-DMA tiles is a partial one)
+    for S, off in ((65536 if n == 16 else 4096, 0), (777, 1), (8960, 0)):
         T = 12 * (2 * n + 1) + 5
         g = torch.Generator(device="cuda").manual_seed(n * 77 + S)
         flat = torch.randn(T * S + 4, generator=g, device="cuda", dtype=torch.float32)
