@@ -99,7 +99,29 @@ struct RollTaps {
     f32x2 g[NOUT][NT][Roll<N>::NP];
     f32x2 q[NOUT][NT][Roll<N>::NP];
     f32x2 sy[NOUT], sx[NOUT];                               // +1 / -1 (both halves equal)
+    f32x2 qx[2 * N + 2];                                     // additive form, x-stationary horizontal pass: (a[k], a[k-1]), k = 0 .. 2N+1, a[-1] = a[2N+1] = 0
 };
+
+// The additive form's weighted horizontal unit, X-STATIONARY (round 5): one window float, broadcast, times the SGPR pair (a[k], a[k-1]) feeds the
+// output pair (c, c + 1) -- no folded pairs, no v_pk_mov_b32 for the pairs that straddle two aligned registers: 2 (2N + 2) multiply-adds per lane and
+// row instead of 2 (N + 1) + 2 N folds + ~N moves (n = 7: 32 against 39 of the row's 94 vector instructions).  Same idiom as sg_k1d_momenth.hpp.
+#ifndef SG_ROLL_XST
+#define SG_ROLL_XST 1
+#endif
+template <int HALF>
+__device__ __forceinline__ void roll_fma_xb(f32x2 &acc, const f32x2 s, const f32x2 x)
+{
+    if constexpr (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(s), "v"(x));
+    else                     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(s), "v"(x));
+}
+template <int HALF>
+__device__ __forceinline__ f32x2 roll_mul_xb(const f32x2 s, const f32x2 x)
+{
+    f32x2 p;
+    if constexpr (HALF == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "s"(s), "v"(x));
+    else                     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(p) : "s"(s), "v"(x));
+    return p;
+}
 
 // a + s * b, s = {+-1, +-1} in an SGPR pair.  Deliberately NOT inline asm: the hazard recogniser counts no wait
 // states for inline asm, so a chain of asm multiply-adds gets an s_nop per step unless compiler-visible
@@ -362,6 +384,26 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             const float s3 = s2 + (wf(hi + 3) - wf(lo + 2));
             r[0] = r[0] + f32x2{s0, s1};
             r[1] = r[1] + f32x2{s2, s3};
+            return;
+        }
+        if constexpr (SG_ROLL_XST && BOX && NOUT == 1 && t == 0) {
+            // window float D + i is tap i - p of output c0 + p and tap i - p - 1 of output c0 + p + 1 (p = 0: r[0], p = 2: r[1]); two chains per
+            // output pair (even / odd i), joined below
+            f32x2 ch[2][2];
+            static_for<2 * N + 4>([&](auto ic) -> bool {
+                constexpr int i = decltype(ic)::value, idx = R::D + i;
+                static_for<2>([&](auto pc) -> bool {
+                    constexpr int p = 2 * decltype(pc)::value, kk = i - p;
+                    if constexpr (kk >= 0 && kk <= 2 * N + 1) {
+                        if constexpr (kk < 2) ch[p / 2][kk & 1] = roll_mul_xb<(idx & 1)>(taps.qx[kk], e[idx >> 1]);
+                        else roll_fma_xb<(idx & 1)>(ch[p / 2][kk & 1], taps.qx[kk], e[idx >> 1]);
+                    }
+                    return true;
+                });
+                return true;
+            });
+            r[0] = ch[0][0] + ch[0][1];
+            r[1] = ch[1][0] + ch[1][1];
             return;
         }
         f32x2 pr[2 * N + 3];                                 // pr[j] = window floats (D+j, D+j+1)
@@ -722,7 +764,11 @@ static bool fill_box_taps(RollTaps<N, 2, 1> &taps, const float *factors, float s
         const float b = (float)((double)scale * q1c * (ga - (double)g1[N]));
         if (k & 1) { taps.q[0][0][k >> 1].y = a; taps.g[0][1][k >> 1].y = b; }
         else       { taps.q[0][0][k >> 1].x = a; taps.g[0][1][k >> 1].x = b; }
+        // the x-stationary table: the same float on both sides of the centre
+        taps.qx[k].x = a; taps.qx[2 * N - k].x = a;
+        taps.qx[k + 1].y = a; taps.qx[2 * N - k + 1].y = a;
     }
+    taps.qx[0].y = 0.0f; taps.qx[2 * N + 1].x = 0.0f;
     taps.sy[0] = f32x2{1.0f, 1.0f};
     taps.sx[0] = f32x2{1.0f, 1.0f};
     return true;
