@@ -386,7 +386,7 @@ __device__ __forceinline__ void roll_item(const Job2D &job, const RollTaps<N, NT
             r[1] = r[1] + f32x2{s2, s3};
             return;
         }
-        if constexpr (SG_ROLL_XST && BOX && NOUT == 1 && t == 0) {
+        if constexpr (SG_ROLL_XST && BOX && NOUT == 1 && t == 0 && TR > 0) {     // tiles only: on the strip walk (n >= 11) the 2N + 2 SGPR pairs cost more than the moves (4-9 % slower)
             // window float D + i is tap i - p of output c0 + p and tap i - p - 1 of output c0 + p + 1 (p = 0: r[0], p = 2: r[1]); two chains per
             // output pair (even / odd i), joined below
             f32x2 ch[2][2];
