@@ -1,5 +1,6 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r5
-L=savitzky-golay-filter_amd/lib/libsavgol_hip.so; B=tools/ab/lib_noxst.so
-{ for n in 11 12 15 16; do echo "## n=$n (strip walk): x-stationary / folded"; python tools/placement_2d.py $L $B --allocations 5 --n $n --images 32 2>&1 | grep -v amdgpu.ids | tail -5; done
-} > gpurun_out/r5/xst_walk.txt 2>&1
-cat gpurun_out/r5/xst_walk.txt
+rm -f gpurun_out/r5/parity.jsonl
+SAVGOL_PARITY_LOG=$PWD/gpurun_out/r5/parity.jsonl timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -30 > gpurun_out/r5/gputests.txt
+python tools/parity_margins.py gpurun_out/r5/parity.jsonl > gpurun_out/r5/parity_margins.txt 2>&1
+bash tools/run_profiles_r5.sh > gpurun_out/r5_prof.log 2>&1
+tail -4 gpurun_out/r5/gputests.txt; grep -c OVER gpurun_out/r5/parity_margins.txt; tail -2 gpurun_out/r5_prof.log
