@@ -520,6 +520,43 @@ def test_fma_bank_is_within_the_fp32_bar_of_the_fp64_oracle(sg, sgo, torch_gpu, 
     assert sg.lib().savgol_streambank_create_ex(None, 4, 1) is None
 
 
+def test_randomized_fused_bank_block_sequences(sg, sgo, torch_gpu):
+    """30 random fused banks (SAVGOL_STREAMBANK_FMA) fed by sequences of push_block calls of random lengths -- shorter than one tile, one tile, many
+    tiles; stream counts with whole, partial and single tile groups; half windows and orders on both sides of the block-moment tiles' range (n = 12..20,
+    taps of degree <= 2) -- against the double oracle, bar: the FMA bank's (max(1e-6, 1.1 x the reference-order bank's own error on the same samples)).
+    Every call continues from the ring the previous one left, so the tiles' history path (rows from the ring, not from this call) is exercised too."""
+    torch = torch_gpu
+    seed, iters = fuzz(20261006, 30)
+    rng = np.random.default_rng(seed)
+    for it in range(iters):
+        n = int(rng.choice([int(rng.integers(1, 33)), int(rng.integers(12, 21))]))
+        m = int(rng.choice([0, 1, 2, 2, 3, 4])); m = min(m, 2 * n)
+        d = int(rng.integers(0, min(m, 2) + 1))
+        dt = float(rng.choice([1.0, 1e-3, 0.5]))
+        S = int(rng.choice([128, 384, 1024, 2176, 8960]))
+        cuts = [int(v) for v in rng.choice([1, 7, 40, 64, 65, 96, 130, 257], size=int(rng.integers(2, 5)))]
+        T = sum(cuts)
+        if T < 2 * n + 2:
+            cuts.append(2 * n + 2 - T + 64); T = sum(cuts)
+        g = torch.Generator(device="cuda").manual_seed(seed + it)
+        xd = torch.randn((T, S), generator=g, device="cuda", dtype=torch.float32)
+        fast, ref = sg.StreamBank(S, n, m, d, dt, fma=True), sg.StreamBank(S, n, m, d, dt)
+        got = torch.full((T, S), float("nan"), device="cuda"); want = torch.full((T, S), float("nan"), device="cuda")
+        t0 = 0
+        for c in cuts:
+            fast.push_block(xd[t0:], c, got[t0:]); ref.push_block(xd[t0:], c, want[t0:]); t0 += c
+        torch.cuda.synchronize()
+        assert torch.isnan(got[:2 * n]).all() and not torch.isnan(got[2 * n:]).any(), (it, n, m, d, S, cuts)
+        pick = sorted({0, 1, S // 2, S - 1, int(rng.integers(0, S))})
+        xh = xd[:, pick].cpu().numpy().astype(np.float64).T.copy()
+        ref64 = sgo.Filter(n, m, d, dt).apply_f64(xh)[:, n:T - n]
+        e_fast = normwise(got[2 * n:, pick].cpu().numpy().T, ref64)
+        e_ref = normwise(want[2 * n:, pick].cpu().numpy().T, ref64)
+        check(e_fast, fp32_bar(e_ref), ("fused bank, random block sequence", it, n, m, d, S, tuple(cuts), e_ref))
+        # every stream, not only the sampled ones: the two banks agree to twice the bar
+        assert normwise(got[2 * n:].cpu().numpy(), want[2 * n:].cpu().numpy()) <= 2 * fp32_bar(e_ref), (it, n, m, d, S, cuts)
+
+
 def test_push_wait_returns_complete_outputs(sg, sgo, torch_gpu):
     """savgol_streambank_push_wait (round 5): one tick whose outputs are complete on return -- the stream writes a completion word behind the
     tick kernel and the host spins on it, no hipStreamSynchronize.  Same values, bit for bit, as savgol_streambank_push + synchronise on a twin
