@@ -34,7 +34,7 @@ N, M, D = 32, 4, 0
 # the dominant kernels of configs 3 / 4 as rocprofv3 names them (profiles/r05_*_kernel_stats.csv)
 STREAM_KERNEL_FMA = "sg_bank_dma_kernel<16,true,32,8,16,1,2,MomTaps<16,2>> (LDS-DMA tiles, 8-tick block moments; SAVGOL_HIP_STREAM_MOMENT=0: tap by tap; SAVGOL_HIP_STREAM_DMA=0: sg_bank_roll_kernel<16,true>)"
 STREAM_KERNEL_REF = "sg_bank_dma_kernel<16,false,...> (SAVGOL_HIP_STREAM_DMA=0: sg_bank_roll_kernel<16,false>)"
-IMAGE_KERNEL = "sg2d_rolling_kernel<7,2,1,true,false,16>"
+IMAGE_KERNEL = "sg2d_rolling_kernel<7,2,1,true,false,20>"
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -582,8 +582,12 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 // tools/membench_tile2d.hip (profiles/r04_membench_tile2d.txt): the bare tile pattern moves 0.71-0.72 of the roofline at full
 // occupancy whatever the tile height (8 ... 32 rows) and MORE on fewer resident waves (8 per CU: 0.757, 4 per CU: 0.775; the flat copy
 // 0.80) -- so the row registers of a 16-row tile (30 rows x 4 VGPRs) cost nothing that matters.
+// 20 rows since the end of round 5: once the x-stationary horizontal unit had freed its 2N + 3 window pairs the taller tile fits the same three waves per
+// SIMD, and over fresh buffer pairs in one process (tools/placement_2d.py, profiles/r05_2d_tile_rows.txt) 20-row tiles are 1.4-2.4 % faster than 16 at
+// n = 2, 3, 7 (all three boundary modes), 0.3-0.9 % at n = 4, 5, 6; 18: 0.7 %, 22 / 24: 1.6 / 5.5 % SLOWER.  (Round 4's single-placement sample of the old
+// kernel had 20 rows 12 % slower: it crossed 168 registers then.)
 #ifndef SG_ROLL_TILE_ROWS
-#define SG_ROLL_TILE_ROWS 16
+#define SG_ROLL_TILE_ROWS 20
 #endif
 // the general one- and two-term forms of one output frame run as tiles too (derivative frames, orders 4-5 of small windows): 12-20 % faster
 // than the walk at n = 2 ... 7 with one term, 12-20 % (n <= 5) / 1-5 % (n = 6, 7) with two (profiles/r04_2d_tile_experiments.txt)

@@ -62,7 +62,7 @@ jobs = [("f32", "sg1d_center_momenth_kernel<32, 5>", 8.0 * 4096 * (1 << 20), Non
         ("f64", "sg1d_center_kernel<double, 32", 16.0 * 1024 * (1 << 22), None, "r05_1d_f64_n32_pmc_summary.json", "bench.py --workload batch1d_f64 --c5-channels 1024 --no-cpu --steps 2 --warmup 1", "BASELINE config 5 chunk: 1024 x 2^22 fp64, n=32, m=4, d=2"),
         ("f64m", "sg1d_center_moment64_kernel<32, 5>", 16.0 * 1024 * (1 << 22), None, "r05_1d_f64m_n32_pmc_summary.json", "bench.py --workload batch1d_f64 --c5-channels 1024 --no-cpu --steps 2 --warmup 1 --f64-moment", "BASELINE config 5 chunk, OPT-IN block moments (SAVGOL_BATCH_MOMENT_F64): 1024 x 2^22 fp64, n=32, m=4, d=2"),
         ("stream", "sg_bank_dma_kernel<16, true", 8.0 * 65536 * 4096, SRC_STREAM, "r05_stream_block_pmc_summary.json", "bench.py --workload stream --no-cpu --no-extra --steps 3 --warmup 1", "BASELINE config 3 block push: 65536 streams x 4096 ticks, n=16, m=2, d=1, SAVGOL_STREAMBANK_FMA"),
-        ("image", "sg2d_rolling_kernel<7, 2, 1, true, false, 16>", 8.0 * 512 * 4096 * 4096, SRC_2D, "r05_2d_config4_pmc_summary.json", "bench.py --workload image --no-cpu --steps 1 --warmup 1", "BASELINE config 4: 512 x 4096^2 fp32, n=7, order 3 (additive form, 16-row tiles)")]
+        ("image", "sg2d_rolling_kernel<7, 2, 1, true, false, 20>", 8.0 * 512 * 4096 * 4096, SRC_2D, "r05_2d_config4_pmc_summary.json", "bench.py --workload image --no-cpu --steps 1 --warmup 1", "BASELINE config 4: 512 x 4096^2 fp32, n=7, order 3 (additive form, 16-row tiles)")]
 for name, kernel, algb, src, out, cmd, wl in jobs:
     if not os.path.isdir(os.path.join(O, name + "_fetch")):
         continue
