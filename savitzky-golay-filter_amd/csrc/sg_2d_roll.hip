@@ -594,16 +594,36 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #ifndef SG_ROLL_TILE_GENERAL
 #define SG_ROLL_TILE_GENERAL 1
 #endif
+// additive form, half windows 8 .. 12 (A/B builds override).  End of round 5, after the x-stationary horizontal unit had freed 2N + 3 register pairs
+// (tools/placement_2d.py, 32 frames of 4096^2, ms over six buffer pairs; profiles/r05_2d_tile_rows.txt): n = 8: 10 rows 0.900, 14 rows 0.862, 16 rows 0.889;
+// n = 9: 10 / 12 / 14 rows 0.992 / 0.967 / 0.949; n = 10: 8 / 10 / 12 rows 1.073 / 1.017 / 1.016; n = 11, 12: 8-12-row tiles 1.38-1.62 against the walk's
+// 1.27 / 1.30 -- they still spill and keep the walk
+#ifndef SG_ROLL_TR8
+#define SG_ROLL_TR8 14
+#endif
+#ifndef SG_ROLL_TR9
+#define SG_ROLL_TR9 14
+#endif
+#ifndef SG_ROLL_TR10
+#define SG_ROLL_TR10 12
+#endif
+#ifndef SG_ROLL_TR11
+#define SG_ROLL_TR11 0
+#endif
+#ifndef SG_ROLL_TR12
+#define SG_ROLL_TR12 0
+#endif
 constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
 {
     if (box && nt == 2 && nout == 1 && n <= 7) return SG_ROLL_TILE_ROWS;
     // half window 8: 16 + 16 rows do not fit three waves per SIMD, 10 + 16 do (with 20 bytes of scratch): 6.92 vs 7.61 ms per 256 frames
     // (12 rows 6.93, 8 rows 7.21; profiles/r04_2d_tile_experiments.txt)
-    if (box && nt == 2 && nout == 1 && n == 8) return 10;
+    if (box && nt == 2 && nout == 1 && n == 8) return SG_ROLL_TR8;
     if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && n == 8) return 12;     // one term: 1.65 vs 1.97 ms per 64 frames (10 rows: 1.70)
     // half windows 9, 10 (64 frames, ms, tile vs walk): n = 9 additive 1.97 vs 2.25, one term 1.85 vs 2.09 (10 rows; 8 rows 2.05 / 1.95);
     // n = 10 additive 2.14 vs 2.31 (8 rows; 10 spill: 2.16), one term 1.91 vs 2.13 (10 rows, 20 bytes of scratch; 8 rows 2.04)
-    if (box && nt == 2 && nout == 1 && (n == 9 || n == 10)) return n == 9 ? 10 : 8;
+    if (box && nt == 2 && nout == 1 && (n == 9 || n == 10)) return n == 9 ? SG_ROLL_TR9 : SG_ROLL_TR10;
+    if (box && nt == 2 && nout == 1 && (n == 11 || n == 12)) return n == 11 ? SG_ROLL_TR11 : SG_ROLL_TR12;
     if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && (n == 9 || n == 10)) return 10;
     // (half windows 11, 12 spill 100-600 bytes at three waves per SIMD even on 6-row tiles: they keep the walk)
     if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt <= 2 && n <= 7) return SG_ROLL_TILE_ROWS;

@@ -1,8 +1,6 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r5
-rm -f gpurun_out/r5/parity.jsonl
-SAVGOL_PARITY_LOG=$PWD/gpurun_out/r5/parity.jsonl timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -30 > gpurun_out/r5/gputests.txt
-python tools/parity_margins.py gpurun_out/r5/parity.jsonl > gpurun_out/r5/parity_margins.txt 2>&1
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r5/smoke.txt 2>&1
-bash tools/run_profiles_r5.sh > gpurun_out/r5_prof.log 2>&1
-python bench.py > gpurun_out/r5/bench_line_after.json 2> gpurun_out/r5/bench_line_after.err
-tail -4 gpurun_out/r5/gputests.txt; grep -c OVER gpurun_out/r5/parity_margins.txt; tail -1 gpurun_out/r5/smoke.txt
+L=savitzky-golay-filter_amd/lib/libsavgol_hip.so; B=tools/ab/lib_before.so
+{ timeout 1500 python -m pytest tests/test_gpu_2d.py -x -q -m gpu 2>&1 | tail -2
+  for n in 8 9 10; do for b in 0 2; do echo "## n=$n boundary $b: new heights / before"; python tools/placement_2d.py $L $B --allocations 5 --n $n --images 32 --boundary $b 2>&1 | grep -v amdgpu.ids | tail -3 | head -1; done; done
+} > gpurun_out/r5/tile_rows_check.txt 2>&1
+cat gpurun_out/r5/tile_rows_check.txt
