@@ -1,7 +1,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r5
-L=savitzky-golay-filter_amd/lib/libsavgol_hip.so; B=tools/ab/lib_before.so
-{ timeout 1500 python -m pytest tests/test_gpu_2d.py -x -q -m gpu 2>&1 | tail -2
-  for i in 1 2; do echo "## derivs, new"; python tools/time_2d_derivs.py 2>&1 | grep -v amdgpu.ids | grep -i "fused\|laplacian\|hessian\|gradient" | head -12; echo "## derivs, before"; SAVGOL_HIP_LIB=$PWD/$B python tools/time_2d_derivs.py 2>&1 | grep -v amdgpu.ids | grep -i "fused\|laplacian\|hessian\|gradient" | head -12; done
-  for cfg in "5 4" "7 4" "3 5"; do set -- $cfg; echo "## n=$1 order $2 (general two-term smoothing): new / before"; python tools/placement_2d.py $L $B --allocations 5 --n $1 --order $2 --images 32 2>&1 | grep -v amdgpu.ids | tail -3 | head -1; done
-} > gpurun_out/r5/xst_general.txt 2>&1
-cat gpurun_out/r5/xst_general.txt
+rm -f gpurun_out/r5/parity.jsonl
+SAVGOL_PARITY_LOG=$PWD/gpurun_out/r5/parity.jsonl timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -30 > gpurun_out/r5/gputests.txt
+python tools/parity_margins.py gpurun_out/r5/parity.jsonl > gpurun_out/r5/parity_margins.txt 2>&1
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r5/smoke.txt 2>&1
+bash tools/run_profiles_r5.sh > gpurun_out/r5_prof.log 2>&1
+tail -4 gpurun_out/r5/gputests.txt; grep -c OVER gpurun_out/r5/parity_margins.txt; tail -1 gpurun_out/r5/smoke.txt
