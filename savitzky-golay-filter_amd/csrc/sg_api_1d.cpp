@@ -355,7 +355,16 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         if (correct_edge && (f->config.derivative & 1)) job.flags |= sg::JOB_EDGE_NEGATE;
     }
     // split so that a launch stays below 2^24 blocks of four tiles (sg::MAX_TILES_PER_LAUNCH)
-    const size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / ((size_t)job.tiles_per_channel + 2);
+    size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / ((size_t)job.tiles_per_channel + 2);
+    if (inplace) {
+        // in place: channel groups whose halo stash stays below 64 MiB -- the stash then lives inside what the scratch pool keeps (256 MiB) instead of
+        // being handed back to the driver and mapped again on every call (config 5's 1024-channel chunk: a 1 GiB stash, 14 ms a call on most boxes and 98
+        // on one), and a 137 GB slice needs 64 MiB beside it, not a gigabyte.  A few more launches; the groups follow each other on the stream.
+        const int NA0 = (n + E - 1) / E * E;
+        const size_t per_ch = ((size_t)job.tiles_per_channel * (size_t)(2 * NA0) + 2 * (size_t)ws) * sizeof(T);
+        const size_t group = per_ch ? ((size_t)64 << 20) / per_ch : max_ch;
+        if (group >= 1 && group < max_ch) max_ch = group;
+    }
     for (size_t c0 = 0; c0 < channels; c0 += max_ch) {
         const size_t nc = (channels - c0 < max_ch) ? channels - c0 : max_ch;
         job.in = d_in + c0 * in_ld;
