@@ -630,7 +630,10 @@ def test_randomized_row_bands_and_rectangular_windows(sg, sgo, torch_gpu):
         assert np.array_equal(ph == -9.0, wh == -9.0), (nx, ny, order, dx, dy, rows, cols, b, method, world)
         additive = method != 1 and nx == ny and order <= 3 and dx + dy == 0
         if additive:
-            assert np.abs(ph - wh).max() <= 2.5e-7 * np.abs(x).max(), (nx, order, rows, cols, b, world)      # rolling sums scale with the INPUT
+            # the additive form's rolling column sums are re-seeded at the first row of every tile, and a band's tiles start at other frame rows than the
+            # whole frame's: the two answers differ by the rounding of up to TR add / subtract steps on sums that scale with the INPUT.  2.5e-7 x max|x|
+            # held with 16-row tiles; the 20-row tiles of round 5 reach 3.3e-7 on two of twelve soak seeds at four times the committed draws (n = 1)
+            assert np.abs(ph - wh).max() <= 4e-7 * np.abs(x).max(), (nx, order, rows, cols, b, world)
         else:
             assert np.array_equal(ph, wh), (nx, ny, order, dx, dy, rows, cols, b, method, world, np.abs(ph - wh).max())
         done += 1
