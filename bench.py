@@ -1011,6 +1011,29 @@ def run_config5(r):
     r.finish()
 
 
+def placement_spread(sg, x, filters, ch, length, alg_bytes):
+    """the headline's passes on up to three fresh buffer pairs (a function of its own: every temporary dies on return -- config 5's slice needs the memory)"""
+    try:
+        free_b, _ = torch.cuda.mem_get_info()
+        pairs = int(min(3, (free_b - (8 << 30)) // (2 * x.numel() * 4))) if free_b > (8 << 30) else 0
+        fr, keep = [], []
+        for _ in range(pairs):
+            x2 = torch.empty_like(x); y2 = torch.empty_like(x)
+            keep += [x2, y2]                                             # alive until the end: the next pair must land on other physical pages
+            sg.synth(x2, channel0=0)
+            for _w in range(2):                                          # the first launches over a fresh pair are slower whatever they are
+                filters[0].apply_batch(x2, y2, ch, length)
+            ms2 = timed(lambda: [flt.apply_batch(x2, y2, ch, length) for flt in filters], reps=3, warm=1) / len(filters)
+            fr.append(round(alg_bytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        if not fr:
+            return {"fresh_pairs": 0, "note": "not enough free memory for another pair of buffers"}
+        return {"fresh_pairs": len(fr), "frac_of_each": fr, "frac_min": min(fr), "frac_max": max(fr),
+                "note": "the same four passes on fresh allocations of the two buffers inside this process, after the timed region: one run's frac is one "
+                        "placement (tools/placement_1d.py, profiles/r05_placement_1d.txt)"}
+    except Exception as e:                                               # noqa: BLE001 -- diagnostic only
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def run_headline(r):
     """BASELINE config 2, the headline: 4096 channels x 2^20 fp32 per GPU, n=32, m=4, one launch per boundary mode per step"""
     args, sg, dev = r.args, r.sg, r.dev
@@ -1099,6 +1122,10 @@ def run_headline(r):
                                                      "library's bit for bit")
             out.update(sec)
         if r.world == 1 and not args.no_extra:
+            # PLACEMENT SPREAD (round 5, profiles/EXPERIMENTS.md R5.9): the same launch on a few FRESH buffer pairs inside this process, the timed pair
+            # kept alive so that new physical pages back the new ones -- how much of this run's `frac` is where its two 16 GiB buffers happen to
+            # sit.  Outside the timed region; `roofline.frac` above is the timed pair's and nothing else.
+            out["roofline"]["placement_spread"] = placement_spread(sg, x, filters, ch, length, alg_bytes)
             del x, y
             torch.cuda.empty_cache()
             extra = {"build": build_facts(sg)}

@@ -37,6 +37,9 @@ def test_single_gpu_line():
     roof = d["roofline"]
     assert {"copy_frac", "frac_of_copy", "read_only_frac"} <= set(roof)
     assert 0.3 < roof["copy_frac"] < 1.0 and 0.3 < roof["read_only_frac"] < 1.0 and abs(roof["frac_of_copy"] - roof["frac"] / roof["copy_frac"]) < 1e-3
+    # round 5: the same passes on fresh buffer pairs inside the process (one run's frac is one placement of its two buffers)
+    sp = roof["placement_spread"]
+    assert "error" not in sp and sp["fresh_pairs"] >= 1 and all(0.05 < v < 1.0 for v in sp["frac_of_each"]), sp
     ex = d["extra"]
     assert ex["build"]["library"].endswith("libsavgol_hip.so") and "library_sha256_16" in ex["build"]
     for leg, keys in (("config1", ()), ("config3", ("block_push",)), ("config4", ("modes", "CONSTANT"))):
