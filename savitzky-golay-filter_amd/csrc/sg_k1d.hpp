@@ -118,7 +118,10 @@ struct K1D {
     static constexpr int SL   = SV * E;                      // elements in a slab
     static constexpr int WQ   = (NA + R + N + E - 1) / E;    // vectors a lane reads
     static constexpr int SLAB = 16 * (SV + (SV + VPL - 1) / VPL);   // bytes: one pad vector after every VPL
-    static constexpr int WAVES = 4;                          // waves per block, each with its own slab
+#ifndef SG_K1D_WAVES
+#define SG_K1D_WAVES 4
+#endif
+    static constexpr int WAVES = SG_K1D_WAVES;               // waves per block, each with its own slab (A/B builds of one kernel family override; the host counts blocks of 4 tiles)
     // waves per SIMD the register allocation must allow (the LDS slabs allow as many blocks per CU)
     // (fp64 fits 128 VGPRs since its taps moved to SGPRs, but A/B'd in one process the 168-VGPR schedule is 2.5 % faster)
     // (the 12 / 16 KiB tiles hold 3 / 2 blocks per CU in LDS: asking for more only caps the registers for nothing)
@@ -374,7 +377,8 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
     const unsigned nb8 = gridDim.x >> 3;
     unsigned blk = blockIdx.x;
     if (blk < nb8 * 8u) {
-        const unsigned cs = job.xcd_chunk_log2;
+        // (the host counts chunks in blocks of four tiles: a kernel family built with fewer waves per block has proportionally more blocks per chunk)
+        const unsigned cs = job.xcd_chunk_log2 == 0 || job.xcd_chunk_log2 >= 32u ? job.xcd_chunk_log2 : job.xcd_chunk_log2 + (K::WAVES == 4 ? 0u : K::WAVES == 2 ? 1u : 2u);
         if (cs == 0) blk = (blk & 7u) * nb8 + (blk >> 3);
         else if (cs < 32u) {
             const unsigned span = 8u << cs, q = blk >> (cs + 3u);
@@ -555,7 +559,7 @@ struct DirectConv {
 
 // V = vectors per lane: the narrow tile every job can use, or the wide one the host picks for big batches (sg_k1d_host.hpp)
 template <typename T, int N, int V>
-__global__ __launch_bounds__(256, (K1D<T, N, V>::MIN_WAVES)) void sg1d_center_kernel(const Job1D job, const Taps taps)
+__global__ __launch_bounds__(64 * SG_K1D_WAVES, (K1D<T, N, V>::MIN_WAVES)) void sg1d_center_kernel(const Job1D job, const Taps taps)
 {
     sg1d_tile_body<T, N, DirectConv<T, N, V>>(job, taps);
 }
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(256, (K1D<T, N, V>::MIN_WAVES)) void sg1d_center_ke
 // and two dense scratch frames).  Everything between staging and store is the dense kernel's (Conv<float, N>, same slab).
 // ---------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256, (K1D<float, N, SG_VPL_NARROW>::MIN_WAVES)) void sg1d_strided_kernel(const JobStrided job, const Taps taps)
+__global__ __launch_bounds__(64 * SG_K1D_WAVES, (K1D<float, N, SG_VPL_NARROW>::MIN_WAVES)) void sg1d_strided_kernel(const JobStrided job, const Taps taps)
 {
     typedef K1D<float, N, SG_VPL_NARROW> K;
     constexpr int R = K::R, TW = K::TW, NA = K::NA, VPL = K::VPL;

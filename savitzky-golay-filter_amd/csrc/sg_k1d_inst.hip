@@ -26,7 +26,7 @@ struct Dispatch1D {
             fprintf(stderr, "[savgol-hip] sg1d_center_kernel<%s,%d,%d>: grid %u x 256, occupancy API %d blocks/CU, %d VGPR, %zu B LDS\n",
                     sizeof(T) == 4 ? "float" : "double", N, V, grid, nb, fa.numRegs, fa.sharedSizeBytes);
         }
-        hipLaunchKernelGGL((sg1d_center_kernel<T, N, V>), dim3(grid), dim3(256), 0, st, job, taps);
+        hipLaunchKernelGGL((sg1d_center_kernel<T, N, V>), dim3(grid * (4 / SG_K1D_WAVES)), dim3(64 * SG_K1D_WAVES), 0, st, job, taps);     // `grid` counts blocks of 4 tiles
     }
     // wide != 0: the job's tiles were laid out with wide_vectors_per_lane (the host only asks where that differs from the narrow tile)
     static int go(int n, int wide, const Job1D &job, const Taps &taps, unsigned grid, hipStream_t st)
@@ -46,7 +46,7 @@ struct Dispatch1D {
 template <int N, int HI>
 static int dispatch_strided(int n, const JobStrided &job, const Taps &taps, unsigned grid, hipStream_t st)
 {
-    if (n == N) { hipLaunchKernelGGL((sg1d_strided_kernel<N>), dim3(grid), dim3(256), 0, st, job, taps); return 1; }
+    if (n == N) { hipLaunchKernelGGL((sg1d_strided_kernel<N>), dim3(grid * (4 / SG_K1D_WAVES)), dim3(64 * SG_K1D_WAVES), 0, st, job, taps); return 1; }
     if constexpr (N < HI) return dispatch_strided<N + 1, HI>(n, job, taps, grid, st);
     else return 0;
 }

@@ -219,7 +219,7 @@ struct MomentHConv {
 };
 
 template <int N, int M1>
-__global__ __launch_bounds__(256, 4) void sg1d_center_momenth_kernel(const Job1D job, const MomentArgs args)
+__global__ __launch_bounds__(64 * SG_K1D_WAVES, 4) void sg1d_center_momenth_kernel(const Job1D job, const MomentArgs args)
 {
     sg1d_tile_body<float, N, MomentHConv<N, M1>>(job, args);
 }
