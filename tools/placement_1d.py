@@ -22,6 +22,7 @@ ap.add_argument("--length", type=int, default=1 << 20)
 ap.add_argument("--allocations", type=int, default=10)
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--f64", action="store_true")
+ap.add_argument("--flags", type=int, default=None, help="SAVGOL_BATCH_* flags: the *_ex entry point (64 = SAVGOL_BATCH_MOMENT_F64)")
 a = ap.parse_args()
 
 
@@ -46,8 +47,13 @@ for spec in a.libs:
     L = C.CDLL(lib_file)
     L.savgol_create.restype = C.c_void_p
     L.savgol_create.argtypes = [C.POINTER(Cfg)]
-    fn = L.savgol_apply_batch_f64 if a.f64 else L.savgol_apply_batch_f32
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_size_t] * 4 + [C.c_void_p]
+    if a.flags is None:
+        fn = L.savgol_apply_batch_f64 if a.f64 else L.savgol_apply_batch_f32
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_size_t] * 4 + [C.c_void_p]
+    else:
+        ex = L.savgol_apply_batch_f64_ex if a.f64 else L.savgol_apply_batch_f32_ex
+        ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_size_t] * 4 + [C.c_uint, C.c_void_p]
+        fn = lambda f, x, y, ch, L_, a1, a2, st, ex=ex: ex(f, x, y, ch, L_, a1, a2, a.flags, st)
     cfg = Cfg(a.n, a.m, a.deriv, 1.0, 1)
     f = L.savgol_create(C.byref(cfg))
     assert f and fn(f, x0.data_ptr(), y0.data_ptr(), 64, a.length, a.length, a.length, st) == 0           # the switches are read here
