@@ -3,7 +3,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "sg_internal.h"
+#include "sg_pk.hpp"
 
 namespace sg {
 
@@ -30,6 +33,55 @@ __device__ __forceinline__ int fix_index(int i, int n, int boundary)
     return i;
 }
 
+// ---- shared by the rolling kernels (sg_2d_roll.hip, sg_2d_hf.hip) ----
+// a + s * b, s = {+-1, +-1} in an SGPR pair.  Deliberately NOT inline asm: the hazard recogniser counts no wait
+// states for inline asm, so a chain of asm multiply-adds gets an s_nop per step unless compiler-visible
+// instructions (these folds) sit between a result and its use.
+__device__ __forceinline__ f32x2 pk_fold(const f32x2 s, const f32x2 b, const f32x2 a)
+{
+    return __builtin_elementwise_fma(s, b, a);
+}
+// (q.y, q.z) of ONE 16-byte LDS read: the middle pair of a quad sits in an odd-aligned register pair, and the compiler copies it
+// out with two v_mov_b32 (it only uses v_pk_mov_b32 for a pair that straddles two reads).  One v_pk_mov_b32 does it: 10 VALU
+// instructions fewer per row at n = 7, rank 2 (135 -> 125).
+__device__ __forceinline__ f32x2 pk_middle(const f32x2 lo, const f32x2 hi)
+{
+#ifdef SG_ROLL_PLAIN_MIDDLE
+    return pk_straddle(lo, hi);
+#else
+    f32x2 r;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+#endif
+}
+// fix_index (sg_2d.hpp) without branches: the row index is wave-uniform, so this is a handful of SALU selects
+__device__ __forceinline__ int fix_row(int i, int n, bool reflect)
+{
+    const int below = reflect ? ~i : 0;                      // i < 0:  -i-1 | 0
+    const int above = reflect ? 2 * n - 1 - i : n - 1;       // i >= n
+    int a = i < 0 ? below : (i >= n ? above : i);
+    a = a < 0 ? 0 : a;                                       // frames smaller than the window: one reflection, then clamp
+    return a >= n ? n - 1 : a;
+}
+
+// factors: per term Q_t[0..2N], pad, G_t[0..2N], pad (sg2d_factors_from_kernel).  Returns false when a vector has no
+// definite parity (cannot happen for a least-squares kernel on a symmetric window; arbitrary kernels may).
+inline bool vector_parity(const float *v, int n, float *sign)
+{
+    float vmax = 0.0f;
+    for (int k = 0; k <= 2 * n; ++k) vmax = fmaxf(vmax, fabsf(v[k]));
+    const float tol = 4e-6f * vmax;
+    bool even = true, odd = true;
+    for (int k = 0; k < n; ++k) {
+        if (fabsf(v[k] - v[2 * n - k]) > tol) even = false;
+        if (fabsf(v[k] + v[2 * n - k]) > tol) odd = false;
+    }
+    if (fabsf(v[n]) > tol) odd = false;
+    if (even) { *sign = 1.0f; return true; }
+    if (odd) { *sign = -1.0f; return true; }
+    return false;
+}
+
 constexpr int SEP_MAX_TERMS = 4;        // per output: rank of a bivariate polynomial of total degree <= 6 is at most 4 (parity in y)
 constexpr int SEP_MAX_OUTPUTS = 3;      // gradient = 2, Hessian = 3 outputs computed from ONE read of the input tile
 
@@ -39,7 +91,9 @@ struct SepPlan {
     int    terms[SEP_MAX_OUTPUTS];      // factors are stored output after output, term after term
     float  scale[SEP_MAX_OUTPUTS];
     float *out[SEP_MAX_OUTPUTS];        // same row stride / image pitch for all
+    int    transposed;                  // 1: vertical pass first (every output y-dominant: deriv_y >= 2, deriv_y > deriv_x), see sg_2d_sep.hip
 };
+inline bool sg2d_y_dominant(int deriv_x, int deriv_y) { return deriv_y >= 2 && deriv_y > deriv_x; }
 
 // Row bands of the strip kernels (sg_2d_roll.hip, sg_2d_dense.hip): an item = one strip x one band, `nwaves` resident
 // waves take items round robin.  Every band pays 2n warm-up rows (weighted `warm`: they cost full work in the dense
@@ -120,6 +174,20 @@ inline int sg2d_launch_rolling3(int n, int terms, const Job2D &job, const float 
     if (sg2d_launch_rolling3_g5(n, terms, job, f0, s0, f1, s1, f2, s2, out1, out2, images, cu_count, st) == 0) return 0;
     return sg2d_launch_rolling3_g6(n, terms, job, f0, s0, f1, s1, f2, s2, out1, out2, images, cu_count, st);
 }
+
+// sg_2d_hf.hip: ONE term of a kernel with the HORIZONTAL pass first (kernels whose x factor cancels harder than their y factor: deriv_x >= 2,
+// deriv_x > deriv_y); job.accumulate: out += result.  Built in three half-window groups (Makefile).  0 = launched, 1 = not covered, -1 = error.
+int sg2d_launch_rolling_hf_g0(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling_hf_g1(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling_hf_g2(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
+inline int sg2d_launch_rolling_hf(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
+{
+    if (sg2d_launch_rolling_hf_g0(n, job, factors, scale, images, cu_count, st) == 0) return 0;
+    if (sg2d_launch_rolling_hf_g1(n, job, factors, scale, images, cu_count, st) == 0) return 0;
+    return sg2d_launch_rolling_hf_g2(n, job, factors, scale, images, cu_count, st);
+}
+// which pass order suits a kernel in fp32 (sg_2d_hf.hip's header, tools/emulate_2d_passes.py): the pass that cancels harder goes first
+inline bool sg2d_x_dominant(int deriv_x, int deriv_y) { return deriv_x >= 2 && deriv_x > deriv_y; }
 
 // sg_2d_dense.hip: the bit-exact dense kernel on packed math, square windows with half window <= DENSE_ROLL_MAX_N.
 // 0 = launched, 1 = not covered (the caller uses sg2d_direct_kernel of sg_2d.hip), -1 = error.  h_w = the kernel on the host.

@@ -123,36 +123,6 @@ __device__ __forceinline__ f32x2 roll_mul_xb(const f32x2 s, const f32x2 x)
     return p;
 }
 
-// a + s * b, s = {+-1, +-1} in an SGPR pair.  Deliberately NOT inline asm: the hazard recogniser counts no wait
-// states for inline asm, so a chain of asm multiply-adds gets an s_nop per step unless compiler-visible
-// instructions (these folds) sit between a result and its use.
-__device__ __forceinline__ f32x2 pk_fold(const f32x2 s, const f32x2 b, const f32x2 a)
-{
-    return __builtin_elementwise_fma(s, b, a);
-}
-// (q.y, q.z) of ONE 16-byte LDS read: the middle pair of a quad sits in an odd-aligned register pair, and the compiler copies it
-// out with two v_mov_b32 (it only uses v_pk_mov_b32 for a pair that straddles two reads).  One v_pk_mov_b32 does it: 10 VALU
-// instructions fewer per row at n = 7, rank 2 (135 -> 125).
-__device__ __forceinline__ f32x2 pk_middle(const f32x2 lo, const f32x2 hi)
-{
-#ifdef SG_ROLL_PLAIN_MIDDLE
-    return pk_straddle(lo, hi);
-#else
-    f32x2 r;
-    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-#endif
-}
-// fix_index (sg_2d.hpp) without branches: the row index is wave-uniform, so this is a handful of SALU selects
-__device__ __forceinline__ int fix_row(int i, int n, bool reflect)
-{
-    const int below = reflect ? ~i : 0;                      // i < 0:  -i-1 | 0
-    const int above = reflect ? 2 * n - 1 - i : n - 1;       // i >= n
-    int a = i < 0 ? below : (i >= n ? above : i);
-    a = a < 0 ? 0 : a;                                       // frames smaller than the window: one reflection, then clamp
-    return a >= n ? n - 1 : a;
-}
-
 // One item: a 256-column strip whose first loaded column is xload, output rows yb .. yb+nout-1 of one frame.  VEC: the strip's 256
 // input columns are inside the frame, all its SW output columns are stored and rows are 16-byte aligned (one
 // dwordx4 load and store per lane per row); otherwise four remapped scalar loads and masked scalar stores (the
@@ -635,8 +605,8 @@ constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
 #ifndef SG_ROLL_TILE_WAVES
 #define SG_ROLL_TILE_WAVES 3
 #endif
-// (the general two-term form at n = 7 spills 52 bytes at 3 waves per SIMD)
-constexpr int roll_tile_waves(int n, int nt = 2, bool box = true, int nout = 1) { return (nout >= 2 || (!box && nt == 2 && n >= 7)) ? 2 : SG_ROLL_TILE_WAVES; }
+// (the general two-term form at n = 6, 7 spills 36-52 bytes at 3 waves per SIMD)
+constexpr int roll_tile_waves(int n, int nt = 2, bool box = true, int nout = 1) { return (nout >= 2 || (!box && nt == 2 && n >= 6)) ? 2 : SG_ROLL_TILE_WAVES; }
 
 // waves per block: the waves of a block walk neighbouring strips row for row, so a block's loads of one row step are one
 // contiguous run of the frame row
@@ -700,35 +670,19 @@ __global__ __launch_bounds__(64 * roll_wpb(N, TR), TR > 0 ? roll_tile_waves(N, N
         // fast variant: all 256 input columns inside the frame, all SW output columns stored, 16-byte aligned rows
         if ((aligned & 3) == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
             roll_item<N, NT, NOUT, 1, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
-        else if (TR > 0 && (aligned & 7) == 7) {             // bit 2: cols % 4 == 0 and wide enough for one reflection
-            if constexpr (TR > 0) {
-                if (valid) roll_item<N, NT, NOUT, 3, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
-                else roll_item<N, NT, NOUT, 2, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
-            }
+        else if constexpr (TR > 0) {
+            // tile kernels are only launched on frames whose every strip can run on vector loads (aligned bits 0-2: 16-byte aligned rows, cols % 4 == 0,
+            // wide enough for one reflection; launch_roll_kernel sends every other frame to the strip walk).  Round 6: the scalar path used to be
+            // compiled into the tile kernels too, and IT was what spilled -- 2 to 24 registers, a private segment for every wave of a launch that
+            // never ran it.
+            if (valid) roll_item<N, NT, NOUT, 3, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+            else roll_item<N, NT, NOUT, 2, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
         } else
             roll_item<N, NT, NOUT, 0, BOX, ACC, TR>(job, taps, mine, in, outs, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
     }
 }
 
 // ---- host ----
-// factors: per term Q_t[0..2N], pad, G_t[0..2N], pad (sg2d_factors_from_kernel).  Returns false when a vector has no
-// definite parity (cannot happen for a least-squares kernel on a symmetric window; arbitrary kernels may).
-static bool vector_parity(const float *v, int n, float *sign)
-{
-    float vmax = 0.0f;
-    for (int k = 0; k <= 2 * n; ++k) vmax = fmaxf(vmax, fabsf(v[k]));
-    const float tol = 4e-6f * vmax;
-    bool even = true, odd = true;
-    for (int k = 0; k < n; ++k) {
-        if (fabsf(v[k] - v[2 * n - k]) > tol) even = false;
-        if (fabsf(v[k] + v[2 * n - k]) > tol) odd = false;
-    }
-    if (fabsf(v[n]) > tol) odd = false;
-    if (even) { *sign = 1.0f; return true; }
-    if (odd) { *sign = -1.0f; return true; }
-    return false;
-}
-
 // fill output o's taps from its factor block; false when a vector has no definite parity or the terms disagree
 template <int N, int NT, int NOUT>
 static bool fill_taps(RollTaps<N, NT, NOUT> &taps, int o, const float *factors, float scale)
@@ -812,8 +766,11 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
     if (job.out_stride % 4 == 0 && job.out_pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(job.out) & 15u) == 0 &&
         (NOUT < 2 || (reinterpret_cast<uintptr_t>(out1) & 15u) == 0) && (NOUT < 3 || (reinterpret_cast<uintptr_t>(out2) & 15u) == 0) &&
         (long long)job.rows * job.out_stride * 4 < 0x7fffff00ll) aligned |= 2;       // the store descriptor holds a 31-bit byte count
-    static const int edge_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_TILE_EDGE"); return e ? atoi(e) : 1; }();     // 0: edge strips on the scalar path (A/B)
-    if (TR > 0 && edge_env && job.cols % 4 == 0 && job.cols >= 32) aligned |= 4;
+    if (TR > 0 && job.cols % 4 == 0 && job.cols >= 32) aligned |= 4;
+    if constexpr (TR > 0) {
+        // frames a tile kernel cannot take on vector loads alone (odd strides, unaligned bases, cols % 4 != 0, narrower than 32 columns): the strip walk
+        if ((aligned & 7) != 7) return launch_roll_kernel<N, NT, NOUT, BOX, ACC, 0>(job, taps, out1, out2, images, cu_count, st);
+    }
     static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_XCD"); return e ? atoi(e) : 1; }();
     if (!xcd_env) aligned |= 8;
     const unsigned strips = (unsigned)((job.cols + R::SW - 1) / R::SW);

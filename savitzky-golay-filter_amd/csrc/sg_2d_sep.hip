@@ -71,9 +71,14 @@ struct Sep {
 };
 
 // NOUT = number of output frames (compile time: the single-output kernel must not pay for the multi-output loop)
+// transposed (round 6): the tile is staged TRANSPOSED in LDS (LDS row = image column), so the "row pass" runs down the image columns with
+// the G taps and the "column pass" along the image rows with the Q taps -- the VERTICAL pass first, for kernels whose y factor cancels
+// harder than their x factor (deriv_y >= 2, deriv_y > deriv_x): the cancelling pass must not be the last arithmetic an output sees
+// (sg_2d_hf.hip's header).  An output tile is then TH columns x 64 rows; loads stay coalesced along image rows, the stores are 48-byte
+// runs per lane -- the accurate order for method 3 on such kernels, not a fast path (method 2 / auto run them on the rolling kernel).
 template <int N, int NOUT>
 __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, const SepPlan plan, const float *__restrict__ factors,
-                                                             unsigned total_tiles)
+                                                             unsigned total_tiles, int transposed)
 {
     typedef Sep<N> S;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -101,6 +106,8 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
     // Wave w takes tile rows w, w+4, ...: the row index (and its remap) is scalar, a lane keeps its two
     // remapped column indices for the whole tile -- no per-element division or remap.
     constexpr int RPW = (S::ROWS + 3) / 4;              // rows per wave
+    constexpr int CPW = (TCOLS + 3) / 4;                // transposed: image rows per wave (<= 2 RPW: they share pre0 / pre1)
+    static_assert(CPW <= 2 * RPW, "transposed staging re-uses the two prefetch arrays");
     float pre0[RPW], pre1[RPW];
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,6 +115,19 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
         const unsigned img = t / tiles_per_image, rem = t - img * tiles_per_image;
         const int by = (int)(rem / (unsigned)job.tiles_x), bx = (int)(rem - (unsigned)by * (unsigned)job.tiles_x);
         const float *in = job.in + (long long)img * job.in_pitch;
+        if (transposed) {                                // uniform: LDS row = image column x0 - N + lane, LDS column c = image row y0 - N + c
+            const int x0 = bx * S::TH, y0 = by * S::TW;
+            const int ix = fix_index(x0 + lane - N, job.cols, job.boundary);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                const int c = wv + 4 * j;
+                if (c < TCOLS && lane < S::ROWS) {
+                    const float v = in[(long long)fix_index(y0 + c - N, job.rows, job.boundary) * job.in_stride + ix];
+                    if (j < RPW) pre0[j < RPW ? j : 0] = v; else pre1[j >= RPW ? j - RPW : 0] = v;
+                }
+            }
+            return;
+        }
         const int x0 = bx * S::TW, y0 = by * S::TH;
         const int ix0 = fix_index(x0 + lane - N, job.cols, job.boundary);
         const int ix1 = fix_index(x0 + lane + 64 - N, job.cols, job.boundary);
@@ -131,9 +151,16 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
     while (tile < total_tiles) {
         const unsigned img = tile / tiles_per_image, rem = tile - img * tiles_per_image;
         const int by = (int)(rem / (unsigned)job.tiles_x), bx = (int)(rem - (unsigned)by * (unsigned)job.tiles_x);
-        const int x0 = bx * S::TW, y0 = by * S::TH;
+        const int x0 = bx * (transposed ? S::TH : S::TW), y0 = by * (transposed ? S::TW : S::TH);
 
         __syncthreads();                                // previous tile's passes are done with tin / hbuf
+        if (transposed) {
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                const int c = wv + 4 * j;
+                if (c < TCOLS && lane < S::ROWS) tin[lane * S::PIN + c] = j < RPW ? pre0[j < RPW ? j : 0] : pre1[j >= RPW ? j - RPW : 0];
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
             const int r = wv + 4 * j;
@@ -141,6 +168,7 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
                 tin[r * S::PIN + lane] = pre0[j];
                 if (lane + 64 < TCOLS) tin[r * S::PIN + lane + 64] = pre1[j];
             }
+        }
         }
         const unsigned next = tile + nblk;
         if (next < total_tiles) prefetch(next);
@@ -155,11 +183,12 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
         for (int t = tbase; t < tbase + plan.terms[o]; ++t) {
             __syncthreads();                            // tin ready / previous term's hbuf consumed
             const float *wt = wl + t * 2 * (2 * N + 2);
+            const float *w_first = transposed ? wt + (2 * N + 2) : wt, *w_second = transposed ? wt : wt + (2 * N + 2);     // taps of the LDS-row pass, of the LDS-column pass
             // 2a. row pass: item = (tile row, 16-column segment); lane slides over 16 + 2N inputs
             {
                 f32x2 Wq[N + 1];
 #pragma unroll
-                for (int p = 0; p < N + 1; ++p) Wq[p] = f32x2{wt[2 * p], wt[2 * p + 1]};
+                for (int p = 0; p < N + 1; ++p) Wq[p] = f32x2{w_first[2 * p], w_first[2 * p + 1]};
                 if (tid < S::ROWS * 4) {
                     const int r = tid >> 2, seg = tid & 3;
                     const float *src = tin + r * S::PIN + seg * 16;
@@ -179,7 +208,7 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
             {
                 f32x2 Wg[N + 1];
 #pragma unroll
-                for (int p = 0; p < N + 1; ++p) Wg[p] = f32x2{wt[(2 * N + 2) + 2 * p], wt[(2 * N + 2) + 2 * p + 1]};
+                for (int p = 0; p < N + 1; ++p) Wg[p] = f32x2{w_second[2 * p], w_second[2 * p + 1]};
                 const float *col = hbuf + crow * S::PH + ccol;
                 WinConv<N, S::RYP>::template quads<0>(
                     [&](int q) {
@@ -204,10 +233,9 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
         const bool valid = job.boundary == SAVGOL2D_BOUNDARY_VALID;
         const int xlo = valid ? N : 0, xhi = valid ? job.cols - N : job.cols;
         const int ylo = valid ? N : 0, yhi = valid ? job.rows - N : job.rows;
-        const int ox = x0 + ccol;
 #pragma unroll
         for (int j = 0; j < S::RY; ++j) {
-            const int oy = y0 + crow + j;
+            const int ox = transposed ? x0 + crow + j : x0 + ccol, oy = transposed ? y0 + ccol : y0 + crow + j;
             const float v = (j & 1) ? acc[j >> 1].y : acc[j >> 1].x;
             if (ox >= xlo && ox < xhi && oy >= ylo && oy < yhi) out[(long long)oy * job.out_stride + ox] = v * plan.scale[o];
         }
@@ -222,17 +250,18 @@ static void launch_sep(const Job2D &job, const SepPlan &plan, const float *d_fac
 {
     typedef Sep<N> S;
     Job2D j = job;
-    j.tiles_x = (job.cols + S::TW - 1) / S::TW;
-    j.tiles_y = (job.rows + S::TH - 1) / S::TH;
+    const int transposed = plan.transposed;
+    j.tiles_x = (job.cols + (transposed ? S::TH : S::TW) - 1) / (transposed ? S::TH : S::TW);
+    j.tiles_y = (job.rows + (transposed ? S::TW : S::TH) - 1) / (transposed ? S::TW : S::TH);
     const size_t lds = sizeof(float) * (S::ROWS * S::PIN + (S::ROWS + 4) * S::PH + SEP_MAX_OUTPUTS * SEP_MAX_TERMS * 2 * (2 * N + 2));
     const unsigned long long total = (unsigned long long)images * j.tiles_x * j.tiles_y;      // caller keeps this < 2^32
     const unsigned per_cu = (unsigned)(160 * 1024 / lds) < 4u ? (unsigned)(160 * 1024 / lds) : 4u;
     unsigned grid = (unsigned)cu_count * (per_cu ? per_cu : 1u);
     if (grid > total) grid = (unsigned)total;
     grid = (grid + 7u) & ~7u;
-    if (plan.outputs == 1)      hipLaunchKernelGGL((sg2d_separable_kernel<N, 1>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total);
-    else if (plan.outputs == 2) hipLaunchKernelGGL((sg2d_separable_kernel<N, 2>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total);
-    else                        hipLaunchKernelGGL((sg2d_separable_kernel<N, 3>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total);
+    if (plan.outputs == 1)      hipLaunchKernelGGL((sg2d_separable_kernel<N, 1>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total, transposed);
+    else if (plan.outputs == 2) hipLaunchKernelGGL((sg2d_separable_kernel<N, 2>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total, transposed);
+    else                        hipLaunchKernelGGL((sg2d_separable_kernel<N, 3>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total, transposed);
 }
 
 template <int N>

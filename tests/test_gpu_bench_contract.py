@@ -21,7 +21,9 @@ def run(cmd, env=None):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    return json.loads(lines[0])
+    d = json.loads(lines[0])
+    d["_stdout_tail_4k"] = r.stdout[-4096:]
+    return d
 
 
 def test_single_gpu_line():
@@ -35,8 +37,22 @@ def test_single_gpu_line():
     # round 5: the distance from the REFERENCE's own fp32 output, and the copy ceiling measured in this process
     assert d["parity_normwise_vs_reference_fp32"] < 1e-6 and d["reference_fp32_own_error_vs_fp64_oracle"] < 1e-6 and "reference_fp32_from" in d
     roof = d["roofline"]
-    assert {"copy_frac", "frac_of_copy", "read_only_frac"} <= set(roof)
-    assert 0.3 < roof["copy_frac"] < 1.0 and 0.3 < roof["read_only_frac"] < 1.0 and abs(roof["frac_of_copy"] - roof["frac"] / roof["copy_frac"]) < 1e-3
+    assert {"copy_frac", "frac_of_copy", "read_ceiling_frac", "kernel_read_only_frac"} <= set(roof)
+    assert 0.3 < roof["copy_frac"] < 1.0 and 0.3 < roof["read_ceiling_frac"] < 1.0 and abs(roof["frac_of_copy"] - roof["frac"] / roof["copy_frac"]) < 1e-3
+    assert abs(roof["kernel_read_only_frac"] - 0.5 * roof["frac"]) < 1e-3          # N x sizeof(T) / t / 8e12, the kernel's own figure
+    # round 6: a compact per-config summary is the LAST key of the line, inside the tail the driver keeps, and no prose rides along
+    tail = d["_stdout_tail_4k"]
+    assert '"summary"' in tail and list(d)[-2] == "summary", list(d)[-3:]
+    sm = d["summary"]
+    assert len(json.dumps(sm)) <= 1400, len(json.dumps(sm))
+    for key in ("c1", "c2", "c3_fused", "c3_bit_exact", "c4_VALID", "c4_CONSTANT", "c4_REFLECT", "c4_rowband", "c5", "c5_in_place"):
+        if key == "c4_rowband" and "skipped" in d["extra"]["config4_rowband"]:
+            continue
+        assert key in sm and set(sm[key]) >= {"frac", "ms", "parity"}, (key, sm.get(key))
+        assert sm[key]["frac"] is not None and sm[key]["ms"] is not None, (key, sm[key])
+    assert "errors" not in sm, sm
+    assert sm["c3_bit_exact"]["parity"] == 0.0 and sm["c2"]["parity"] < 1e-6 and sm["c5"]["parity"] < 1e-6
+    assert '"note"' not in json.dumps({k: v for k, v in d.items() if k != "_stdout_tail_4k"})
     # round 5: the same passes on fresh buffer pairs inside the process (one run's frac is one placement of its two buffers)
     sp = roof["placement_spread"]
     assert "error" not in sp and sp["fresh_pairs"] >= 1 and all(0.05 < v < 1.0 for v in sp["frac_of_each"]), sp
