@@ -119,6 +119,8 @@ SIGNATURES = {
     "savgol_apply_strided_batch_f32": (C.c_int, [_F, _vp, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
     "savgol_apply_batch_f32_ex": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
     "savgol_apply_batch_f64_ex": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
+    "savgol_apply_batch_f64_tol": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, C.c_double, _vp]),
+    "savgol_apply_valid_batch_f64_tol": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, C.c_double, _vp]),
     "savgol_apply_valid_batch_f32_ex": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
     "savgol_apply_valid_batch_f64_ex": (C.c_int, [_F, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
     "savgol_apply_strided_batch_f32_ex": (C.c_int, [_F, _vp, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
@@ -283,12 +285,14 @@ class Filter:
                                           dst.ctypes.data, out_stride, out_offset, count)
 
     # ---- device-pointer batch calls (torch tensors or raw addresses) ----
-    def apply_batch(self, d_in, d_out, channels, length, in_ld=None, out_ld=None, dtype="f32", valid=False, stream=None, flags=None):
-        """flags=None: the process-wide defaults (savgol_hip_set_option); an int: the *_ex entry point with exactly these SAVGOL_BATCH_* flags."""
-        name = f"savgol_apply_{'valid_' if valid else ''}batch_{dtype}" + ("" if flags is None else "_ex")
+    def apply_batch(self, d_in, d_out, channels, length, in_ld=None, out_ld=None, dtype="f32", valid=False, stream=None, flags=None, rel_tol=None):
+        """flags=None: the process-wide defaults (savgol_hip_set_option); an int: the *_ex entry point with exactly these SAVGOL_BATCH_* flags;
+        rel_tol (fp64 only): savgol_apply[_valid]_batch_f64_tol -- the accuracy the caller accepts picks the kernel."""
+        assert rel_tol is None or (dtype == "f64" and flags is None)
+        name = f"savgol_apply_{'valid_' if valid else ''}batch_{dtype}" + ("_tol" if rel_tol is not None else ("" if flags is None else "_ex"))
         args = [self.ptr, _addr(d_in), _addr(d_out), channels, length, length if in_ld is None else in_ld,
                 (length - 2 * self.n if valid else length) if out_ld is None else out_ld]
-        rc = getattr(lib(), name)(*args, *([] if flags is None else [flags]), _stream(stream))
+        rc = getattr(lib(), name)(*args, *([float(rel_tol)] if rel_tol is not None else ([] if flags is None else [flags])), _stream(stream))
         if rc != 0:
             raise RuntimeError(f"{name} returned {rc}: {last_error()}")
 

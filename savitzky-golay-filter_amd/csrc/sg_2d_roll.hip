@@ -575,7 +575,7 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #define SG_ROLL_TR9 14
 #endif
 #ifndef SG_ROLL_TR10
-#define SG_ROLL_TR10 12
+#define SG_ROLL_TR10 10     /* round 6: 12 rows spill 4 registers now that nothing else does; 10 rows were level (1.017 against 1.016 ms) */
 #endif
 #ifndef SG_ROLL_TR11
 #define SG_ROLL_TR11 0

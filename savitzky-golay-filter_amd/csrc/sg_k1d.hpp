@@ -402,7 +402,19 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
 #endif
     SG_STAMP(0);
     const unsigned c = job.tpc_shift >= 32 ? tile : (__umulhi(tile, job.tpc_magic) >> job.tpc_shift);   // tile / tiles_per_channel, on the scalar unit
-    const int ts = (int)(tile - c * job.tiles_per_channel) * TW;
+    // in-place colour phases (Job1D::phase): the launch holds the even (1) or the odd (2) tiles of every channel; slot = the tile's place in the stash
+    unsigned k = tile - c * job.tiles_per_channel, slot = tile;
+    bool st_left = job.stash != nullptr, st_right = st_left;
+    if (job.phase) {
+        k = 2u * k + (job.phase - 1u);
+        slot = c * job.tpc_all + k;
+        if (job.phase == 1u) {
+            st_left = k == 0u;
+            const int last_body = (int)job.length - (int)(job.tpc_all - 1u) * TW;          // samples in the channel's last tile
+            st_right = k + 1u == job.tpc_all || (k + 2u == job.tpc_all && last_body < NA);
+        }
+    }
+    const int ts = (int)k * TW;
     const T *__restrict__ row = gin + (long long)c * job.in_ld;
     // slab byte offset of vector lane + 64*s: when VPL divides 64 the pad count splits, (lane + 64 s)/VPL = lane/VPL + s*64/VPL,
     // so one VGPR holds the lane part and s goes into the instruction's immediate offset
@@ -413,19 +425,20 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
     };
 
     // ---- stage tile + halo into the slab ----
-    if (job.stash) {
-        // IN PLACE (out == in): the body [ts, ts + TW) belongs to this tile alone -- nobody else reads or writes it -- and the NA samples on
-        // either side, which the neighbours overwrite in their own time, come from the stash (already remapped / zero-filled per mode)
-        const VT *st = static_cast<const VT *>(job.stash) + (size_t)tile * (2 * HV);
+    if (st_left || st_right) {
+        // IN PLACE (out == in): the body [ts, ts + TW) belongs to this tile alone -- nobody else reads or writes it.  A halo the neighbours may already
+        // have overwritten (odd phase: both) or that reaches past the channel's end (even phase) comes from the tile's stash slot, already remapped /
+        // zero-filled per mode; the other side of an even tile is still untouched in the rows
+        const VT *st = static_cast<const VT *>(job.stash) + (size_t)slot * (2 * HV);
         if ((job.flags & JOB_VEC_IN) && ts + TW <= L) {
             const VT *src = reinterpret_cast<const VT *>(row + ts) - HV;              // slab vector v <-> sample ts - NA + v E
             VT p[VPL + 1];
 #pragma unroll
             for (int s = 0; s < VPL; ++s) {
-                if (s == 0) p[0] = lane < HV ? st[lane] : ld_stream(src + lane);
+                if (s == 0) p[0] = (lane < HV && st_left) ? st[lane] : ld_stream(src + lane);
                 else p[s] = ld_stream(src + lane + 64 * s);
             }
-            if (lane < 2 * HV) p[VPL] = lane < HV ? ld_stream(src + TV + lane) : st[lane];          // body tail, then the right halo = st[HV + (lane - HV)]
+            if (lane < 2 * HV) p[VPL] = (lane < HV || !st_right) ? ld_stream(src + TV + lane) : st[lane];          // body tail, then the right halo = st[HV + (lane - HV)]
 #pragma unroll
             for (int s = 0; s < VPL; ++s) *row_vec(s) = p[s];
             if (lane < 2 * HV) *row_vec(VPL) = p[VPL];
@@ -437,9 +450,9 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
             for (int e = lane; e < K::SL; e += 64) {
                 const int g = ts - NA + e;
                 T x = T(0);
-                if (g < ts) x = se[e];
+                if (g < ts) x = st_left ? se[e] : row[g];
                 else if (g < tend) x = row[g];
-                else if (g < tend + NA) x = se[NA + (g - tend)];
+                else if (g < tend + NA) x = st_right ? se[NA + (g - tend)] : row[g];
                 *reinterpret_cast<T *>(slab + slab_vec_off<VPL>(e / E) + (e % E) * (int)sizeof(T)) = x;
             }
         }
@@ -488,6 +501,17 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
     SG_STAMP(1);
     wave_lds_sync();
     SG_STAMP(2);
+    if (job.phase == 1u) {
+        // even phase: the first NA input samples of this body are the RIGHT halo of tile k - 1, the last NA the LEFT halo of tile k + 1 -- into
+        // their slots before this tile's results overwrite the rows (the slab holds them: vectors HV .. 2 HV - 1 and TV .. TV + HV - 1; positions
+        // past the channel's end hold the remapped values the staging put there, which is what the neighbour's window needs)
+        VT *slots = const_cast<VT *>(static_cast<const VT *>(job.stash));
+        if (lane < HV) {
+            if (k > 0u) slots[(size_t)(slot - 1u) * (2 * HV) + HV + lane] = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(HV + lane));
+        } else if (lane < 2 * HV) {
+            if (k + 1u < job.tpc_all) slots[(size_t)(slot + 1u) * (2 * HV) + (lane - HV)] = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(TV + lane - HV));
+        }
+    }
 
     // ---- the convolution: lane owns outputs [lane*R, lane*R + R) of the tile ----
     T acc[R];

@@ -77,12 +77,19 @@ struct Job1D {
     // 2c + 1 = trailing end; edges = the filter's [n][2n+1] edge table on the device, NULL = none
     unsigned    edge_items;
     const float *edges;
-    // IN PLACE (out == in, round 5): no tile may read what a neighbour has already overwritten, so the NA samples on either side of every
-    // tile's body -- already remapped / zero-filled per boundary mode -- are taken from `stash` (tile t: [left NA | right NA], filled by
-    // sg1d_launch_stash before the tiles run), and the edge items read the 2n+1 samples of their channel end from `edge_stash`
-    // ([channel][end][2n+1]).  NULL = out of place: halos and edge samples come from the rows themselves.
+    // IN PLACE (out == in; round 6: two colour phases, no stash pass).  No tile may read what a neighbour has already overwritten.  `stash` holds one
+    // slot per tile of the launch group, [left NA | right NA] = the NA samples either side of the tile's body as they were before anybody stored.
+    //   phase 1: the EVEN tiles of every channel.  Their neighbours' bodies are untouched, so their halos are read LIVE from the rows; only a halo that
+    //            reaches past a channel end (tile 0's left, the last tile's right, and the right of the tile before a last tile shorter than NA) comes
+    //            from the stash, where sg1d_launch_ends put it -- remapped per boundary mode -- before the phase.  Before storing, an even tile writes
+    //            the first and last NA input samples of its own body into its odd neighbours' slots.
+    //   phase 2: the ODD tiles: body live, both halos from their slot.
+    // tiles_per_channel / tpc_magic / total_tiles count the tiles of the PHASE; tpc_all = tiles of a whole channel (the slot pitch).  phase 0 with a
+    // stash = every tile takes both halos from its slot (round 5's form: a full stash pass first).  The edge items read the 2n+1 samples of their
+    // channel end from `edge_stash` ([channel][end][2n+1]).  NULL = out of place: halos and edge samples come from the rows themselves.
     const void *stash;
     const void *edge_stash;
+    unsigned    phase, tpc_all;
     // tile order (sg1d_tile_body): 0 = each XCD sweeps one contiguous eighth of the tiles; s in 1..31 = chunks of 2^s blocks dealt to the XCDs round
     // robin (the eight fronts stay within 8 * 2^s blocks of each other); >= 32 = launch order.  SAVGOL_HIP_1D_XCD_CHUNK_LOG2, tools/placement_1d.py
     unsigned    xcd_chunk_log2;
@@ -210,9 +217,10 @@ int sg1d_launch_f64_moment_t3(int n, const sg::Job1D *job, const double *d_table
 int sg1d_launch_f64_moment_t5(int n, const sg::Job1D *job, const double *d_table, unsigned grid, void *stream);
 int sg1d_launch_f64_moment_t7(int n, const sg::Job1D *job, const double *d_table, unsigned grid, void *stream);
 
-// fills Job1D::stash / edge_stash for an in-place call (elem_bytes 4 / 8; tile width TW and rounded halo NA as the tile kernel will use them)
-int sg1d_launch_stash(const void *in, long long in_ld, unsigned length, unsigned tiles_per_channel, unsigned total_tiles, int TW, int NA, int mode,
-                      void *stash, void *edge_stash, int ws, size_t channels, int elem_bytes, void *stream);
+// in place, before the two phases: the halos that reach past a channel end (slot(c, 0).left, slot(c, T-1).right, and slot(c, T-2).right when the
+// last tile is shorter than NA), remapped per boundary mode, and the edge rows' samples -- a few hundred samples per channel
+int sg1d_launch_ends(const void *in, long long in_ld, unsigned length, unsigned tiles_per_channel, int TW, int NA, int mode, void *stash, void *edge_stash,
+                     int ws, size_t channels, int elem_bytes, void *stream);
 int sg1d_launch_reference_order_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
                                     const float *d_table, float dt_inv, int mode, int store_lo, int store_hi, int out_shift,
                                     int negate_leading, size_t channels, void *stream);

@@ -552,106 +552,59 @@ int sg_launch_scatter_f32(const float *src, size_t src_ld, void *base, size_t st
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// ---- in-place batch calls (round 5): what every tile will need from OUTSIDE its own body, captured before any tile stores ----
+// ---- in-place batch calls: what the tiles at a channel's ends need from beyond it (and the edge rows' samples), captured before any tile stores ----
 }  // extern "C"
 namespace sg {
+// Round 6 (in place in two colour phases): only the halos that reach past a channel's end need a pass of their own -- slot(c, 0).left,
+// slot(c, T-1).right and, when the last tile holds fewer than NA samples, slot(c, T-2).right -- plus the edge rows' samples: 3 NA + 2 ws samples
+// per channel, whatever its length.  Everything else the even tiles hand to their odd neighbours while they run (Job1D::phase).
 template <typename T>
-__global__ __launch_bounds__(256) void sg1d_stash_kernel(const T *__restrict__ in, long long in_ld, int L, unsigned tiles_per_channel, unsigned total_tiles, int TW,
-                                                         int NA, int mode, T *__restrict__ stash, T *__restrict__ edge_stash, int ws, size_t channels)
+__global__ __launch_bounds__(256) void sg1d_ends_kernel(const T *__restrict__ in, long long in_ld, int L, unsigned tiles_per_channel, int TW, int NA, int mode,
+                                                        T *__restrict__ stash, T *__restrict__ edge_stash, int ws, size_t channels)
 {
-    const size_t halo_items = (size_t)total_tiles * (size_t)(2 * NA);
-    const size_t edge_items = edge_stash ? channels * 2 * (size_t)ws : 0;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < halo_items + edge_items; idx += (size_t)gridDim.x * 256) {
-        if (idx < halo_items) {
-            const unsigned tile = (unsigned)(idx / (size_t)(2 * NA));
-            const int j = (int)(idx % (size_t)(2 * NA));
-            const unsigned c = tile / tiles_per_channel;
-            const int ts = (int)(tile - c * tiles_per_channel) * TW;
-            const int tend = ts + TW < L ? ts + TW : L;
-            int g = j < NA ? ts - NA + j : tend + (j - NA);
-            const T *row = in + (long long)c * in_ld;
+    const size_t per_ch = (size_t)(3 * NA) + (edge_stash ? 2 * (size_t)ws : 0);
+    const unsigned Tn = tiles_per_channel;
+    const int last_ts = (int)(Tn - 1u) * TW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < channels * per_ch; idx += (size_t)gridDim.x * 256) {
+        const size_t c = idx / per_ch;
+        const int j = (int)(idx - c * per_ch);
+        const T *row = in + (long long)c * in_ld;
+        T *slots = stash + c * (size_t)Tn * (size_t)(2 * NA);
+        if (j < 3 * NA) {
+            int g;
+            T *dst;
+            if (j < NA) { g = j - NA; dst = slots + j; }                                                              // slot(c, 0).left
+            else if (j < 2 * NA) { g = L + (j - NA); dst = slots + (size_t)(Tn - 1u) * (size_t)(2 * NA) + NA + (j - NA); }   // slot(c, T-1).right
+            else {
+                if (Tn < 2u || L - last_ts >= NA) continue;                                                            // slot(c, T-2).right: only before a short last tile
+                g = last_ts + (j - 2 * NA); dst = slots + (size_t)(Tn - 2u) * (size_t)(2 * NA) + NA + (j - 2 * NA);
+            }
             bool zero = false;
             if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
-            stash[idx] = zero ? T(0) : row[g];
+            *dst = zero ? T(0) : row[g];
         } else {
-            const size_t k = idx - halo_items;
-            const size_t c = k / (2 * (size_t)ws);
-            const int r = (int)(k % (2 * (size_t)ws));
+            const int r = j - 3 * NA;
             const int g = r < ws ? r : L - ws + (r - ws);                              // leading end: samples 0..2n, trailing end: L-ws..L-1
-            edge_stash[k] = in[(long long)c * in_ld + g];
-        }
-    }
-}
-// The same stash, a 16-byte VECTOR per thread (round 5: the scalar kernel above spent 1.5 ms on a 1024 x 2^22 fp64 chunk -- a 64-bit division and an
-// 8-byte load / store per sample).  Thread t of a block serves vector t % VP2 of tile blockIdx * (256 / VP2) + t / VP2 (VP2 = vectors per tile
-// rounded up to a power of two: shifts and masks only).  A vector that lies inside its channel and starts on a vector boundary moves as one load /
-// store; the ones at a channel's ends (remapped or zero-filled samples, a last tile that ends off a boundary) go sample by sample.
-template <typename T>
-__global__ __launch_bounds__(256) void sg1d_stash_vec_kernel(const T *__restrict__ in, long long in_ld, int L, unsigned tiles_per_channel, unsigned tpc_magic, unsigned tpc_shift,
-                                                             unsigned total_tiles, int TW, int NA, int mode, T *__restrict__ stash, int vp2_log2)
-{
-    constexpr int E = 16 / (int)sizeof(T);
-    typedef T VT __attribute__((ext_vector_type(E)));
-    const unsigned vps = (unsigned)(NA / E), vpt = 2u * vps;
-    const unsigned t = threadIdx.x, j = t & ((1u << vp2_log2) - 1u);
-    const unsigned tile = blockIdx.x * (256u >> vp2_log2) + (t >> vp2_log2);
-    if (tile >= total_tiles || j >= vpt) return;
-    const unsigned c = tpc_shift >= 32 ? tile : (__umulhi(tile, tpc_magic) >> tpc_shift);
-    const int ts = (int)(tile - c * tiles_per_channel) * TW;
-    const int tend = ts + TW < L ? ts + TW : L;
-    const int g0 = j < vps ? ts - NA + (int)j * E : tend + (int)(j - vps) * E;
-    const T *row = in + (long long)c * in_ld;
-    T *dst = stash + (size_t)tile * (size_t)(2 * NA) + (size_t)j * E;
-    if (g0 >= 0 && g0 + E <= L && (g0 % E) == 0) {
-        *reinterpret_cast<VT *>(dst) = *reinterpret_cast<const VT *>(row + g0);
-    } else {
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            int g = g0 + e;
-            bool zero = false;
-            if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
-            dst[e] = zero ? T(0) : row[g];
+            edge_stash[c * 2 * (size_t)ws + r] = row[g];
         }
     }
 }
 }  // namespace sg
 extern "C" {
-int sg1d_launch_stash(const void *in, long long in_ld, unsigned length, unsigned tiles_per_channel, unsigned total_tiles, int TW, int NA, int mode,
-                      void *stash, void *edge_stash, int ws, size_t channels, int elem_bytes, void *stream)
+int sg1d_launch_ends(const void *in, long long in_ld, unsigned length, unsigned tiles_per_channel, int TW, int NA, int mode, void *stash, void *edge_stash,
+                     int ws, size_t channels, int elem_bytes, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // vector form for the halos where the rows are 16-byte aligned (every call the tile kernels run with vector loads); the scalar kernel then
-    // only fills the edge rows' samples
-    const int E = 16 / elem_bytes;
-    const unsigned vpt = (unsigned)(2 * NA / E);
-    if (total_tiles && NA % E == 0 && vpt >= 1 && vpt <= 256 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && (in_ld * elem_bytes) % 16 == 0 &&
-        (reinterpret_cast<uintptr_t>(stash) & 15u) == 0) {
-        int lg = 0;
-        while ((1u << lg) < vpt) ++lg;
-        const unsigned tiles_per_block = 256u >> lg;
-        const unsigned grid = (total_tiles + tiles_per_block - 1) / tiles_per_block;
-        unsigned magic = 0, shift = 32;
-        sg::division_magic(tiles_per_channel, &magic, &shift);
-        if (elem_bytes == 4)
-            hipLaunchKernelGGL(sg::sg1d_stash_vec_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float *>(in), in_ld, (int)length, tiles_per_channel, magic, shift,
-                               total_tiles, TW, NA, mode, static_cast<float *>(stash), lg);
-        else
-            hipLaunchKernelGGL(sg::sg1d_stash_vec_kernel<double>, dim3(grid), dim3(256), 0, st, static_cast<const double *>(in), in_ld, (int)length, tiles_per_channel, magic, shift,
-                               total_tiles, TW, NA, mode, static_cast<double *>(stash), lg);
-        if (hipGetLastError() != hipSuccess) return -1;
-        if (!edge_stash) return 0;
-        total_tiles = 0;                                                 // the scalar kernel below: edge samples only
-    }
-    const size_t items = (size_t)total_tiles * (size_t)(2 * NA) + (edge_stash ? channels * 2 * (size_t)ws : 0);
+    const size_t items = channels * ((size_t)(3 * NA) + (edge_stash ? 2 * (size_t)ws : 0));
     if (items == 0) return 0;
     size_t blocks = (items + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
+    if (blocks > 65535) blocks = 65535;
     if (elem_bytes == 4)
-        hipLaunchKernelGGL(sg::sg1d_stash_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float *>(in), in_ld, (int)length, tiles_per_channel,
-                           total_tiles, TW, NA, mode, static_cast<float *>(stash), static_cast<float *>(edge_stash), ws, channels);
+        hipLaunchKernelGGL(sg::sg1d_ends_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float *>(in), in_ld, (int)length, tiles_per_channel, TW, NA,
+                           mode, static_cast<float *>(stash), static_cast<float *>(edge_stash), ws, channels);
     else
-        hipLaunchKernelGGL(sg::sg1d_stash_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const double *>(in), in_ld, (int)length, tiles_per_channel,
-                           total_tiles, TW, NA, mode, static_cast<double *>(stash), static_cast<double *>(edge_stash), ws, channels);
+        hipLaunchKernelGGL(sg::sg1d_ends_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const double *>(in), in_ld, (int)length, tiles_per_channel, TW, NA,
+                           mode, static_cast<double *>(stash), static_cast<double *>(edge_stash), ws, channels);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -17,6 +17,7 @@
 // only for the samples and the outputs.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <immintrin.h>
 
@@ -674,7 +675,10 @@ int savgol_streambank_push(SavgolStreamBank *bank, const float *d_samples, float
 int savgol_streambank_push_wait(SavgolStreamBank *bank, const float *d_samples, float *d_out, void *stream)
 {
     const char *who = "savgol_streambank_push_wait";
-    if (!bank) { sg_set_error("%s: NULL pointer", who); return -1; }
+    if (!bank || !d_samples || !d_out) { sg_set_error("%s: NULL pointer", who); return -1; }
+    // arguments and device first, THEN the lazy allocation: a first call from the wrong device used to leave the counter on that device for
+    // good, and later calls from the right one then added to a foreign-device pointer
+    if (!sg::bank_on_current_device(bank, who)) return -1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bank->signal_state == 0) {
         void *host = nullptr, *dev = nullptr, *counter = nullptr;
@@ -714,6 +718,10 @@ int savgol_streambank_push_wait(SavgolStreamBank *bank, const float *d_samples, 
             return ok && *bank->signal == seq ? rc : -1;
         }
     }
+    // The flag was written after every block's write-through output stores had drained (tick_signal: vmcnt(0) per wave, the block's barrier, the
+    // ticket) -- the `sc0 sc1` store + drained-flag hand-off of /opt/skills/guides/MI355X_MICROARCH.md ("Valid forms"), measured on gfx950, not a
+    // guarantee of the HIP memory model.  On the host side the acquire below keeps the caller's reads of d_out behind the spin's last load.
+    std::atomic_thread_fence(std::memory_order_acquire);
     return rc;
 }
 

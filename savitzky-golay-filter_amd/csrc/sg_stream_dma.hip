@@ -272,13 +272,13 @@ __global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job
     // Step g consumes pair g (already in xa, xb), after it has waited for pair g + 1 and issued its LDS reads (their latency hides behind
     // the arithmetic), and ends by issuing DMA g + DP into the ring slot pair g has just left.  A row without an output still issues its
     // store (into an empty descriptor), so the queue arithmetic above is static.
-    wait_vm<Q::younger(0, 0)>();
+    wait_vm<(Q::younger(0, 0) > 63 ? 63 : Q::younger(0, 0))>();           // (a smaller count only waits longer: the counter has 6 bits)
     f32x2 xa = row_in(std::integral_constant<int, 0>{}), xb = row_in(std::integral_constant<int, 1>{});
     static_for<NI>([&](auto gc) -> bool {
         constexpr int g = decltype(gc)::value;
         f32x2 na = xa, nb = xb;
         if constexpr (g + 1 < NI) {
-            wait_vm<Q::younger(g + 1, g)>();
+            wait_vm<(Q::younger(g + 1, g) > 63 ? 63 : Q::younger(g + 1, g))>();
             na = row_in(std::integral_constant<int, 2 * g + 2>{});
             nb = row_in(std::integral_constant<int, 2 * g + 3>{});
             __builtin_amdgcn_sched_barrier(0);                                                    // keep these reads AHEAD of pair g's arithmetic (left alone, hipcc sinks them to their use)
@@ -323,12 +323,14 @@ template <int N, bool FMA, int TRT, int WPB, int DPR, int FCH = 2>
     constexpr int DP = DPR < D::NI ? DPR : D::NI;                                                 // ring of row pairs (all of the tile's pairs: every load up front)
     constexpr size_t lds = (size_t)WPB * DP * 1024;
     static_assert(lds <= 160 * 1024, "slabs of one block must fit the CU's LDS");
-    static const bool attr_ok = [] {
-        return lds <= 65536 || hipFuncSetAttribute(reinterpret_cast<const void *>(sg_bank_dma_kernel<N, FMA, TRT, WPB, DP, FCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-    }();
-    if (!attr_ok) return 1;
+    // more than 64 KiB of dynamic LDS needs the attribute, and the attribute belongs to the (function, DEVICE) pair: set per launch -- a process-wide
+    // static applied it on whichever device launched first only (a block push is >= 0.1 ms, the call is host-side bookkeeping)
+    if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void *>(sg_bank_dma_kernel<N, FMA, TRT, WPB, DP, FCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+    }
     hipLaunchKernelGGL((sg_bank_dma_kernel<N, FMA, TRT, WPB, DP, FCH>), dim3(grid), dim3(64 * WPB), lds, st, job, taps, geo);
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : 1;                                              // a refused launch = not covered: the caller falls back to the walk
 }
 
 #ifndef SG_DMA_MOM_BUILD
@@ -399,6 +401,9 @@ int SG_DMA_FN(int n, int fma, const float *center, const BankJob &job, int /*cu_
 #define SG_DMA_MOM_WPB 8                                     // (waves per block, ring pairs) of the block-moment tiles: with a third of the arithmetic gone the tiles
 #define SG_DMA_MOM_PAIRS 16                                  // want FEWER resident waves with deeper rings -- 8 waves per CU, 16 KiB in flight each (R5.9)
 #endif
+#ifndef SG_DMA_MOM_TR
+#define SG_DMA_MOM_TR SG_DMA_TR                              // output ticks per block-moment tile
+#endif
 
 template <int N, int M, int TRT, int WPB, int DPR>
 static int launch_bank_dma_mom(const StreamMomentFit &fit, const float *center, BankJob job, hipStream_t st)
@@ -440,25 +445,28 @@ static int launch_bank_dma_mom(const StreamMomentFit &fit, const float *center, 
     constexpr size_t lds = (size_t)WPB * DP * 1024;
     static_assert(lds <= 160 * 1024, "slabs of one block must fit the CU's LDS");
     auto kernel = sg_bank_dma_kernel<N, true, TRT, WPB, DP, 1, M, MomTaps<N, M>>;
-    static const bool attr_ok = [&] {
-        return lds <= 65536 || hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-    }();
-    if (!attr_ok) return 1;
+    if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {     // per launch: see launch_bank_dma
+        (void)hipGetLastError();
+        return 1;
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * WPB), lds, st, job, taps, geo);
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 template <int N, int M>
 static int launch_bank_dma_mom_shape(const StreamMomentFit &fit, const float *center, const BankJob &job, hipStream_t st)
 {
 #ifdef SG_DMA_EXPERIMENT        // A/B build: waves per block and ring depth picked per process
+    static const int tr = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_TR"); return e ? atoi(e) : SG_DMA_MOM_TR; }();
     static const int wpb = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_WPB"); return e ? atoi(e) : SG_DMA_MOM_WPB; }();
     static const int dp = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_PAIRS"); return e ? atoi(e) : SG_DMA_MOM_PAIRS; }();
-#define SG_DMA_TRY(W, P) if (wpb == W && dp == P) return launch_bank_dma_mom<N, M, SG_DMA_TR, W, P>(fit, center, job, st);
-    SG_DMA_TRY(4, 12) SG_DMA_TRY(4, 16) SG_DMA_TRY(4, 24) SG_DMA_TRY(8, 8) SG_DMA_TRY(8, 12) SG_DMA_TRY(8, 16) SG_DMA_TRY(8, 20) SG_DMA_TRY(16, 8) SG_DMA_TRY(2, 32)
+#define SG_DMA_TRY(T, W, P) if (tr == T && wpb == W && dp == P) return launch_bank_dma_mom<N, M, T, W, P>(fit, center, job, st);
+    SG_DMA_TRY(32, 8, 16) SG_DMA_TRY(32, 8, 12) SG_DMA_TRY(32, 4, 16)
+    SG_DMA_TRY(48, 8, 16) SG_DMA_TRY(64, 8, 16) SG_DMA_TRY(64, 8, 12) SG_DMA_TRY(64, 8, 20) SG_DMA_TRY(64, 4, 16) SG_DMA_TRY(64, 4, 24) SG_DMA_TRY(64, 4, 32)
+    SG_DMA_TRY(96, 8, 16) SG_DMA_TRY(128, 8, 16) SG_DMA_TRY(128, 4, 24)
 #undef SG_DMA_TRY
 #endif
-    return launch_bank_dma_mom<N, M, SG_DMA_TR, SG_DMA_MOM_WPB, SG_DMA_MOM_PAIRS>(fit, center, job, st);
+    return launch_bank_dma_mom<N, M, SG_DMA_MOM_TR, SG_DMA_MOM_WPB, SG_DMA_MOM_PAIRS>(fit, center, job, st);
 }
 
 #ifndef SG_DMA_MOM_MIN_N

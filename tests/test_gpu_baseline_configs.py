@@ -168,7 +168,7 @@ def test_config5_full_slice_in_chunks(sg, sgo, torch_gpu):
     one chunk-sized output).  Oracle on channels of the first and the last chunk (1e-12), linearity on the last chunk."""
     torch = torch_gpu
     channels, chunk, length = 4096, 1024, 1 << 22
-    _need_hbm(torch, 3 * chunk * length * 8)
+    _need_hbm(torch, 4 * chunk * length * 8)
     f = sg.Filter(32, 4, 2, 1.0, 0)
     of = sgo.Filter(32, 4, 2, 1.0, 0)
     x = torch.empty((chunk, length), dtype=torch.float64, device="cuda")
@@ -184,8 +184,22 @@ def test_config5_full_slice_in_chunks(sg, sgo, torch_gpu):
             sample = [0, 1, chunk // 2, chunk - 1]
             ref = of.apply_f64(x[sample].cpu().numpy())
             assert normwise(y[sample].cpu().numpy(), ref) < 1e-12, c0
+            # round 6: the same chunk through savgol_apply_batch_f64_tol with the bar the config states -- what bench.py's
+            # config-5 figure times: another kernel (different bits), inside 1e-6; a tolerance below that keeps the 1e-12 path (same bits)
+            z = torch.full_like(y, float("nan"))
+            f.apply_batch(x, z, chunk, length, dtype="f64", rel_tol=1e-6)
+            torch.cuda.synchronize()
+            assert not torch.isnan(z).any() and not torch.equal(z, y)
+            e = normwise(z[sample].cpu().numpy(), ref)
+            assert 1e-13 < e < 1e-6, (c0, e)
+            f.apply_batch(x, z, chunk, length, dtype="f64", rel_tol=1e-9)
+            torch.cuda.synchronize()
+            assert torch.equal(z, y)
+            del z
             checked += 1
     assert checked == 2
+    with pytest.raises(RuntimeError, match="rel_tol"):
+        f.apply_batch(x, y, chunk, length, dtype="f64", rel_tol=float("nan"))
     t = torch.arange(length, dtype=torch.float64, device="cuda")
     ft = f.apply_tensor(t.view(1, -1).contiguous())
     z = torch.empty_like(y)

@@ -558,28 +558,52 @@ def test_randomized_fused_bank_block_sequences(sg, sgo, torch_gpu):
 
 
 def test_push_wait_returns_complete_outputs(sg, sgo, torch_gpu):
-    """savgol_streambank_push_wait (round 5): one tick whose outputs are complete on return -- the stream writes a completion word behind the
-    tick kernel and the host spins on it, no hipStreamSynchronize.  Same values, bit for bit, as savgol_streambank_push + synchronise on a twin
-    bank (the reference's savgol_stream_push arithmetic, src/savgol_stream.c:152-178), through the filling phase, on the default and on another
-    stream, and read back WITHOUT any synchronise in between."""
+    """savgol_streambank_push_wait (round 5): one tick whose outputs are complete on return -- the tick kernel's last block writes a completion word
+    into pinned host memory and the host spins on it, no hipStreamSynchronize.  Same values, bit for bit, as savgol_streambank_push + synchronise on
+    a twin bank (the reference's savgol_stream_push arithmetic, src/savgol_stream.c:152-178), through the filling phase, on the default and on another
+    stream.  Round 6: the property push_wait ADDS is exercised -- the outputs are read right after the call returns with NO device
+    synchronise in between: (a) d_out in mapped pinned host memory, read by the CPU at once; (b) a non-blocking device-to-host copy on a stream that
+    has no dependency on the tick's stream.  A bank whose stream count is not a multiple of 64 takes the push + synchronise fallback: same values."""
+    import ctypes as C
     torch = torch_gpu
-    S, n = 4096, 8
-    a, b = sg.StreamBank(S, n, 3, 0, 1.0), sg.StreamBank(S, n, 3, 0, 1.0)
-    x = torch.randn((60, S), device="cuda")
-    oa = torch.zeros(S, device="cuda"); ob = torch.zeros(S, device="cuda")
-    pinned = torch.zeros(S).pin_memory()
-    side = torch.cuda.Stream()
-    for t in range(60):
-        st = side if t % 2 else None
-        if st is not None:
-            side.wait_stream(torch.cuda.current_stream())
-        ra = a.push_wait(x[t], oa, stream=st)
-        rb = b.push(x[t], ob)
+    hip = C.CDLL("libamdhip64.so")
+    for S, n in ((4096, 8), (4000, 8)):                    # 4000 streams: not whole waves at the barrier -> the fallback path
+        a, b = sg.StreamBank(S, n, 3, 0, 1.0), sg.StreamBank(S, n, 3, 0, 1.0)
+        x = torch.randn((60, S), device="cuda")
+        # the twin's outputs first, fully synchronised: what every tick must produce
+        want = []
+        ob = torch.zeros(S, device="cuda")
+        for t in range(60):
+            rb = b.push(x[t], ob)
+            torch.cuda.synchronize()
+            want.append((rb, ob.cpu().numpy().copy()))
+        host = torch.zeros(S).pin_memory()                 # (a) the kernel writes straight into host memory
+        dev_view = C.c_void_p()
+        mapped = hip.hipHostGetDevicePointer(C.byref(dev_view), C.c_void_p(host.data_ptr()), 0) == 0 and dev_view.value
+        oa = torch.zeros(S, device="cuda")
+        landing = torch.zeros(S).pin_memory()              # (b) target of the unordered copy
+        side, copier = torch.cuda.Stream(), torch.cuda.Stream()
         torch.cuda.synchronize()
-        assert ra == rb == (1 if t >= 2 * n else 0)
-        if ra:
-            assert torch.equal(oa, ob), t
-    assert a.counters[0] == 60 and a.counters[1] == 60 - 2 * n
+        for t in range(60):
+            st = side if t % 2 else None
+            use_host = bool(mapped) and t % 3 == 0
+            if use_host:
+                host.fill_(-1.0)
+            ra = a.push_wait(x[t], dev_view.value if use_host else oa, stream=st)
+            # NO torch.cuda.synchronize() here: the call itself promised the outputs
+            if use_host:
+                got = host.numpy().copy()
+            else:
+                with torch.cuda.stream(copier):             # no wait_stream: nothing orders this copy behind the tick but push_wait's return
+                    landing.copy_(oa, non_blocking=True)
+                copier.synchronize()
+                got = landing.numpy().copy()
+            rb, exp = want[t]
+            assert ra == rb == (1 if t >= 2 * n else 0)
+            if ra:
+                assert same_bits(got, exp), (S, t, use_host)
+        assert a.counters[0] == 60 and a.counters[1] == 60 - 2 * n
+        torch.cuda.synchronize()
 
 
 def test_few_streams_long_block_uses_enough_bands(sg, sgo, torch_gpu):
