@@ -468,6 +468,29 @@ def bench_stream(sg, a):
                                        "kernel": STREAM_KERNEL_REF,
                                        "note": "savgol_streambank_create: multiply and add rounded separately, bit-identical to the reference's savgol_stream_push"},
     }
+    # PLACEMENT SPREAD: the same two launches on fresh pairs of buffers inside this process, the timed pair kept alive so that new
+    # physical pages back the new ones -- the block push is 0.36-0.42 ms for ONE kernel depending on where its two 1 GiB buffers sit (R5.9)
+    try:
+        fr_f, fr_r = [], []
+        keep = []
+        for _ in range(3):
+            free, _tot = torch.cuda.mem_get_info()
+            if free < 3 * x.numel() * 4:
+                break
+            x2 = torch.empty_like(x); y2 = torch.empty_like(out)
+            x2.copy_(x)
+            keep += [x2, y2]
+            bank2.push_block(x2, T, y2); bank2r.push_block(x2, T, y2); torch.cuda.synchronize()           # first touch of a fresh pair is slower whatever runs
+            t_f = timed(lambda: bank2.push_block(x2, T, y2), reps=5, warm=1)
+            t_r = timed(lambda: bank2r.push_block(x2, T, y2), reps=5, warm=1)
+            fr_f.append(round(8.0 * samples / (t_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            fr_r.append(round(8.0 * samples / (t_r * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        del keep
+        if fr_f:
+            res["block_push"]["roofline"]["placement_spread"] = {"fresh_pairs": len(fr_f), "frac_of_each": fr_f, "frac_min": min(fr_f), "frac_max": max(fr_f)}
+            res["block_push_reference_order"]["placement_spread"] = {"fresh_pairs": len(fr_r), "frac_of_each": fr_r, "frac_min": min(fr_r), "frac_max": max(fr_r)}
+    except Exception as e:                                               # noqa: BLE001 -- diagnostic only
+        res["block_push"]["roofline"]["placement_spread"] = {"error": f"{type(e).__name__}: {e}"}
     if not a.no_cpu:
         # parity of what was just timed, on four streams: the reference's own stream arithmetic (one chain, product and sum rounded: the oracle's
         # push loop, pinned bit for bit to the compiled reference) and the double-accumulation oracle
@@ -858,11 +881,30 @@ class Run:
             step(events)
         self.barrier()
         el = time.perf_counter() - t0
+        self.per_rank = None
         if self.dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+            dev = self.dev if self.backend == "nccl" else "cpu"
+            # every rank's own wall time per step and mean launch duration (its HIP events), gathered: a SCALE line can then be read against the N = 1 line
+            # rank by rank (VERDICT r05 next #9b) -- the job's figure stays the MAX over ranks
+            launch = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else 0.0
+            mine = torch.tensor([el / self.args.steps * 1e3, launch], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(allr, mine)
+            self.per_rank = {"ms_per_step": [round(float(v[0]), 4) for v in allr], "avg_launch_ms": [round(float(v[1]), 4) for v in allr]}
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             el = t.item()
         return el, events
+
+    def per_rank_fields(self, alg_bytes_per_launch):
+        """N > 1: per-rank timings and each rank's own roofline fraction (the N = 1 line's `roofline.frac`, rank by rank), the communicator's size"""
+        if self.per_rank is None:
+            return {}
+        ms = self.per_rank["ms_per_step"]
+        fr = [round(alg_bytes_per_launch / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v > 0 else None for v in self.per_rank["avg_launch_ms"]]
+        return {"per_rank": {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "ms_per_step_each": ms, "avg_launch_ms_each": self.per_rank["avg_launch_ms"],
+                             "roofline_frac_each": fr},
+                "backend": self.backend, "rccl_ranks": self.dist.get_world_size() if self.backend == "nccl" else None}
 
     def agree(self, ok):
         """every rank learns whether EVERY rank is fine (MIN all-reduce): a rank must never leave the others inside a collective"""
@@ -928,6 +970,7 @@ def run_stream(r):
                "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": "f32",
                "config": {"workload": f"BASELINE config 3: {S} streams per GPU x {T} ticks per step, n=16, m=2, d=1, dt=1e-3", "sharding": "streams, no collective"},
                "roofline": add_ceiling(with_traffic(roofline(8.0 * S * T, ms, lms, kernel=STREAM_KERNEL_FMA), "r*_stream_block_pmc_summary.json", SOURCES_STREAM), ceil)}
+        out.update(r.per_rank_fields(8.0 * S * T))
         if r.world == 1 and not args.no_extra:
             out["latency"] = bench_stream(sg, args)
             if "cpu_baseline" in out["latency"]:
@@ -1042,6 +1085,11 @@ def run_image(r):
                "roofline": add_ceiling(roofline(8.0 * per_launch_pix, ms, lms, kernel=IMAGE_KERNEL if args.method == 2 else "sg2d_dense_roll_kernel<7>"), ceil)}
         if args.method == 2 and not args.rowband:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(8.0 * per_launch_pix, "r*_2d_config4_pmc_summary.json", SOURCES_2D)
+        pr = r.per_rank_fields(8.0 * per_launch_pix)
+        if pr:
+            if args.rowband:
+                pr.pop("rccl_ranks", None)                  # the row-band line reports the exchange's own communicator (extra_top)
+            out.update(pr)
         if r.world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_reference("image")
         emit(out)
@@ -1080,6 +1128,7 @@ def run_config5(r):
                           "channels_per_gpu": resident, "length": length, "sharding": "channels, no collective"},
                "roofline": add_ceiling(with_traffic(roofline(16.0 * chunk * length, ms, lms, kernel="sg1d_center_kernel<double,32>" if exact else "sg1d_center_moment64_kernel<32,5>"),
                                                     "r*_1d_f64_n32_pmc_summary.json" if exact else "r*_1d_f64m_n32_pmc_summary.json"), ceil)}
+        out.update(r.per_rank_fields(16.0 * chunk * length))
         out["config"]["call"] = "savgol_apply_batch_f64_ex(flags=0): 1e-12 of the fp64 oracle" if exact else f"savgol_apply_batch_f64_tol(rel_tol={C5_TOL:g}): the bar the config states"
         if r.world == 1 and not args.no_cpu:
             from oracle import sgo
@@ -1123,10 +1172,16 @@ def run_headline(r):
     """BASELINE config 2, the headline: 4096 channels x 2^20 fp32 per GPU, n=32, m=4, one launch per boundary mode per step"""
     args, sg, dev = r.args, r.sg, r.dev
     ch, length = args.channels, args.length
+    ch0 = r.rank * ch
+    if args.total_channels:
+        # a FIXED channel count split over the ranks (strong scaling; uneven when it does not divide: savgol_hip_shard_range gives the first
+        # total % world ranks one channel more) -- the plumbing check for ragged shards (tools/check_multirank_plumbing.sh)
+        ch0, hi = sg.shard_range(args.total_channels, r.world, r.rank)
+        ch = hi - ch0
     modes = [0, 1, 2, 3]
     x = torch.empty((ch, length), dtype=torch.float32, device=dev)
     y = torch.empty_like(x)
-    sg.synth(x, channel0=r.rank * ch)                       # generated in HBM, never crosses PCIe
+    sg.synth(x, channel0=ch0)                               # generated in HBM, never crosses PCIe
     filters = [sg.Filter(N, M, D, 1.0, mode) for mode in modes]
     torch.cuda.synchronize()
     ceil = copy_ceiling(sg, x, y)                           # the same two buffers, the same process, before the timed region
@@ -1143,12 +1198,11 @@ def run_headline(r):
         launches_ms = [a.elapsed_time(b) for a, b in events]
         avg_ms = float(np.mean(launches_ms))
         alg_bytes = 8.0 * ch * length                        # 4 B read + 4 B written per sample
-        samples = float(len(modes)) * ch * length * args.steps * r.world
+        samples = float(len(modes)) * (args.total_channels if args.total_channels else ch * r.world) * length * args.steps
         import ctypes as C
         tab = (C.c_float * 400)()
-        half = os.environ.get("SAVGOL_HIP_MOMENT_FORM") != "32"              # round 5's half-lane form unless the A/B switch asks for round 2's
-        terms = (sg.lib().savgol_hip_momenth_table if half else sg.lib().savgol_hip_moment_table)(filters[0].ptr, tab)
-        kernel = (f"sg1d_center_momenth_kernel<{N},{terms}>" if half else f"sg1d_center_moment_kernel<{N},{terms}>") if terms > 0 else f"sg1d_center_kernel<float,{N}>"
+        terms = sg.lib().savgol_hip_momenth_table(filters[0].ptr, tab)
+        kernel = f"sg1d_center_momenth_kernel<{N},{terms}>" if terms > 0 else f"sg1d_center_kernel<float,{N}>"
         traffic, traffic_src = pmc_traffic(alg_bytes)
         out = {
             "metric": "Msamples/s filtered (1D batch, hw=32, poly=4) + % HBM roofline",
@@ -1157,12 +1211,16 @@ def run_headline(r):
             "config": {"workload": f"BASELINE config 2: {ch} channels x {length} fp32 samples per GPU, half_window={N}, "
                                    f"poly_order={M}, derivative={D}, one pass per boundary mode "
                                    "(POLYNOMIAL, REFLECT, PERIODIC, CONSTANT) per step",
-                       "channels_per_gpu": ch, "length": length, "sharding": "channels, no collective"},
+                       "channels_per_gpu": ch, "length": length, "sharding": "channels, no collective",
+                       **({"total_channels": args.total_channels, "split": "savgol_hip_shard_range (rank 0's share shown in channels_per_gpu)"} if args.total_channels else {})},
             "roofline": add_ceiling({**roofline(alg_bytes, avg_ms, launches_ms, kernel=kernel), "traffic": traffic, "traffic_source": traffic_src}, ceil),
             # where the two 16 GiB buffers landed: the same launch runs 5.2-5.75 ms depending on their physical placement
             # (DESIGN 4.1 "Run-to-run spread"); with the addresses a 0.75 run and a 0.83 run can be told apart
             "buffers": {"x": hex(x.data_ptr()), "y": hex(y.data_ptr()), "bytes_each": x.numel() * 4},
         }
+        out.update(r.per_rank_fields(alg_bytes))
+        if args.total_channels:
+            out["scaling"] = "strong"
         if r.world == 1 and not args.no_cpu:
             # CPU leg (rank 0, N=1 only): the reference timed on this host + parity spot checks of what was just timed
             # (last mode run = CONSTANT) against the CPU oracle and against the reference's own fp32 output -- the only place bench.py touches oracle/
@@ -1234,6 +1292,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
     ap.add_argument("--length", type=int, default=1 << 20)
+    ap.add_argument("--total-channels", type=int, default=0, help="batch1d: a fixed channel count split over the ranks by savgol_hip_shard_range (uneven shards when it "
+                                                                   "does not divide; scaling 'strong') instead of --channels per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs and the oracle spot checks")
     ap.add_argument("--no-extra", action="store_true", help="headline only: skip the configs 1/3/4/5 'extra' section")
     ap.add_argument("--workload", choices=["batch1d", "batch1d_f64", "stream", "image"], default="batch1d",

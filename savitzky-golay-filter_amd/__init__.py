@@ -107,7 +107,6 @@ SIGNATURES = {
     "savgol_hip_last_error": (C.c_char_p, []),
     "savgol_hip_version": (C.c_char_p, []),
     "savgol_hip_set_option": (C.c_int, [C.c_int, C.c_int]),
-    "savgol_hip_moment_table": (C.c_int, [_F, _fp]),
     "savgol_hip_momenth_table": (C.c_int, [_F, _fp]),
     "savgol_hip_stream_moment_table": (C.c_int, [C.c_int, _fp, _fp]),
     "savgol_export_header": (C.c_long, [_F, C.c_char_p, C.c_char_p, C.c_char_p, _sz]),

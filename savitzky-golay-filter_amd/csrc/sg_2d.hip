@@ -198,13 +198,6 @@ static const Savgol2DFilter *rect_filter_cached(const Savgol2DConfig *cfg, bool 
     return f;
 }
 
-// SAVGOL_HIP_DENSE_KERNEL=1 forces the one-pixel-per-lane dense kernel (diagnostics / A-B timing)
-static int dense_kernel_env()
-{
-    static const int v = [] { const char *e = getenv("SAVGOL_HIP_DENSE_KERNEL"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
 // The rolling kernel on one output, in one launch where its taps fit the scalar registers (4 terms up to n = 8, 3 up to n = 12, 2
 // beyond), else in TWO: the first half of the terms, then the rest with job.accumulate (out += ...).  The second pass re-reads the
 // input and read-modify-writes the output -- 20 B per pixel instead of 8 -- which these arithmetic-bound shapes can afford: order 6
@@ -290,9 +283,8 @@ static int roll_passes(int n, int terms, const Job2D &job, const float *factors,
         const int rc = roll_passes_hf(n, terms, job, factors, scale, images, cu_count, st);
         if (rc != 1) return rc;
     }
-    static const int split_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_SPLIT"); return e ? atoi(e) : 1; }();     // 0: A/B against the tile kernel
     int rc = sg2d_launch_rolling(n, terms, job, factors, scale, images, cu_count, st);
-    if (rc != 1 || n < 9 || terms < 3 || terms > 4 || !split_env) return rc;      // split only what is "not covered" (1), never an error (-1)
+    if (rc != 1 || n < 9 || terms < 3 || terms > 4) return rc;      // split only what is "not covered" (1), never an error (-1)
     // 2 + 2 (or 2 + 1) rather than 3 + 1 where three terms fit: the accumulating pass moves 12 B per pixel and takes ~0.9 ms per 16
     // frames at n = 9 whether it carries one term or two, so it may as well carry two (3 + 1: 1.05 + 0.89 ms, 2 + 2: 0.75 + 0.93)
     const int first = 2;
@@ -382,7 +374,7 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
         const size_t ni = images - i0 < 65535 ? images - i0 : 65535;
         job.in = d_in + (long long)i0 * in_pitch;
         job.out = d_out + (long long)i0 * out_pitch;
-        if (dense_kernel_env() != 1) {
+        {
             const int rc = sg2d_launch_dense_rolling(job, f->weights, ctx, (unsigned)ni, st);
             if (rc < 0) return -1;
             if (rc == 0) continue;
@@ -618,6 +610,7 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
     job.in_pitch = (long long)in_pitch; job.out_pitch = (long long)out_pitch;
     job.nx = n; job.ny = n;
     job.boundary = (boundary == SAVGOL2D_BOUNDARY_VALID || boundary == SAVGOL2D_BOUNDARY_REFLECT) ? boundary : SAVGOL2D_BOUNDARY_CONSTANT;
+    int odx[SEP_MAX_OUTPUTS] = {0, 0, 0}, ody[SEP_MAX_OUTPUTS] = {0, 0, 0};          // derivative orders of plan's outputs (the summed Laplacian: none)
     if (!sum_into_one) {
         // x-dominant frames (the Hessian's xx: deriv_x >= 2, deriv_x > deriv_y) run on their own with the HORIZONTAL pass first (sg_2d_hf.hip:
         // the pass order that keeps them inside the parity rule); the other frames share their launches as before
@@ -625,7 +618,6 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
         SepPlan rest;
         memset(&rest, 0, sizeof(rest));
         int tb = 0, rest_terms = 0;
-        bool any_y = false, any_x = false;                   // the tile kernel's pass order for what is left (sg_2d_sep.hip: transposed)
         for (int o = 0; o < plan.outputs; ++o) {
             const float *fo = factors + (size_t)tb * 2 * (ws + 1);
             bool done = false;
@@ -634,8 +626,7 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
                 done = roll_passes_hf(n, plan.terms[o], job, fo, plan.scale[o], (unsigned)images, ctx->cu_count, st) == 0;
             }
             if (!done) {
-                any_y = any_y || sg2d_y_dominant(specs[o].dx, specs[o].dy);
-                any_x = any_x || sg2d_x_dominant(specs[o].dx, specs[o].dy);
+                odx[rest.outputs] = specs[o].dx; ody[rest.outputs] = specs[o].dy;
                 memcpy(rest_factors + (size_t)rest_terms * 2 * (ws + 1), fo, sizeof(float) * (size_t)plan.terms[o] * 2 * (ws + 1));
                 rest.terms[rest.outputs] = plan.terms[o]; rest.scale[rest.outputs] = plan.scale[o]; rest.out[rest.outputs] = plan.out[o];
                 rest.outputs++;
@@ -644,8 +635,6 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
             tb += plan.terms[o];
         }
         if (rest.outputs == 0) return hip_ok(hipGetLastError(), who) ? 0 : -1;
-        rest.transposed = (any_y && !any_x) ? 1 : 0;
-        plan.transposed = rest.transposed;
         if (rest.outputs != plan.outputs) {
             plan = rest;
             total_terms = rest_terms;
@@ -663,31 +652,26 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
                                  plan.out[1], (unsigned)images, ctx->cu_count, st) == 0)
             return hip_ok(hipGetLastError(), who) ? 0 : -1;
     }
-    // three outputs with the same number of terms (the Hessian of order <= 3: rank 1 each): ONE rolling launch up to n = 9
-    if (plan.outputs == 3 && plan.terms[0] == plan.terms[1] && plan.terms[1] == plan.terms[2]) {
-        job.out = plan.out[0];
-        const size_t tstride = (size_t)plan.terms[0] * 2 * (ws + 1);
-        if (sg2d_launch_rolling3(n, plan.terms[0], job, factors, plan.scale[0], factors + tstride, plan.scale[1], factors + 2 * tstride, plan.scale[2],
-                                 plan.out[1], plan.out[2], (unsigned)images, ctx->cu_count, st) == 0)
-            return hip_ok(hipGetLastError(), who) ? 0 : -1;
-    }
-    // (three frames that could not share one rolling launch -- Hessians of order >= 4: two or three terms each -- also go one
-    //  rolling launch per frame from n = 6 up: n = 8, order 4: 2.21 ms fused on the tile kernel, 1.52 as three launches; n = 16,
-    //  order 3: 2.72 vs 1.72; at n = 4 the fused tile kernel is level or ahead, 1.41 vs 1.56)
-    if (plan.outputs <= 2 || n >= 6) {
-        bool rolled = true;
-        int tbase = 0;
-        for (int o = 0; o < plan.outputs && rolled; ++o) {
-            job.out = plan.out[o];
-            rolled = roll_passes(n, plan.terms[o], job, factors + (size_t)tbase * 2 * (ws + 1), plan.scale[o], (unsigned)images,
-                                 ctx->cu_count, st) == 0;
-            tbase += plan.terms[o];
+    // everything else: one rolling launch (or pair of passes) per frame; the tile kernel, one frame at a time, for what the rolling kernels do not
+    // cover.  (Until round 5 three Hessian frames shared one walk / one LDS tile; since the xx frame runs horizontal-first on its own -- above --
+    // at most two frames are left, and the three-output instantiations are gone.)
+    int tbase = 0;
+    for (int o = 0; o < plan.outputs; ++o) {
+        const float *fo = factors + (size_t)tbase * 2 * (ws + 1);
+        job.out = plan.out[o];
+        const int rc = roll_passes(n, plan.terms[o], job, fo, plan.scale[o], (unsigned)images, ctx->cu_count, st);
+        if (rc < 0) return -1;
+        if (rc != 0) {
+            SepPlan one;
+            memset(&one, 0, sizeof(one));
+            one.outputs = 1; one.terms[0] = plan.terms[o]; one.scale[0] = plan.scale[o]; one.out[0] = plan.out[o];
+            one.transposed = sg2d_y_dominant(odx[o], ody[o]) ? 1 : 0;       // the tile kernel's pass order (sg_2d_sep.hip)
+            const float *d_f = ctx_table(ctx, fo, sizeof(float) * (size_t)plan.terms[o] * 2 * (ws + 1), 0x6d000000u + (unsigned)n);
+            if (!d_f) return -1;
+            if (sg2d_launch_separable(n, job, one, d_f, (unsigned)images, ctx->cu_count, st) != 0) { sg_set_error("%s: no separable kernel for n=%d", who, n); return -1; }
         }
-        if (rolled) return hip_ok(hipGetLastError(), who) ? 0 : -1;
+        tbase += plan.terms[o];
     }
-    const float *d_f = ctx_table(ctx, factors, sizeof(float) * (size_t)total_terms * 2 * (ws + 1), 0x6d000000u + (unsigned)n);
-    if (!d_f) return -1;
-    if (sg2d_launch_separable(n, job, plan, d_f, (unsigned)images, ctx->cu_count, st) != 0) { sg_set_error("%s: no separable kernel for n=%d", who, n); return -1; }
     return hip_ok(hipGetLastError(), who) ? 0 : -1;
 }
 

@@ -158,23 +158,6 @@ inline int sg2d_launch_rolling2(int n, int terms, const Job2D &job, const float 
     return sg2d_launch_rolling2_g6(n, terms, job, f0, s0, f1, s1, out1, images, cu_count, st);
 }
 
-// three output frames (job.out, out1, out2) from one walk; every output has `terms` terms (the Hessian of order <= 3: 1 each)
-#define SG_ROLL3_DECL(g) int sg2d_launch_rolling3_##g(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, const float *f2, float s2, \
-                                                      float *out1, float *out2, unsigned images, int cu_count, hipStream_t st);
-SG_ROLL3_DECL(g0) SG_ROLL3_DECL(g1) SG_ROLL3_DECL(g2) SG_ROLL3_DECL(g3) SG_ROLL3_DECL(g4) SG_ROLL3_DECL(g5) SG_ROLL3_DECL(g6)
-#undef SG_ROLL3_DECL
-inline int sg2d_launch_rolling3(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, const float *f2, float s2,
-                                float *out1, float *out2, unsigned images, int cu_count, hipStream_t st)
-{
-    if (sg2d_launch_rolling3_g0(n, terms, job, f0, s0, f1, s1, f2, s2, out1, out2, images, cu_count, st) == 0) return 0;
-    if (sg2d_launch_rolling3_g1(n, terms, job, f0, s0, f1, s1, f2, s2, out1, out2, images, cu_count, st) == 0) return 0;
-    if (sg2d_launch_rolling3_g2(n, terms, job, f0, s0, f1, s1, f2, s2, out1, out2, images, cu_count, st) == 0) return 0;
-    if (sg2d_launch_rolling3_g3(n, terms, job, f0, s0, f1, s1, f2, s2, out1, out2, images, cu_count, st) == 0) return 0;
-    if (sg2d_launch_rolling3_g4(n, terms, job, f0, s0, f1, s1, f2, s2, out1, out2, images, cu_count, st) == 0) return 0;
-    if (sg2d_launch_rolling3_g5(n, terms, job, f0, s0, f1, s1, f2, s2, out1, out2, images, cu_count, st) == 0) return 0;
-    return sg2d_launch_rolling3_g6(n, terms, job, f0, s0, f1, s1, f2, s2, out1, out2, images, cu_count, st);
-}
-
 // sg_2d_hf.hip: ONE term of a kernel with the HORIZONTAL pass first (kernels whose x factor cancels harder than their y factor: deriv_x >= 2,
 // deriv_x > deriv_y); job.accumulate: out += result.  Built in three half-window groups (Makefile).  0 = launched, 1 = not covered, -1 = error.
 int sg2d_launch_rolling_hf_g0(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);

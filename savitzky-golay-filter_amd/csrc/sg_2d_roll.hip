@@ -567,7 +567,8 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 // additive form, half windows 8 .. 12 (A/B builds override).  End of round 5, after the x-stationary horizontal unit had freed 2N + 3 register pairs
 // (tools/placement_2d.py, 32 frames of 4096^2, ms over six buffer pairs; profiles/r05_2d_tile_rows.txt): n = 8: 10 rows 0.900, 14 rows 0.862, 16 rows 0.889;
 // n = 9: 10 / 12 / 14 rows 0.992 / 0.967 / 0.949; n = 10: 8 / 10 / 12 rows 1.073 / 1.017 / 1.016; n = 11, 12: 8-12-row tiles 1.38-1.62 against the walk's
-// 1.27 / 1.30 -- they still spill and keep the walk
+// 1.27 / 1.30 at THREE waves per SIMD (67-127 spilled registers); round 6: at two waves per SIMD (roll_tile_waves) 12-row tiles hold no scratch and are 5 %
+// ahead of the walk (64 frames: 2.344 / 2.406 against 2.469 / 2.546 ms, tools/ab_2d.py, profiles/r06_2d_tiles_n11_16.txt)
 #ifndef SG_ROLL_TR8
 #define SG_ROLL_TR8 14
 #endif
@@ -578,10 +579,13 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #define SG_ROLL_TR10 10     /* round 6: 12 rows spill 4 registers now that nothing else does; 10 rows were level (1.017 against 1.016 ms) */
 #endif
 #ifndef SG_ROLL_TR11
-#define SG_ROLL_TR11 0
+#define SG_ROLL_TR11 12     /* round 6: at TWO waves per SIMD the 12-row tiles hold no scratch: 2.34 against the walk's 2.47 ms per 64 frames */
 #endif
 #ifndef SG_ROLL_TR12
-#define SG_ROLL_TR12 0
+#define SG_ROLL_TR12 12     /* 2.41 against 2.55 */
+#endif
+#ifndef SG_ROLL_TR13
+#define SG_ROLL_TR13 0           // A/B builds: tile rows for every half window 13 .. 16 (0 = the table in roll_tile_rows)
 #endif
 constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
 {
@@ -594,8 +598,10 @@ constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
     // n = 10 additive 2.14 vs 2.31 (8 rows; 10 spill: 2.16), one term 1.91 vs 2.13 (10 rows, 20 bytes of scratch; 8 rows 2.04)
     if (box && nt == 2 && nout == 1 && (n == 9 || n == 10)) return n == 9 ? SG_ROLL_TR9 : SG_ROLL_TR10;
     if (box && nt == 2 && nout == 1 && (n == 11 || n == 12)) return n == 11 ? SG_ROLL_TR11 : SG_ROLL_TR12;
+    // half windows 13 .. 16 as 8-row tiles at two waves per SIMD against the walk (64 frames of 4096^2, ms; profiles/r06_2d_tiles_n11_16.txt):
+    // n = 13: 2.95 / 2.76, 14: 3.10 / 2.85, 15: 2.96 / 3.12, 16: 3.22 / 3.15 -- only 15 gains (its walk runs five rows ahead)
+    if (box && nt == 2 && nout == 1 && n >= 13) return SG_ROLL_TR13 ? SG_ROLL_TR13 : (n == 15 ? 8 : 0);
     if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && (n == 9 || n == 10)) return 10;
-    // (half windows 11, 12 spill 100-600 bytes at three waves per SIMD even on 6-row tiles: they keep the walk)
     if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt <= 2 && n <= 7) return SG_ROLL_TILE_ROWS;
     // the fused two- / three-output forms with one term per frame (gradient of order <= 2, Hessian of order <= 3): the three Hessian frames
     // of 64 x 4096^2 at n = 7 in 3.54 ms instead of 4.02 (2 waves per SIMD: 178 registers)
@@ -606,7 +612,7 @@ constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
 #define SG_ROLL_TILE_WAVES 3
 #endif
 // (the general two-term form at n = 6, 7 spills 36-52 bytes at 3 waves per SIMD)
-constexpr int roll_tile_waves(int n, int nt = 2, bool box = true, int nout = 1) { return (nout >= 2 || (!box && nt == 2 && n >= 6)) ? 2 : SG_ROLL_TILE_WAVES; }
+constexpr int roll_tile_waves(int n, int nt = 2, bool box = true, int nout = 1) { return (nout >= 2 || (!box && nt == 2 && n >= 6) || n >= 11) ? 2 : SG_ROLL_TILE_WAVES; }
 
 // waves per block: the waves of a block walk neighbouring strips row for row, so a block's loads of one row step are one
 // contiguous run of the frame row
@@ -752,11 +758,6 @@ static bool fill_box_taps(RollTaps<N, 2, 1> &taps, const float *factors, float s
     return true;
 }
 
-static int roll_box_env()                                   // SAVGOL_HIP_ROLL_BOX=0: additive kernels run the general two-term form (A/B runs)
-{
-    static const int v = [] { const char *e = getenv("SAVGOL_HIP_ROLL_BOX"); return e ? atoi(e) : 1; }();
-    return v;
-}
 template <int N, int NT, int NOUT, bool BOX, bool ACC = false, int TR = 0>
 static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &taps, float *out1, float *out2, unsigned images, int cu_count, hipStream_t st)
 {
@@ -771,25 +772,10 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
         // frames a tile kernel cannot take on vector loads alone (odd strides, unaligned bases, cols % 4 != 0, narrower than 32 columns): the strip walk
         if ((aligned & 7) != 7) return launch_roll_kernel<N, NT, NOUT, BOX, ACC, 0>(job, taps, out1, out2, images, cu_count, st);
     }
-    static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_XCD"); return e ? atoi(e) : 1; }();
-    if (!xcd_env) aligned |= 8;
     const unsigned strips = (unsigned)((job.cols + R::SW - 1) / R::SW);
     static int per_cu = 0;                                   // resident blocks per CU of this instantiation
     constexpr unsigned WPB = (unsigned)roll_wpb(N, TR);
     size_t lds = sizeof(float) * WPB * 2 * NOUT * NT * R::BUFW;
-    if (TR > 0) {
-        // resident blocks per CU of the tile form (tuning knob): unused dynamic LDS is what limits them
-        static const int cap = [] { const char *e = getenv("SAVGOL_HIP_ROLL_TILE_CAP"); return e ? atoi(e) : 0; }();
-        if (cap > 0) {
-            const size_t want = (size_t)(160 * 1024 / cap) - 1024;
-            if (want > lds) lds = want;
-            static bool raised = false;
-            if (!raised && lds > 65536) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                raised = true;
-            }
-        }
-    }
     if (per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_kernel<N, NT, NOUT, BOX, ACC, TR>, 64 * WPB, lds) != hipSuccess || nb < 1)
@@ -797,19 +783,16 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
         per_cu = nb > (int)(16 / WPB) ? (int)(16 / WPB) : nb;
     }
     const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * WPB;
-    static const char *env_bands = getenv("SAVGOL_HIP_ROLL_BANDS"), *env_one = getenv("SAVGOL_HIP_ROLL_ONEWAVE");     // tuning knobs
     // One item per wave, blocks handed out by the hardware dispatcher in order -- as in the 1-D kernel, and for the same reason: the
-    // same items and bands on a persistent grid (resident waves striding over the items) are 1-5 % slower at every half window
-    // (n = 4: 1.89 vs 1.79 ms per 64 frames).  SAVGOL_HIP_ROLL_ONEWAVE=0 brings the persistent grid back for A/B runs; the band
-    // count is still chosen for whole rounds of the resident waves, which is also what keeps the tail of the dispatch short.
-    const bool persistent = env_one && atoi(env_one) == 0;
+    // same items and bands on a persistent grid (resident waves striding over the items) were 1-5 % slower at every half window
+    // (n = 4: 1.89 vs 1.79 ms per 64 frames; round 3).  The band count is still chosen for whole rounds of the resident waves, which is
+    // also what keeps the tail of the dispatch short.
     // a launch indexes < 2^32 threads (HIP rejects gridDim.x * blockDim.x >= 2^32) and < 2^32 items: split over images
     unsigned long long per_image;
     unsigned bands;
     int band_rows;
     auto geometry = [&](unsigned long long imgs) {
         bands = choose_bands(job.rows, imgs * strips, nwaves, N, 0.3);       // warm-up rows are only loaded
-        if (env_bands && atoi(env_bands) > 0 && atoi(env_bands) <= job.rows) bands = (unsigned)atoi(env_bands);
         band_rows = (int)((job.rows + (int)bands - 1) / (int)bands);
         // the additive form re-seeds its rolling column sums every U rows of a band: bands that start on multiples of U keep that
         // phase tied to the FRAME row, so a frame's bits do not depend on how many frames share the launch (the band count does)
@@ -826,8 +809,7 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
     for (unsigned long long i0 = 0; i0 < images; i0 += img_step) {
         const unsigned long long ni = images - i0 < img_step ? images - i0 : img_step;
         const unsigned long long total = ni * per_image;
-        unsigned grid = (persistent && TR == 0) ? (unsigned)cu_count * (unsigned)per_cu : (unsigned)((total + WPB - 1) / WPB);
-        if ((unsigned long long)grid * WPB > total) grid = (unsigned)((total + WPB - 1) / WPB);
+        unsigned grid = (unsigned)((total + WPB - 1) / WPB);
         grid = (grid + 7u) & ~7u;
         Job2D part = job;
         part.in = job.in + (long long)i0 * job.in_pitch;
@@ -835,11 +817,10 @@ static int launch_roll_kernel(const Job2D &job, const RollTaps<N, NT, NOUT> &tap
         // XCD chunk (round 5): whole frames, at least 128 bands of every strip, dealt to the XCDs round robin -- the eight fronts stay within a few frames of
         // each other instead of an eighth of the stack apart, and no halo row crosses a chunk.  Sampled over fresh buffer pairs in one process, columns
         // rotated (tools/placement_2d.py, profiles/r05_placement_2d.txt; 64 frames of 4096^2, n = 7): 1.624 against 1.632 ms median for contiguous eighths
-        // (first pass over a fresh pair 1.641 / 1.669) -- level to slightly ahead; 64-band chunks 1.645.  SAVGOL_HIP_ROLL_XCD_CHUNK_BANDS=k forces k bands, 0 the old order.
-        static const int chunk_bands_env = [] { const char *e = getenv("SAVGOL_HIP_ROLL_XCD_CHUNK_BANDS"); return e ? atoi(e) : -1; }();
+        // (first pass over a fresh pair 1.641 / 1.669) -- level to slightly ahead; 64-band chunks 1.645.
         int aligned_launch = aligned;
-        const int chunk_bands = chunk_bands_env >= 0 ? chunk_bands_env : (int)(bands * ((128u + bands - 1u) / bands));
-        if (chunk_bands > 0 && !persistent && TR > 0) {
+        const int chunk_bands = (int)(bands * ((128u + bands - 1u) / bands));
+        if (chunk_bands > 0 && TR > 0) {
             const unsigned long long chunk_items = (unsigned long long)chunk_bands * strips;
             if (chunk_items % WPB == 0 && chunk_items / WPB < (1u << 22) && chunk_items / WPB * 8u <= grid) aligned_launch |= (int)((unsigned)(chunk_items / WPB) << 8);
         }
@@ -866,7 +847,7 @@ static int launch_roll(const Job2D &job, const float *const (&factors)[NOUT], co
     if constexpr (NT == 2 && NOUT == 1) {
         RollTaps<N, 2, 1> box;
         memset(&box, 0, sizeof(box));
-        if (roll_box_env() != 0 && fill_box_taps<N>(box, factors[0], scale[0])) {
+        if (fill_box_taps<N>(box, factors[0], scale[0])) {
             constexpr int TR = roll_tile_rows(N, 2, 1, true);
             if constexpr (TR > 0) {
                 // SAVGOL_HIP_ROLL_TILE=0: the strip walk of rounds 1-3 (A/B runs)
@@ -916,20 +897,6 @@ static int dispatch_roll2(int n, int terms, const Job2D &job, const float *f0, f
     else return 1;
 }
 
-// three output frames from one walk over the input, the same number of terms for all three: the Hessian (reference
-// savgol2d_hessian, src/savgol2d.c:501-558, creates, applies and destroys one filter per frame)
-template <int N, int NT>
-static int dispatch_roll3(int n, int terms, const Job2D &job, const float *const (&ff)[3], const float (&ss)[3], float *out1, float *out2, unsigned images,
-                          int cu_count, hipStream_t st)
-{
-    if constexpr (roll_max_terms(N, 3) >= NT) {
-        if (n == N && terms == NT) return launch_roll<N, NT, 3>(job, ff, ss, out1, out2, images, cu_count, st);
-    }
-    if constexpr (NT < roll_max_terms(N, 3)) return dispatch_roll3<N, NT + 1>(n, terms, job, ff, ss, out1, out2, images, cu_count, st);
-    else if constexpr (N < SEP_ROLL_MAX_N) return dispatch_roll3<N + 1, 1>(n, terms, job, ff, ss, out1, out2, images, cu_count, st);
-    else return 1;
-}
-
 // 0 = launched, 1 = this object does not cover the case (half window outside SEP_ROLL_MIN_N..SEP_ROLL_MAX_N, no
 // definite parity).  Built once per half-window group (Makefile), each under its own name SEP_ROLL_FN.
 int SEP_ROLL_FN(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
@@ -944,16 +911,6 @@ int SEP_ROLL_FN2(int n, int terms, const Job2D &job, const float *factors0, floa
 {
     if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > roll_max_terms(n, 2)) return 1;
     return dispatch_roll2<SEP_ROLL_MIN_N, 1>(n, terms, job, factors0, scale0, factors1, scale1, out1, images, cu_count, st);
-}
-
-// the three-output form: job.out, out1 and out2 share stride and pitch; every output has `terms` terms
-int SEP_ROLL_FN3(int n, int terms, const Job2D &job, const float *f0, float s0, const float *f1, float s1, const float *f2, float s2, float *out1,
-                 float *out2, unsigned images, int cu_count, hipStream_t st)
-{
-    if (n < SEP_ROLL_MIN_N || n > SEP_ROLL_MAX_N || terms < 1 || terms > roll_max_terms(n, 3)) return 1;
-    const float *const ff[3] = {f0, f1, f2};
-    const float ss[3] = {s0, s1, s2};
-    return dispatch_roll3<SEP_ROLL_MIN_N, 1>(n, terms, job, ff, ss, out1, out2, images, cu_count, st);
 }
 
 #ifdef SG_STAMPS2D

@@ -259,9 +259,8 @@ static void launch_sep(const Job2D &job, const SepPlan &plan, const float *d_fac
     unsigned grid = (unsigned)cu_count * (per_cu ? per_cu : 1u);
     if (grid > total) grid = (unsigned)total;
     grid = (grid + 7u) & ~7u;
-    if (plan.outputs == 1)      hipLaunchKernelGGL((sg2d_separable_kernel<N, 1>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total, transposed);
-    else if (plan.outputs == 2) hipLaunchKernelGGL((sg2d_separable_kernel<N, 2>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total, transposed);
-    else                        hipLaunchKernelGGL((sg2d_separable_kernel<N, 3>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total, transposed);
+    // one output frame per launch since round 6 (the callers loop: the multi-output instantiations were two thirds of this object and only a fallback's fallback)
+    hipLaunchKernelGGL((sg2d_separable_kernel<N, 1>), dim3(grid), dim3(256), lds, st, j, plan, d_factors, (unsigned)total, transposed);
 }
 
 template <int N>
@@ -275,6 +274,7 @@ static int dispatch_sep(int n, const Job2D &job, const SepPlan &plan, const floa
 int sg2d_launch_separable(int n, const Job2D &job, const SepPlan &plan, const float *d_factors, unsigned images, int cu_count,
                           hipStream_t st)
 {
+    if (plan.outputs != 1) return -1;
     return dispatch_sep<1>(n, job, plan, d_factors, images, cu_count, st) ? 0 : -1;
 }
 

@@ -102,12 +102,6 @@ inline size_t filter_used_bytes(const SavgolFilter *f)
     return offsetof(SavgolFilter, edge_weights) + sizeof(f->edge_weights[0]) * (size_t)f->config.half_window;
 }
 
-static bool moment_form_half()
-{
-    static const bool v = [] { const char *e = getenv("SAVGOL_HIP_MOMENT_FORM"); return !(e && atoi(e) == 32); }();
-    return v;
-}
-
 // the plan of (filter content, device); `need` = which lazily built parts this call wants
 enum : unsigned { NEED_EDGES = 1, NEED_REF = 2, NEED_MOMENT = 4, NEED_MOMENT64 = 8 };
 const FilterPlan *plan_get(DeviceCtx *ctx, const SavgolFilter *f, unsigned need)
@@ -154,10 +148,9 @@ const FilterPlan *plan_get(DeviceCtx *ctx, const SavgolFilter *f, unsigned need)
     }
     if ((need & NEED_MOMENT) && p->moment_terms < 0) {
         // wide-window fast path (half windows 24..32): the polynomial fit of the centre taps (sg_k1d_moment_fit.cpp)
-        // round 5: the half-lane form (sg_k1d_momenth.hpp) unless SAVGOL_HIP_MOMENT_FORM=32 asks for round 2's (A/B runs; read once per process)
-        const int terms = moment_form_half() ? sg1d_momenth_prepare(n, f->center_weights, p->moment_table) : sg1d_moment_prepare(n, f->center_weights, p->moment_table);
+        const int terms = sg1d_momenth_prepare(n, f->center_weights, p->moment_table);            // the half-lane form (sg_k1d_momenth.hpp)
         if (terms > 0) {
-            p->d_moment = sg::ctx_table(ctx, p->moment_table, sizeof(p->moment_table), (moment_form_half() ? 0x2100u : 0x1f00u) + (unsigned)n);
+            p->d_moment = sg::ctx_table(ctx, p->moment_table, sizeof(p->moment_table), 0x2100u + (unsigned)n);
             if (!p->d_moment) return nullptr;
         }
         p->moment_terms = terms;
@@ -217,6 +210,13 @@ bool rows_overlap(const T *d_in, size_t in_ld, size_t in_len, const T *d_out, si
     return d < il || d + ol > pitch;
 }
 
+// a stream-ordered scratch block that every exit hands back (the error returns of the in-place call leaked its stash)
+template <typename T>
+struct ScratchGuard {
+    T *p; hipStream_t st; bool armed;
+    ~ScratchGuard() { if (armed && p) (void)sg::scratch_free(p, st, "scratch free (in-place stash, error exit)"); }
+};
+
 template <typename T>
 int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_out, size_t channels, size_t length,
                   size_t in_ld, size_t out_ld, Variant variant, hipStream_t st, unsigned flags)
@@ -251,7 +251,7 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     // shows: 1.5-2.9 x the reference's own fp32 error there, <= 1.3 x for poly_order >= 2 with derivative <= 1 (every half window
     // 24..32, all boundary modes; the plain three-chain kernel: 0.7-1.3 x everywhere).  Those filters take the plain kernel (8 % slower).
     const bool moment_safe = f->config.poly_order >= 2 && f->config.derivative <= 1;
-    const bool want_moment = sizeof(T) == 4 && !reference_order && n >= (moment_form_half() ? sg::MOMENTH_MIN_N : sg::MOMENT_MIN_N) && n <= sg::MOMENT_MAX_N &&
+    const bool want_moment = sizeof(T) == 4 && !reference_order && n >= sg::MOMENTH_MIN_N && n <= sg::MOMENT_MAX_N &&
                              !(flags & SAVGOL_BATCH_PLAIN_SUMMATION) && moment_safe;
     // fp64, half windows 24..32, on request only: block moments (sg_k1d_moment64.hpp) -- within ~1e-7 of the default path, not its 1e-12
     const bool want_moment64 = sizeof(T) == 8 && (flags & SAVGOL_BATCH_MOMENT_F64) && n >= sg::MOMENT_MIN_N && n <= sg::MOMENT_MAX_N;
@@ -357,12 +357,13 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     // split so that a launch stays below 2^24 blocks of four tiles (sg::MAX_TILES_PER_LAUNCH)
     size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / ((size_t)job.tiles_per_channel + 2);
     if (inplace) {
-        // in place: channel groups whose halo stash stays below 64 MiB -- the stash then lives inside what the scratch pool keeps (256 MiB) instead of
-        // being handed back to the driver and mapped again on every call (config 5's 1024-channel chunk: a 1 GiB stash, 14 ms a call on most boxes and 98
-        // on one), and a 137 GB slice needs 64 MiB beside it, not a gigabyte.  A few more launches; the groups follow each other on the stream.
+        // in place: channel groups whose stash (one slot of 2 NA samples per ODD tile + 4 NA per channel) stays below 192 MiB -- inside what the scratch pool
+        // keeps (256 MiB), so it is neither handed back to the driver nor mapped again from call to call (round 5: a 1 GiB stash per 1024-channel chunk cost
+        // 14 ms a call on most boxes and 98 on one).  The groups follow each other on the stream; config 5's chunk is 6 groups (round 6's first version
+        // stashed a slot per tile under a 64 MiB cap: 32 groups of 0.19 ms launches, +22 %).
         const int NA0 = (n + E - 1) / E * E;
-        const size_t per_ch = ((size_t)job.tiles_per_channel * (size_t)(2 * NA0) + 2 * (size_t)ws) * sizeof(T);
-        const size_t group = per_ch ? ((size_t)64 << 20) / per_ch : max_ch;
+        const size_t per_ch = ((size_t)(job.tiles_per_channel / 2) * (size_t)(2 * NA0) + (size_t)(4 * NA0)) * sizeof(T);
+        const size_t group = per_ch ? ((size_t)192 << 20) / per_ch : max_ch;
         if (group >= 1 && group < max_ch) max_ch = group;
     }
     // the tile launch of the chosen kernel family: one tile per wave, blocks dispatched in order (see sg1d_center_kernel)
@@ -370,13 +371,9 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         unsigned blocks = (j.total_tiles + j.edge_items + 3u) / 4u;
         blocks = (blocks + 7u) & ~7u;                                    // the XCD remap wants a multiple of 8
         if (d_moment)
-            return moment_form_half()
-                       ? (moment_terms == 3 ? sg1d_launch_f32_momenth_t3(n, &j, d_moment, blocks, st)
-                          : moment_terms == 5 ? sg1d_launch_f32_momenth_t5(n, &j, d_moment, blocks, st)
-                                              : sg1d_launch_f32_momenth_t7(n, &j, d_moment, blocks, st))
-                       : (moment_terms == 3 ? sg1d_launch_f32_moment_t3(n, &j, d_moment, blocks, st)
-                          : moment_terms == 5 ? sg1d_launch_f32_moment_t5(n, &j, d_moment, blocks, st)
-                                              : sg1d_launch_f32_moment_t7(n, &j, d_moment, blocks, st));
+            return moment_terms == 3 ? sg1d_launch_f32_momenth_t3(n, &j, d_moment, blocks, st)
+                 : moment_terms == 5 ? sg1d_launch_f32_momenth_t5(n, &j, d_moment, blocks, st)
+                                     : sg1d_launch_f32_momenth_t7(n, &j, d_moment, blocks, st);
         if (d_moment64) {
             const int mt = plan->moment64_terms;
             return mt == 3 ? sg1d_launch_f64_moment_t3(n, &j, d_moment64, blocks, st)
@@ -386,6 +383,13 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
         return sg::launch_center<T>(n, wide, j, taps, blocks, st);
     };
     const unsigned tpc = job.tiles_per_channel;
+    // in place: the 2n+1 input samples of every channel end, for the edge rows that run after the last group (2 (2n+1) samples per channel)
+    T *edge_all = nullptr;
+    if (inplace && d_edges) {
+        edge_all = static_cast<T *>(sg::scratch_alloc(ctx, (channels * 2 * (size_t)ws + 4) * sizeof(T), st, "scratch (in-place edge samples)"));
+        if (!edge_all) return -1;
+    }
+    ScratchGuard<T> edge_guard{edge_all, st, edge_all != nullptr};
     for (size_t c0 = 0; c0 < channels; c0 += max_ch) {
         const size_t nc = (channels - c0 < max_ch) ? channels - c0 : max_ch;
         job.in = d_in + c0 * in_ld;
@@ -396,22 +400,21 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
             if (launch_tiles(job) != 0) return -1;
             continue;
         }
-        // IN PLACE, two colour phases (round 6; round 5 copied every tile's halo in a pass of its own first: +7-13 %).
+        // IN PLACE, two colour phases (round 6; round 5 copied every tile's halo in a pass of its own first).
         // 1. sg1d_launch_ends: the halos that reach past a channel's end + the edge rows' samples -- a few hundred samples per channel;
-        // 2. the EVEN tiles: halos live from the rows (their neighbours are untouched), their own first / last NA inputs into the neighbours' slots;
-        // 3. the ODD tiles: body live, halos from their slots;  4. the POLYNOMIAL edge rows (they overwrite samples the end tiles read).
+        // 2. the EVEN tiles: halos live from the rows (their neighbours are untouched), their own first / last NA inputs into the odd neighbours' slots;
+        // 3. the ODD tiles: body live, halos from their slots;  4. after the last group: the POLYNOMIAL edge rows of every channel in ONE launch (they
+        //    overwrite samples the end tiles read; their 2n+1 input samples per end were put aside by step 1).
         const int NA = (n + E - 1) / E * E;
-        const size_t halo = nc * (size_t)tpc * (size_t)(2 * NA), edge = d_edges ? nc * 2 * (size_t)ws : 0;
-        T *stash = static_cast<T *>(sg::scratch_alloc(ctx, (halo + edge + 4) * sizeof(T), st, "scratch (in-place halo stash)"));
+        const size_t halo = nc * (size_t)(tpc / 2) * (size_t)(2 * NA), ends = nc * (size_t)(4 * NA);
+        T *stash = static_cast<T *>(sg::scratch_alloc(ctx, (halo + ends + 4) * sizeof(T), st, "scratch (in-place halo stash)"));
         if (!stash) return -1;
-        struct StashGuard {                                             // every exit hands the stash back (the error returns leaked it)
-            T *p; hipStream_t st; bool armed;
-            ~StashGuard() { if (armed) (void)sg::scratch_free(p, st, "scratch free (in-place halo stash)"); }
-        } guard{stash, st, true};
-        if (sg1d_launch_ends(job.in, job.in_ld, job.length, tpc, (int)TW, NA, (int)(job.flags & sg::JOB_MODE_MASK), stash, d_edges ? stash + halo : nullptr, ws, nc,
-                             (int)sizeof(T), st) != 0) { sg_set_error("%s: channel-end stash launch failed", who); return -1; }
+        ScratchGuard<T> guard{stash, st, true};
+        if (sg1d_launch_ends(job.in, job.in_ld, job.length, tpc, (int)TW, NA, (int)(job.flags & sg::JOB_MODE_MASK), stash, stash + halo,
+                             edge_all ? edge_all + c0 * 2 * (size_t)ws : nullptr, ws, nc, (int)sizeof(T), st) != 0) { sg_set_error("%s: channel-end stash launch failed", who); return -1; }
         sg::Job1D pj = job;
         pj.stash = stash;
+        pj.ends = stash + halo;
         pj.edge_stash = nullptr;
         pj.edge_items = 0;
         pj.tpc_all = tpc;
@@ -423,16 +426,24 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
             pj.total_tiles = (unsigned)(nc * per);
             if (launch_tiles(pj) != 0) return -1;
         }
-        if (d_edges) {
+        guard.armed = false;
+        if (!sg::scratch_free(stash, st, "scratch free (in-place halo stash)")) return -1;
+    }
+    if (inplace && edge_all) {
+        // every channel's two edge items, 2^22 items (two million channels) per launch
+        for (size_t c0 = 0; c0 < channels; c0 += (size_t)1 << 21) {
+            const size_t nc = channels - c0 < ((size_t)1 << 21) ? channels - c0 : ((size_t)1 << 21);
             sg::Job1D ej = job;
-            ej.edge_stash = stash + halo;
+            ej.in = d_in + c0 * in_ld;
+            ej.out = d_out + c0 * out_ld;
+            ej.edge_stash = edge_all + c0 * 2 * (size_t)ws;
             ej.total_tiles = 0; ej.edge_items = (unsigned)(2 * nc);
             unsigned eb = (ej.edge_items + 3u) / 4u;
             eb = (eb + 7u) & ~7u;
             if (sg::launch_center<T>(n, 0, ej, taps, eb, st) != 0) return -1;
         }
-        guard.armed = false;
-        if (!sg::scratch_free(stash, st, "scratch free (in-place halo stash)")) return -1;
+        edge_guard.armed = false;
+        if (!sg::scratch_free(edge_all, st, "scratch free (in-place edge samples)")) return -1;
     }
     return 0;
 }
@@ -537,11 +548,7 @@ int host_apply_pipelined(const char *who, DeviceCtx *ctx, const SavgolFilter *f,
     const int shift = (variant == VALID) ? n : 0;
     const float dt_inv = dt_inverse(f);
 
-    static const size_t PIPE_CHUNK = [] {
-        const char *e = getenv("SAVGOL_HIP_PIPE_CHUNK_LOG2");
-        const int l = e ? atoi(e) : 0;
-        return (l >= 16 && l <= 26) ? (size_t)1 << l : PIPE_CHUNK_DEFAULT;
-    }();
+    constexpr size_t PIPE_CHUNK = PIPE_CHUNK_DEFAULT;
     const size_t lo = PIPE_HALO, hi = L - PIPE_HALO;                       // centre outputs [lo, hi) go through the chunks
     const size_t nchunks = (hi - lo + PIPE_CHUNK - 1) / PIPE_CHUNK;
     std::vector<hipEvent_t> done(nchunks, nullptr);
@@ -628,12 +635,6 @@ int savgol_hip_set_option(int option, int value)
     return -1;
 }
 
-int savgol_hip_moment_table(const SavgolFilter *filter, float *table)
-{
-    if (!filter || !table) { sg_set_error("savgol_hip_moment_table: NULL pointer"); return -1; }
-    return sg1d_moment_prepare(filter->config.half_window, filter->center_weights, table);
-}
-
 int savgol_hip_momenth_table(const SavgolFilter *filter, float *table)
 {
     if (!filter || !table) { sg_set_error("savgol_hip_momenth_table: NULL pointer"); return -1; }
@@ -645,13 +646,8 @@ int savgol_hip_momenth_table(const SavgolFilter *filter, float *table)
 // synchronise ends the call: launch + synchronise instead of H2D + launch + D2H.  Same kernel, same bits.  Measured
 // (tools/time_host_small.py, profiles/r03_host_small.txt): 4096 samples 30 -> 23 us, 65 536: 66 -> 53 us, 262 144: 139 -> 129 us;
 // BELOW ~2000 samples it loses (360 samples, the reference's demo: 20 -> 26 us -- the kernel's dependent loads then each pay a
-// PCIe round trip), so short signals keep the copies.  SAVGOL_HIP_ZERO_COPY_MIN / _MAX override the range (tuning).
-static bool zero_copy_length(size_t n)
-{
-    static const size_t lo = [] { const char *e = getenv("SAVGOL_HIP_ZERO_COPY_MIN"); return e ? (size_t)atoll(e) : (size_t)2048; }();
-    static const size_t hi = [] { const char *e = getenv("SAVGOL_HIP_ZERO_COPY_MAX"); return e ? (size_t)atoll(e) : (size_t)262144; }();
-    return n >= lo && n <= hi;
-}
+// PCIe round trip), so short signals keep the copies.
+static bool zero_copy_length(size_t n) { return n >= 2048 && n <= 262144; }
 
 // Short host signals (<= 4096 samples; the reference's demo filters 360): the resident small-call service of sg_k1d_misc.hip -- no
 // launch, no copies through the runtime: 0 = `output` holds the result, 1 = not taken (longer signal, service disabled or

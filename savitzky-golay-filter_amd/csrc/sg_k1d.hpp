@@ -402,16 +402,27 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
 #endif
     SG_STAMP(0);
     const unsigned c = job.tpc_shift >= 32 ? tile : (__umulhi(tile, job.tpc_magic) >> job.tpc_shift);   // tile / tiles_per_channel, on the scalar unit
-    // in-place colour phases (Job1D::phase): the launch holds the even (1) or the odd (2) tiles of every channel; slot = the tile's place in the stash
-    unsigned k = tile - c * job.tiles_per_channel, slot = tile;
-    bool st_left = job.stash != nullptr, st_right = st_left;
+    // in-place colour phases (Job1D::phase): the launch holds the even (1) or the odd (2) tiles of every channel.  Stash layout (Job1D): one slot of
+    // [left NA | right NA] per ODD tile (slot of tile k = c * (T / 2) + (k - 1) / 2), and per channel `ends` = [tile 0's left | the last tile's right |
+    // tile T-2's right when the last tile is shorter than NA | pad], NA samples each
+    unsigned k = tile - c * job.tiles_per_channel;
+    bool st_left = false, st_right = false;
+    const VT *stl = nullptr, *str = nullptr;                              // where a stashed left / right halo comes from
+    unsigned odd_slots = 0;
     if (job.phase) {
         k = 2u * k + (job.phase - 1u);
-        slot = c * job.tpc_all + k;
+        odd_slots = job.tpc_all >> 1;
         if (job.phase == 1u) {
             st_left = k == 0u;
             const int last_body = (int)job.length - (int)(job.tpc_all - 1u) * TW;          // samples in the channel's last tile
-            st_right = k + 1u == job.tpc_all || (k + 2u == job.tpc_all && last_body < NA);
+            const bool last = k + 1u == job.tpc_all;
+            st_right = last || (k + 2u == job.tpc_all && last_body < NA);
+            stl = static_cast<const VT *>(job.ends) + (size_t)c * (4 * HV);
+            str = stl + (last ? HV : 2 * HV);
+        } else {
+            st_left = st_right = true;
+            stl = static_cast<const VT *>(job.stash) + ((size_t)c * odd_slots + (k >> 1)) * (2 * HV);
+            str = stl + HV;
         }
     }
     const int ts = (int)k * TW;
@@ -429,30 +440,29 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
         // IN PLACE (out == in): the body [ts, ts + TW) belongs to this tile alone -- nobody else reads or writes it.  A halo the neighbours may already
         // have overwritten (odd phase: both) or that reaches past the channel's end (even phase) comes from the tile's stash slot, already remapped /
         // zero-filled per mode; the other side of an even tile is still untouched in the rows
-        const VT *st = static_cast<const VT *>(job.stash) + (size_t)slot * (2 * HV);
         if ((job.flags & JOB_VEC_IN) && ts + TW <= L) {
             const VT *src = reinterpret_cast<const VT *>(row + ts) - HV;              // slab vector v <-> sample ts - NA + v E
             VT p[VPL + 1];
 #pragma unroll
             for (int s = 0; s < VPL; ++s) {
-                if (s == 0) p[0] = (lane < HV && st_left) ? st[lane] : ld_stream(src + lane);
+                if (s == 0) p[0] = (lane < HV && st_left) ? stl[lane] : ld_stream(src + lane);
                 else p[s] = ld_stream(src + lane + 64 * s);
             }
-            if (lane < 2 * HV) p[VPL] = (lane < HV || !st_right) ? ld_stream(src + TV + lane) : st[lane];          // body tail, then the right halo = st[HV + (lane - HV)]
+            if (lane < 2 * HV) p[VPL] = (lane < HV || !st_right) ? ld_stream(src + TV + lane) : str[lane - HV];          // body tail, then the right halo
 #pragma unroll
             for (int s = 0; s < VPL; ++s) *row_vec(s) = p[s];
             if (lane < 2 * HV) *row_vec(VPL) = p[VPL];
         } else {
             // the last tile of a channel (its body ends at L) and rows without 16-byte alignment: element by element
-            const T *se = reinterpret_cast<const T *>(st);
+            const T *sel = reinterpret_cast<const T *>(stl), *ser = reinterpret_cast<const T *>(str);
             const int tend = ts + TW < L ? ts + TW : L;
 #pragma unroll 4
             for (int e = lane; e < K::SL; e += 64) {
                 const int g = ts - NA + e;
                 T x = T(0);
-                if (g < ts) x = st_left ? se[e] : row[g];
+                if (g < ts) x = st_left ? sel[e] : row[g];
                 else if (g < tend) x = row[g];
-                else if (g < tend + NA) x = st_right ? se[NA + (g - tend)] : row[g];
+                else if (g < tend + NA) x = st_right ? ser[g - tend] : row[g];
                 *reinterpret_cast<T *>(slab + slab_vec_off<VPL>(e / E) + (e % E) * (int)sizeof(T)) = x;
             }
         }
@@ -505,11 +515,11 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
         // even phase: the first NA input samples of this body are the RIGHT halo of tile k - 1, the last NA the LEFT halo of tile k + 1 -- into
         // their slots before this tile's results overwrite the rows (the slab holds them: vectors HV .. 2 HV - 1 and TV .. TV + HV - 1; positions
         // past the channel's end hold the remapped values the staging put there, which is what the neighbour's window needs)
-        VT *slots = const_cast<VT *>(static_cast<const VT *>(job.stash));
+        VT *slots = const_cast<VT *>(static_cast<const VT *>(job.stash)) + (size_t)c * odd_slots * (2 * HV);       // this channel's odd slots: tile 2j + 1 -> slot j
         if (lane < HV) {
-            if (k > 0u) slots[(size_t)(slot - 1u) * (2 * HV) + HV + lane] = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(HV + lane));
+            if (k > 0u) slots[(size_t)((k >> 1) - 1u) * (2 * HV) + HV + lane] = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(HV + lane));        // tile k - 1's right halo
         } else if (lane < 2 * HV) {
-            if (k + 1u < job.tpc_all) slots[(size_t)(slot + 1u) * (2 * HV) + (lane - HV)] = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(TV + lane - HV));
+            if (k + 1u < job.tpc_all) slots[(size_t)(k >> 1) * (2 * HV) + (lane - HV)] = *reinterpret_cast<const VT *>(slab + slab_vec_off<VPL>(TV + lane - HV));   // tile k + 1's left halo
         }
     }
 

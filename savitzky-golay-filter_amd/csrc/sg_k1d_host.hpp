@@ -77,17 +77,18 @@ struct Job1D {
     // 2c + 1 = trailing end; edges = the filter's [n][2n+1] edge table on the device, NULL = none
     unsigned    edge_items;
     const float *edges;
-    // IN PLACE (out == in; round 6: two colour phases, no stash pass).  No tile may read what a neighbour has already overwritten.  `stash` holds one
-    // slot per tile of the launch group, [left NA | right NA] = the NA samples either side of the tile's body as they were before anybody stored.
+    // IN PLACE (out == in; round 6: two colour phases, no stash pass).  No tile may read what a neighbour has already overwritten.
     //   phase 1: the EVEN tiles of every channel.  Their neighbours' bodies are untouched, so their halos are read LIVE from the rows; only a halo that
     //            reaches past a channel end (tile 0's left, the last tile's right, and the right of the tile before a last tile shorter than NA) comes
-    //            from the stash, where sg1d_launch_ends put it -- remapped per boundary mode -- before the phase.  Before storing, an even tile writes
-    //            the first and last NA input samples of its own body into its odd neighbours' slots.
-    //   phase 2: the ODD tiles: body live, both halos from their slot.
-    // tiles_per_channel / tpc_magic / total_tiles count the tiles of the PHASE; tpc_all = tiles of a whole channel (the slot pitch).  phase 0 with a
-    // stash = every tile takes both halos from its slot (round 5's form: a full stash pass first).  The edge items read the 2n+1 samples of their
-    // channel end from `edge_stash` ([channel][end][2n+1]).  NULL = out of place: halos and edge samples come from the rows themselves.
+    //            from `ends` ([channel][left of tile 0 | right of the last tile | right of tile T-2 | pad], NA samples each), where sg1d_launch_ends put
+    //            it -- remapped per boundary mode -- before the phase.  Before storing, an even tile writes the first and last NA input samples of its
+    //            own body into its odd neighbours' slots.
+    //   phase 2: the ODD tiles: body live, both halos from their slot in `stash` ([channel][odd tile (k-1)/2][left NA | right NA]; an odd LAST tile's
+    //            right half is written by sg1d_launch_ends).
+    // tiles_per_channel / tpc_magic / total_tiles count the tiles of the PHASE; tpc_all = tiles of a whole channel.  The edge items read the 2n+1 samples
+    // of their channel end from `edge_stash` ([channel][end][2n+1]).  NULL = out of place: halos and edge samples come from the rows themselves.
     const void *stash;
+    const void *ends;
     const void *edge_stash;
     unsigned    phase, tpc_all;
     // tile order (sg1d_tile_body): 0 = each XCD sweeps one contiguous eighth of the tiles; s in 1..31 = chunks of 2^s blocks dealt to the XCDs round
@@ -130,22 +131,15 @@ inline void set_tiles_per_channel(Job1D &job, unsigned d)
     division_magic(d, &job.tpc_magic, &job.tpc_shift);
 }
 
-// The wide-window fp32 fast path (sg_k1d_moment.hpp, half windows 24..32): one device table per filter content, read through
-// scalar loads.  Geometry (host and kernel must agree): a lane's window is X[0 .. 32 + 2n + OFF), output r reads X[r + OFF + k];
-// the block every output's window contains is X[LO .. HI), both even.
-//   floats [0, 66)    centre taps w[0..2n], zero padded
-//   floats [80, 176)  phi[s-1][t] = P_s((t - (BK-1)/2) / (BK/2)), s = 1..6, t = 0..BK/2-1   (Legendre; P_s(BK-1-t) = (-1)^s P_s(t))
-//   floats [176, 400) c[s][J] = (c_s(2J), c_s(2J+1)), s = 0..6, J = 0..15: the block's share of output r is sum_s c_s(r) mu_s
-constexpr int MOMENT_MIN_N = 24, MOMENT_MAX_N = 32;
+// Block-moment kernels, common constants.  One device table per filter content, read through scalar loads; OFF = the slab offset of the first sample
+// output 0 reads (K1D<float, n>).  (Round 2's whole-lane fp32 form, sg_k1d_moment.hpp, went in round 6; its plan slot size stays.)
+constexpr int MOMENT_MIN_N = 24, MOMENT_MAX_N = 32;         // the fp64 kernel's range; the fp32 half-lane form starts at MOMENTH_MIN_N
 constexpr int MOMENT_MAX_TERMS = 7;
-constexpr int MOMENT_OFF_W = 0, MOMENT_OFF_PHI = 80, MOMENT_OFF_C = 176;
-constexpr int MOMENT_TABLE_FLOATS = MOMENT_OFF_C + MOMENT_MAX_TERMS * 32;
-constexpr int moment_off(int n) { return (n + 3) / 4 * 4 - n; }                       // OFF of K1D<float, n>
-constexpr int moment_lo(int n) { return (31 + moment_off(n) + 1) / 2 * 2; }           // first sample of the common block (even)
-constexpr int moment_hi(int n) { return (moment_off(n) + 2 * n + 1) / 2 * 2; }        // one past its last sample (even)
+constexpr int MOMENT_TABLE_FLOATS = 400;
+constexpr int moment_off(int n) { return (n + 3) / 4 * 4 - n; }
 struct MomentArgs { const float *table; };
 
-// Round 5's fp32 form on HALF-lane blocks (sg_k1d_momenth.hpp): a lane's 32 outputs as two groups of 16, each with the block X[LO .. HI) of ITS window
+// The fp32 form on HALF-lane blocks (sg_k1d_momenth.hpp, round 5): a lane's 32 outputs as two groups of 16, each with the block X[LO .. HI) of ITS window
 // (LO even >= 15 + OFF, HI even <= OFF + 2n + 1: 48 samples at n = 32), paired front to back, two pairs per packed step.
 //   floats [0, 132)    tap pairs (w[k], w[k-1]), k = 0 .. 2n+1, w[-1] = w[2n+1] = 0   (what one broadcast sample feeds into an output pair)
 //   floats [132, 276)  phi pairs [u][s-1] = (phi_s(2u), phi_s(2u+1)), u = 0 .. BK/4-1 (<= 12 steps), s = 1..6: six pairs per step
@@ -158,7 +152,7 @@ static_assert(MOMENTH_TABLE_FLOATS <= MOMENT_TABLE_FLOATS, "the half-lane table 
 constexpr int momenth_lo(int n) { return (15 + moment_off(n) + 1) / 2 * 2; }
 constexpr int momenth_hi(int n) { return (moment_off(n) + 2 * n + 1) / 2 * 2; }
 
-// The opt-in fp64 block-moment path (sg_k1d_moment64.hpp, half windows 24..32, SAVGOL_BATCH_MOMENT_F64): 16 outputs per lane, the window is
+// The fp64 block-moment path (sg_k1d_moment64.hpp, half windows 24..32; savgol_apply_batch_f64_tol with rel_tol >= 1e-6, or SAVGOL_BATCH_MOMENT_F64): 16 outputs per lane, the window is
 // X[0 .. 16 + 2n + OFF), the common block X[LO .. HI) with LO = 15 + OFF, HI = OFF + 2n + 1 (2n - 14 samples: 50 at n = 32), paired front to back.
 //   doubles [0, 16)     centre taps 0..14 (exact promotions of the fp32 table), one pad
 //   doubles [16, 166)   phi[t][s-1] = P_s((t - (BK-1)/2) / (BK/2)), t = 0..BK/2-1 (<= 25 pairs), s = 1..6: six per pair whatever the term count
@@ -199,13 +193,9 @@ int sg1d_launch_f64_g2(int n, int wide, const sg::Job1D *job, const sg::Taps *ta
 int sg1d_launch_f64_g3(int n, int wide, const sg::Job1D *job, const sg::Taps *taps, unsigned grid, void *stream);
 
 // the fp32 kernel for half window n (24..32) with `terms` block moments (3, 5 or 7); one object per term count; returns 0 when enqueued
-int sg1d_launch_f32_moment_t3(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
-int sg1d_launch_f32_moment_t5(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
-int sg1d_launch_f32_moment_t7(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
 // fits the polynomial behind the 2n+1 centre taps and fills table[MOMENT_TABLE_FLOATS]; returns the number of moments the kernel
 // needs (3, 5, 7) or 0 when n is outside 24..32 or the taps are not a polynomial of degree <= 6 to fp32 rounding
 // (sg_k1d_moment_fit.cpp)
-int sg1d_moment_prepare(int n, const float *center_weights, float *table);
 // the half-lane form's table (MOMENTH_TABLE_FLOATS floats) and launchers; same return value
 int sg1d_momenth_prepare(int n, const float *center_weights, float *table);
 int sg1d_launch_f32_momenth_t3(int n, const sg::Job1D *job, const float *d_table, unsigned grid, void *stream);
@@ -217,9 +207,9 @@ int sg1d_launch_f64_moment_t3(int n, const sg::Job1D *job, const double *d_table
 int sg1d_launch_f64_moment_t5(int n, const sg::Job1D *job, const double *d_table, unsigned grid, void *stream);
 int sg1d_launch_f64_moment_t7(int n, const sg::Job1D *job, const double *d_table, unsigned grid, void *stream);
 
-// in place, before the two phases: the halos that reach past a channel end (slot(c, 0).left, slot(c, T-1).right, and slot(c, T-2).right when the
-// last tile is shorter than NA), remapped per boundary mode, and the edge rows' samples -- a few hundred samples per channel
-int sg1d_launch_ends(const void *in, long long in_ld, unsigned length, unsigned tiles_per_channel, int TW, int NA, int mode, void *stash, void *edge_stash,
+// in place, before the two phases: the halos that reach past a channel end (Job1D::ends; an odd last tile's right half goes into its stash slot too),
+// remapped per boundary mode, and the edge rows' samples -- a few hundred samples per channel
+int sg1d_launch_ends(const void *in, long long in_ld, unsigned length, unsigned tiles_per_channel, int TW, int NA, int mode, void *stash, void *ends, void *edge_stash,
                      int ws, size_t channels, int elem_bytes, void *stream);
 int sg1d_launch_reference_order_f32(const float *in, float *out, long long in_ld, long long out_ld, long long L, int n,
                                     const float *d_table, float dt_inv, int mode, int store_lo, int store_hi, int out_shift,

@@ -339,8 +339,7 @@ static SmallService *small_service(DeviceCtx *ctx)
     bool ok = hipGetDeviceProperties(&prop, ctx->ordinal) == hipSuccess && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
     // mailbox + input: host-writable device memory when the BAR covers it (the doorbell is a posted write, the kernel polls its own memory)
     const size_t dev_bytes = sizeof(SmallMailbox) + sizeof(float) * SMALL_MAX_SAMPLES;
-    static const bool force_host = getenv("SAVGOL_HIP_SERVICE_HOST_BELL") != nullptr;
-    if (ok && prop.isLargeBar && !force_host && hipExtMallocWithFlags(&p, dev_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+    if (ok && prop.isLargeBar && hipExtMallocWithFlags(&p, dev_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
         if (host_can_write_device_memory(p)) { s->in_device_memory = true; s->bell_host = s->bell_dev = static_cast<SmallMailbox *>(p); }
         else (void)hipFree(p);
     } else (void)hipGetLastError();
@@ -555,33 +554,35 @@ int sg_launch_scatter_f32(const float *src, size_t src_ld, void *base, size_t st
 // ---- in-place batch calls: what the tiles at a channel's ends need from beyond it (and the edge rows' samples), captured before any tile stores ----
 }  // extern "C"
 namespace sg {
-// Round 6 (in place in two colour phases): only the halos that reach past a channel's end need a pass of their own -- slot(c, 0).left,
-// slot(c, T-1).right and, when the last tile holds fewer than NA samples, slot(c, T-2).right -- plus the edge rows' samples: 3 NA + 2 ws samples
-// per channel, whatever its length.  Everything else the even tiles hand to their odd neighbours while they run (Job1D::phase).
+// Round 6 (in place in two colour phases): only the halos that reach past a channel's end need a pass of their own -- per channel `ends` = [tile 0's
+// left | the last tile's right | tile T-2's right when the last tile holds fewer than NA samples | pad], remapped per boundary mode; an ODD last tile
+// reads its right halo from its own stash slot, so it is written there as well -- plus the edge rows' samples: 4 NA + 2 ws samples per channel,
+// whatever its length.  Everything else the even tiles hand to their odd neighbours while they run (Job1D::phase).
 template <typename T>
 __global__ __launch_bounds__(256) void sg1d_ends_kernel(const T *__restrict__ in, long long in_ld, int L, unsigned tiles_per_channel, int TW, int NA, int mode,
-                                                        T *__restrict__ stash, T *__restrict__ edge_stash, int ws, size_t channels)
+                                                        T *__restrict__ stash, T *__restrict__ ends, T *__restrict__ edge_stash, int ws, size_t channels)
 {
     const size_t per_ch = (size_t)(3 * NA) + (edge_stash ? 2 * (size_t)ws : 0);
-    const unsigned Tn = tiles_per_channel;
+    const unsigned Tn = tiles_per_channel, odd_slots = Tn >> 1;
     const int last_ts = (int)(Tn - 1u) * TW;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < channels * per_ch; idx += (size_t)gridDim.x * 256) {
         const size_t c = idx / per_ch;
         const int j = (int)(idx - c * per_ch);
         const T *row = in + (long long)c * in_ld;
-        T *slots = stash + c * (size_t)Tn * (size_t)(2 * NA);
         if (j < 3 * NA) {
             int g;
-            T *dst;
-            if (j < NA) { g = j - NA; dst = slots + j; }                                                              // slot(c, 0).left
-            else if (j < 2 * NA) { g = L + (j - NA); dst = slots + (size_t)(Tn - 1u) * (size_t)(2 * NA) + NA + (j - NA); }   // slot(c, T-1).right
+            if (j < NA) g = j - NA;                                                    // tile 0's left halo
+            else if (j < 2 * NA) g = L + (j - NA);                                     // the last tile's right halo
             else {
-                if (Tn < 2u || L - last_ts >= NA) continue;                                                            // slot(c, T-2).right: only before a short last tile
-                g = last_ts + (j - 2 * NA); dst = slots + (size_t)(Tn - 2u) * (size_t)(2 * NA) + NA + (j - 2 * NA);
+                if (Tn < 2u || L - last_ts >= NA) continue;                            // tile T-2's right halo: only before a short last tile
+                g = last_ts + (j - 2 * NA);
             }
             bool zero = false;
             if (g < 0 || g >= L) g = remap_index(g, L, mode, zero);
-            *dst = zero ? T(0) : row[g];
+            const T v = zero ? T(0) : row[g];
+            ends[c * (size_t)(4 * NA) + j] = v;
+            if (j >= NA && j < 2 * NA && (Tn & 1u) == 0u)                              // an odd last tile (T even): the right half of its slot
+                stash[(c * (size_t)odd_slots + (size_t)(odd_slots - 1u)) * (size_t)(2 * NA) + NA + (j - NA)] = v;
         } else {
             const int r = j - 3 * NA;
             const int g = r < ws ? r : L - ws + (r - ws);                              // leading end: samples 0..2n, trailing end: L-ws..L-1
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(256) void sg1d_ends_kernel(const T *__restrict__ in
 }
 }  // namespace sg
 extern "C" {
-int sg1d_launch_ends(const void *in, long long in_ld, unsigned length, unsigned tiles_per_channel, int TW, int NA, int mode, void *stash, void *edge_stash,
+int sg1d_launch_ends(const void *in, long long in_ld, unsigned length, unsigned tiles_per_channel, int TW, int NA, int mode, void *stash, void *ends, void *edge_stash,
                      int ws, size_t channels, int elem_bytes, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -601,10 +602,10 @@ int sg1d_launch_ends(const void *in, long long in_ld, unsigned length, unsigned 
     if (blocks > 65535) blocks = 65535;
     if (elem_bytes == 4)
         hipLaunchKernelGGL(sg::sg1d_ends_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float *>(in), in_ld, (int)length, tiles_per_channel, TW, NA,
-                           mode, static_cast<float *>(stash), static_cast<float *>(edge_stash), ws, channels);
+                           mode, static_cast<float *>(stash), static_cast<float *>(ends), static_cast<float *>(edge_stash), ws, channels);
     else
         hipLaunchKernelGGL(sg::sg1d_ends_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const double *>(in), in_ld, (int)length, tiles_per_channel, TW, NA,
-                           mode, static_cast<double *>(stash), static_cast<double *>(edge_stash), ws, channels);
+                           mode, static_cast<double *>(stash), static_cast<double *>(ends), static_cast<double *>(edge_stash), ws, channels);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -7,7 +7,7 @@
 // Why.  sg1d_center_kernel<double, 32> issues 1040 v_fma_f64 per tile and lane and is issue-bound (4.4 cycles per instruction, 47 % of
 // the wave cycles stalled on issue: profiles/r04_1d_f64_n32_pmc_summary.json) at 0.68 of the HBM roofline.  Only fewer instructions help.
 //
-// How (the construction of sg_k1d_moment.hpp, re-derived for 16 outputs per lane and scalar doubles).  A lane owns outputs r = 0..15; its
+// How (round 2's block-moment construction, re-derived for 16 outputs per lane and scalar doubles).  A lane owns outputs r = 0..15; its
 // window is X[0 .. 16 + 2n + OFF) and output r reads X[r + OFF + k] with tap k.  The samples X[LO .. HI), LO = 15 + OFF, HI = OFF + 2n + 1
 // (50 of the 80 at n = 32) lie inside EVERY output's window, and there the taps are a polynomial q_r(t) of degree < M1 in t (the centre
 // taps of a Savitzky-Golay filter are samples of a polynomial of degree <= poly_order, reference compute_weight :336-356).  In the

@@ -1,5 +1,5 @@
-// sg_k1d_momenth.hpp -- fp32 block moments on HALF-lane blocks: half windows 24..32 at ~19 multiply-adds per output (round 5; the round-2 form,
-// sg_k1d_moment.hpp, needs 23, the plain sum 33: packed instructions per output).
+// sg_k1d_momenth.hpp -- fp32 block moments on HALF-lane blocks: half windows 20..32 (MOMENTH_MIN_N) at ~19 packed multiply-adds per output pair at
+// n = 32 (round 5; round 2's whole-lane form -- removed in round 6 -- needed 23, the plain sum 33).
 //
 // Reference loop served: the centre loop of savgol_apply, src/savgolFilter.c:763-766 (convolve_ilp :547-580).
 //
@@ -15,7 +15,7 @@
 //   * moments: block samples paired front to back, two pairs per instruction: e = front + back, o = front - back, then M1 - 1 multiply-adds
 //     (phi_s(BK-1-t) = (-1)^s phi_s(t): even moments from e, odd ones from o);
 //   * M1 multiply-adds per output pair for the block's share, added LAST (it is the largest single term of an output that cancels).
-// ~300 packed instructions per 16 outputs at n = 32, M1 = 5.  Constants through pinned scalar loads, as in sg_k1d_moment.hpp.
+// ~300 packed instructions per 16 outputs at n = 32, M1 = 5.  Constants through pinned scalar loads.
 #pragma once
 
 #include "sg_k1d.hpp"

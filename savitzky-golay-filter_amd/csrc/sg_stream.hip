@@ -147,70 +147,7 @@ __global__ __launch_bounds__(256) void sg_bank_rows_kernel(const float *__restri
 // Every accumulator still sees its taps in ascending order with separate multiply and add -> bit-identical to the
 // per-tick kernel and to the reference; 16 independent chains per lane hide the add latency.  HBM traffic = the
 // samples and the outputs (8 B/sample); afterwards sg_bank_store_tail_kernel writes the newest 2n+1 samples back.
-constexpr int BLOCK_TT = 64;         // ticks per block of the time-tiled push (4 lane groups x 16 consecutive ticks); 128 spills and is 6x slower
-
 struct alignas(8) StreamTaps { float w[SAVGOL_MAX_WINDOW + 1]; };     // by-value kernarg -> 33 aligned SGPR pairs
-
-// acc += w * x for two ticks at once, multiply and add rounded SEPARATELY (v_pk_mul_f32 then v_pk_add_f32: the same
-// two roundings per lane as the reference's `sum += w * x`); the tap is broadcast out of an aligned SGPR pair.
-template <int SEL>
-__device__ __forceinline__ void pk_mul_add(f32x2 &acc, const f32x2 wpair, const f32x2 x)
-{
-    const f32x2 p = pk_mul_sgpr<SEL>(wpair, x);
-    asm("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
-}
-
-template <int N>
-__global__ __launch_bounds__(256) void sg_bank_block_kernel(const float *__restrict__ ring, const float *__restrict__ samples,
-                                                            float *__restrict__ out, size_t streams, const StreamTaps taps,
-                                                            int wp0, unsigned long long received0, size_t ticks, float dt_inv)
-{
-    constexpr int WS = 2 * N + 1, TT = BLOCK_TT, PER = TT / 4, ROWS = TT + WS - 1;
-    __shared__ float tile[ROWS * 64];                           // [row][stream]: conflict free both ways
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const size_t s = (size_t)blockIdx.x * 64 + lane;
-    const size_t t0 = (size_t)blockIdx.y * TT;                  // first tick of this tile
-    const bool live = s < streams;
-
-    // row r of the tile = history index h = t0 + r - (WS-1):  h >= 0 -> this call's sample h, h < 0 -> the ring
-    // (sample -k, k = 1..WS-1, sits at slot (wp0 - k) mod WS)
-    for (int r = grp; r < ROWS; r += 4) {
-        const long long h = (long long)t0 + r - (WS - 1);
-        float v = 0.0f;
-        if (live) {
-            if (h >= 0) { if ((size_t)h < ticks) v = samples[(size_t)h * streams + s]; }
-            else { int slot = wp0 + (int)h; if (slot < 0) slot += WS; v = ring[(size_t)slot * streams + s]; }
-        }
-        tile[r * 64 + lane] = v;
-    }
-    __syncthreads();
-
-    f32x2 W[33];
-#pragma unroll
-    for (int p = 0; p < 33; ++p) W[p] = f32x2{taps.w[2 * p], taps.w[2 * p + 1]};
-    f32x2 acc[PER / 2];                                          // pair J = ticks 2J, 2J+1 of this lane
-#pragma unroll
-    for (int j = 0; j < PER / 2; ++j) acc[j] = f32x2{0.0f, 0.0f};
-    const float *col = tile + (grp * PER) * 64 + lane;
-#pragma unroll
-    for (int r = 0; r < PER + WS - 2; ++r) {
-        const f32x2 x = {col[r * 64], col[(r + 1) * 64]};        // rows r, r+1: one ds_read2st64_b32
-#pragma unroll
-        for (int J = 0; J < PER / 2; ++J) {
-            const int i = r - 2 * J;                             // literal after unrolling; same tap for both ticks
-            if (i >= 0 && i < WS) {
-                if (i & 1) pk_mul_add<1>(acc[J], W[i >> 1], x); else pk_mul_add<0>(acc[J], W[i >> 1], x);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const size_t t = t0 + (size_t)(grp * PER + j);
-        const float v = (j & 1) ? acc[j >> 1].y : acc[j >> 1].x;
-        // an output exists once 2n+1 samples have arrived (reference savgol_stream.c:166-170)
-        if (live && t < ticks && received0 + t + 1 >= (unsigned long long)WS) out[t * streams + s] = __fmul_rn(v, dt_inv);
-    }
-}
 
 // newest min(ticks, WS) samples of the call -> their ring slots (sample q of the call lands in slot (wp0 + q) mod WS)
 __global__ __launch_bounds__(256) void sg_bank_store_tail_kernel(float *__restrict__ ring, const float *__restrict__ samples,
@@ -221,29 +158,6 @@ __global__ __launch_bounds__(256) void sg_bank_store_tail_kernel(float *__restri
     const size_t first = ticks > (size_t)ws ? ticks - (size_t)ws : 0;
     for (size_t q = first + blockIdx.y; q < ticks; q += gridDim.y)
         ring[(size_t)((wp0 + q) % (size_t)ws) * streams + s] = samples[q * streams + s];
-}
-
-template <int N>
-static int dispatch_block(int n, const float *ring, const float *samples, float *out, size_t streams, const StreamTaps &taps,
-                          int wp0, unsigned long long received0, size_t ticks, float dt_inv, hipStream_t st)
-{
-    if (n == N) {
-        const unsigned gx = (unsigned)((streams + 63) / 64);
-        for (size_t done = 0; done < ticks; done += (size_t)65535 * BLOCK_TT) {       // gridDim.y limit
-            const size_t part = ticks - done < (size_t)65535 * BLOCK_TT ? ticks - done : (size_t)65535 * BLOCK_TT;
-            hipLaunchKernelGGL((sg_bank_block_kernel<N>), dim3(gx, (unsigned)((part + BLOCK_TT - 1) / BLOCK_TT)), dim3(256), 0, st, ring,
-                               samples + done * streams, out + done * streams, streams, taps,
-                               (int)((wp0 + done) % (size_t)(2 * N + 1)), received0 + done, part, dt_inv);
-            // rows of a later part that reach back before it come out of `samples` only if the ring is current:
-            // keep the ring in step between parts
-            hipLaunchKernelGGL(sg_bank_store_tail_kernel, dim3((unsigned)((streams + 255) / 256), 8), dim3(256), 0, st,
-                               const_cast<float *>(ring), samples + done * streams, streams, 2 * N + 1,
-                               (int)((wp0 + done) % (size_t)(2 * N + 1)), part);
-        }
-        return 1;
-    }
-    if constexpr (N < SAVGOL_MAX_HALF_WINDOW) return dispatch_block<N + 1>(n, ring, samples, out, streams, taps, wp0, received0, ticks, dt_inv, st);
-    else return 0;
 }
 
 // One tick with every load in flight at once: half window known at compile time, so the 2n ring rows a stream needs
@@ -752,35 +666,30 @@ int savgol_streambank_push_full(SavgolStreamBank *bank, const float *d_samples, 
     return rows.count;
 }
 
-// SAVGOL_HIP_STREAM_BLOCK_KERNEL=1 forces the LDS-tiled block kernel (diagnostics / A-B timing)
-static int method_env()
-{
-    static const int v = [] { const char *e = getenv("SAVGOL_HIP_STREAM_BLOCK_KERNEL"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
 int savgol_streambank_push_block(SavgolStreamBank *bank, const float *d_samples, size_t ticks, float *d_out, void *stream)
 {
     if (!bank || !d_samples || !d_out) { sg_set_error("savgol_streambank_push_block: NULL pointer"); return -1; }
     if (!sg::bank_on_current_device(bank, "savgol_streambank_push_block")) return -1;
     if (ticks == 0) return 0;
     const int ws = bank->filter->window_size;
-    sg::StreamTaps taps;
-    memset(&taps, 0, sizeof(taps));
-    memcpy(taps.w, bank->filter->center_weights, sizeof(float) * ws);
     hipStream_t st = static_cast<hipStream_t>(stream);
     sg::DeviceCtx *ctx = sg::ctx_get();
     if (!ctx) return -1;
-    if (method_env() != 1 &&
-        sg::sg_bank_roll_launch(bank->filter->config.half_window, bank->filter->center_weights, bank->d_ring, d_samples, d_out,
-                                bank->streams, bank->wp, bank->received, ticks, bank->dt_inv, (bank->flags & SAVGOL_STREAMBANK_FMA) ? 1 : 0, ctx->cu_count, st) == 0) {
-        // rolling-window kernel (n <= 16) wrote the outputs; the newest samples still have to reach the ring
+    // a launch indexes < 2^31 ticks: longer calls go part by part, the ring kept in step in between (rows of a later part that reach back before it
+    // come out of the ring).  Every half window 1..32 has a block kernel (LDS-DMA tiles where the call shape allows, else the walk / register tiles).
+    for (size_t done = 0; done < ticks;) {
+        const size_t part = ticks - done < ((size_t)1 << 30) ? ticks - done : ((size_t)1 << 30);
+        const int wp_part = (int)(((size_t)bank->wp + done) % (size_t)ws);
+        if (sg::sg_bank_roll_launch(bank->filter->config.half_window, bank->filter->center_weights, bank->d_ring, d_samples + done * bank->streams,
+                                    d_out + done * bank->streams, bank->streams, wp_part, bank->received + done, part, bank->dt_inv,
+                                    (bank->flags & SAVGOL_STREAMBANK_FMA) ? 1 : 0, ctx->cu_count, st) != 0) {
+            sg_set_error("savgol_streambank_push_block: no kernel for half_window %d", bank->filter->config.half_window);
+            return -1;
+        }
+        // the kernel wrote the outputs; the newest samples still have to reach the ring
         hipLaunchKernelGGL(sg::sg_bank_store_tail_kernel, dim3((unsigned)((bank->streams + 255) / 256), 8), dim3(256), 0, st,
-                           bank->d_ring, d_samples, bank->streams, ws, bank->wp, ticks);
-    } else if (!sg::dispatch_block<1>(bank->filter->config.half_window, bank->d_ring, d_samples, d_out, bank->streams, taps, bank->wp,
-                               bank->received, ticks, bank->dt_inv, st)) {
-        sg_set_error("savgol_streambank_push_block: no kernel for half_window %d", bank->filter->config.half_window);
-        return -1;
+                           bank->d_ring, d_samples + done * bank->streams, bank->streams, ws, wp_part, part);
+        done += part;
     }
     if (!sg::hip_ok(hipGetLastError(), "savgol_streambank_push_block launch")) return -1;
     const unsigned long long before = bank->received;

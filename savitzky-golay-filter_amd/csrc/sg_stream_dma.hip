@@ -310,16 +310,14 @@ template <int N, bool FMA, int TRT, int WPB, int DPR, int FCH = 2>
     TileGeom geo;
     geo.strips = (unsigned)(job.streams / 128);
     geo.bands = (unsigned)((job.ticks + D::TR - 1) / D::TR);
-    static const int group_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_GROUP"); return e ? atoi(e) : 0; }();
-    geo.group = group_env > 0 ? (unsigned)group_env : 128u;                                      // 64 KiB of a tick row
+    geo.group = 128u;                                                                            // 64 KiB of a tick row
     if (geo.group > geo.strips) geo.group = geo.strips;
     const unsigned groups = (geo.strips + geo.group - 1) / geo.group;
     geo.total = (unsigned long long)groups * geo.group * geo.bands;
     const unsigned long long blocks = (geo.total + WPB - 1) / WPB;
     if (geo.total >= 0x7fffff00ull) return 1;
     const unsigned grid = ((unsigned)blocks + 7u) & ~7u;
-    static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_XCD"); return e ? atoi(e) : 1; }();
-    job.aligned = 1 | (xcd_env ? 0 : 2);
+    job.aligned = 1;
     constexpr int DP = DPR < D::NI ? DPR : D::NI;                                                 // ring of row pairs (all of the tile's pairs: every load up front)
     constexpr size_t lds = (size_t)WPB * DP * 1024;
     static_assert(lds <= 160 * 1024, "slabs of one block must fit the CU's LDS");
@@ -424,7 +422,6 @@ static int launch_bank_dma_mom(const StreamMomentFit &fit, const float *center, 
     TileGeom geo;
     geo.strips = (unsigned)(job.streams / 128);
     geo.bands = (unsigned)((job.ticks + D::TR - 1) / D::TR);
-    static const int group_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA_GROUP"); return e ? atoi(e) : 0; }();
     // strips per group: 32 KiB of a tick row (64 strips), a quarter of the row for narrow banks.  Measured over FRESH ALLOCATIONS inside one process
     // (tools/placement_stream.py, profiles/r05_placement_stream.txt): with 128-strip groups config 3's launch is 0.363-0.370 ms on most placements of the
     // two buffers and 0.405-0.414 on the rest (3 of 12 to 7 of 12 from call to call); with 64-strip groups 0.373-0.397 on all of them -- the same mean, a
@@ -432,15 +429,14 @@ static int launch_bank_dma_mom(const StreamMomentFit &fit, const float *center, 
     // that do not divide an XCD's eighth of the tile order (48, 80, 96) cost 10-18 %.  (The tap-by-tap tiles keep 128: the bit-exact bank is 5 % slower on 64.)
     unsigned want = geo.strips / 4;
     want = want < 16u ? 16u : (want > 64u ? 64u : want);
-    geo.group = group_env > 0 ? (unsigned)group_env : want;
+    geo.group = want;
     if (geo.group > geo.strips) geo.group = geo.strips;
     const unsigned groups = (geo.strips + geo.group - 1) / geo.group;
     geo.total = (unsigned long long)groups * geo.group * geo.bands;
     const unsigned long long blocks = (geo.total + WPB - 1) / WPB;
     if (geo.total >= 0x7fffff00ull) return 1;
     const unsigned grid = ((unsigned)blocks + 7u) & ~7u;
-    static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_XCD"); return e ? atoi(e) : 1; }();
-    job.aligned = 1 | (xcd_env ? 0 : 2);
+    job.aligned = 1;
     constexpr int DP = DPR < D::NI ? DPR : D::NI;
     constexpr size_t lds = (size_t)WPB * DP * 1024;
     static_assert(lds <= 160 * 1024, "slabs of one block must fit the CU's LDS");

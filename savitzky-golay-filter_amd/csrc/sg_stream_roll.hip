@@ -329,7 +329,6 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg_bank_roll_kernel<N, FMA>, 256, 0) != hipSuccess || nb < 1) nb = 2;
         per_cu = nb > 4 ? 4 : nb;
         if (FMA && N <= 16 && per_cu > 2) per_cu = 2;        // fewer waves, more rows in flight each (see SRoll::P)
-        if (const char *e = getenv("SAVGOL_HIP_STREAM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 4 && v <= nb) per_cu = v; }      // A/B runs
     }
     // Where the tile form pays (profiles/r04_stream_tile.txt; config 3's shape, 65 536 streams x 4096 ... 16 384 ticks, five variants of
     // streams per lane x rows per tile x waves per block, strips per group 8 ... 256): the reference-order bank at n <= 12 (n = 4: 0.393 vs
@@ -338,24 +337,21 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
     // 0.403-0.446).  Both forms sit at 0.60-0.69 of the roofline on this 2 GB call, a 0.4 ms launch, whatever the call's length.
     if constexpr (N <= 12 && !FMA) {
         // the tile form: rows of whole 16-byte quads (the buffer range check works on whole accesses), rows < 2 GiB, at least two tiles of ticks
-        static const int tile_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_TILE"); return e ? atoi(e) : 1; }();
         const bool quads = job.streams % 4 == 0 && job.streams * 4 < 0x7fffff00ull &&
                            ((reinterpret_cast<uintptr_t>(job.samples) | reinterpret_cast<uintptr_t>(job.out) | reinterpret_cast<uintptr_t>(job.ring)) & 15u) == 0;
-        if (tile_env && quads && job.ticks >= 2 * SG_STREAM_TILE_ROWS) {
+        if (quads && job.ticks >= 2 * SG_STREAM_TILE_ROWS) {
             TileGeom geo;
             geo.strips = (unsigned)((job.streams + 64 * SG_STREAM_TILE_SPL - 1) / (64 * SG_STREAM_TILE_SPL));
             geo.bands = (unsigned)((job.ticks + SG_STREAM_TILE_ROWS - 1) / SG_STREAM_TILE_ROWS);
             // strips per group: (TR + 2N) rows x group KiB should stay well inside an XCD's 4 MiB L2 beside the rows in flight
-            static const int group_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_TILE_GROUP"); return e ? atoi(e) : 0; }();
-            geo.group = group_env > 0 ? (unsigned)group_env : (unsigned)(256 / SG_STREAM_TILE_SPL);      // 64 KiB of a tick row
+            geo.group = (unsigned)(256 / SG_STREAM_TILE_SPL);      // 64 KiB of a tick row
             if (geo.group > geo.strips) geo.group = geo.strips;
             const unsigned groups = (geo.strips + geo.group - 1) / geo.group;
             geo.total = (unsigned long long)groups * geo.group * geo.bands;
             const unsigned long long blocks = (geo.total + SG_STREAM_TILE_WPB - 1) / SG_STREAM_TILE_WPB;
             if (blocks < 0x7fffff00ull) {
                 unsigned grid = ((unsigned)blocks + 7u) & ~7u;
-                static const int xcd_tile = [] { const char *e = getenv("SAVGOL_HIP_STREAM_XCD"); return e ? atoi(e) : 1; }();
-                job.aligned = 1 | (xcd_tile ? 0 : 2);
+                job.aligned = 1;
                 hipLaunchKernelGGL((sg_bank_tile_kernel<N, FMA>), dim3(grid), dim3(64 * SG_STREAM_TILE_WPB), 0, st, job, taps, geo);
                 return 0;
             }
@@ -398,17 +394,7 @@ static int launch_bank_roll(const float *center, BankJob job, int cu_count, hipS
     grid = (grid + 7u) & ~7u;
     job.aligned = (job.streams % 2 == 0 && ((reinterpret_cast<uintptr_t>(job.samples) | reinterpret_cast<uintptr_t>(job.out) |
                                               reinterpret_cast<uintptr_t>(job.ring)) & 7u) == 0) ? 1 : 0;
-    static const int xcd_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_XCD"); return e ? atoi(e) : 0; }();
-    if (!xcd_env) job.aligned |= 2;
-    static const int one_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_ONEWAVE"); return e ? atoi(e) : 0; }();     // A/B: one item per wave, blocks in order
-    if (one_env) {
-        size_t b2 = job.ticks / (size_t)(one_env > 1 ? one_env : 256);
-        if (b2 < 1) b2 = 1;
-        job.band_ticks = (int)((job.ticks + b2 - 1) / b2);
-        job.bands = (unsigned)((job.ticks + (size_t)job.band_ticks - 1) / (size_t)job.band_ticks);
-        grid = (unsigned)(((unsigned long long)job.strips * job.bands + 3) / 4);
-        grid = (grid + 7u) & ~7u;
-    }
+    job.aligned |= 2;                                        // the walk's items in launch order (the XCD order lost, R3)
     hipLaunchKernelGGL((sg_bank_roll_kernel<N, FMA>), dim3(grid), dim3(256), 0, st, job, taps);
     return 0;
 }

@@ -316,7 +316,6 @@ int savgol_streambank_service_start(SavgolStreamBank *bank, unsigned idle_ms)
     sg::BankService *s = new sg::BankService();
     s->waves = (unsigned)waves;
     s->idle_ms = idle_ms ? idle_ms : 1000;
-    if (const char *e = getenv("SAVGOL_HIP_SERVICE_BELLS")) { const int b = atoi(e); if (b >= 1 && b <= (int)sg::SERVICE_BELLS) s->bells = (unsigned)b; }      // tuning knob
     hipDeviceProp_t prop;
     bool ok = sg::hip_ok(hipGetDeviceProperties(&prop, bank->device), who);
     if (ok) {
@@ -334,9 +333,8 @@ int savgol_streambank_service_start(SavgolStreamBank *bank, unsigned idle_ms)
          sg::hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->done_dev), done, 0), who);
     s->done_host = done;
     // the mailbox: host-writable device memory where the whole of it is visible to the host (large BAR: the doorbell is one
-    // posted write and the waves poll their own memory), pinned host memory otherwise (SAVGOL_HIP_SERVICE_HOST_BELL=1 forces it)
-    static const bool force_host = getenv("SAVGOL_HIP_SERVICE_HOST_BELL") != nullptr;
-    if (ok && prop.isLargeBar && !force_host) {
+    // posted write and the waves poll their own memory), pinned host memory otherwise
+    if (ok && prop.isLargeBar) {
         void *p = nullptr;
         if (hipExtMallocWithFlags(&p, sizeof(sg::ServiceMailbox) * sg::SERVICE_BELLS, hipDeviceMallocFinegrained) == hipSuccess) {
             if (sg::host_can_write_device_memory(p)) {

@@ -1,7 +1,7 @@
-"""Host logic of the wide-window (half windows 24..32) fast path (csrc/sg_k1d_moment_fit.cpp), no GPU needed: the constant table the kernel
-reads is rebuilt into outputs with the kernel's own arithmetic (fp32 FMA chains in the kernel's order, emulated in numpy)
-and compared with the fp64 oracle.  The reference loop this path replaces: savgol_apply centre loop,
-/root/reference/src/savgolFilter.c:763-766 with convolve_ilp :547-580."""
+"""Host logic of the fp32 block-moment kernel (csrc/sg_k1d_momenth.hpp, half windows 20..32; host fit: csrc/sg_k1d_moment_fit.cpp), no GPU needed:
+the constant table the kernel reads is rebuilt into outputs with the kernel's own arithmetic (fp32 FMA chains in the kernel's order, emulated in
+numpy) and compared with the fp64 oracle.  The reference loop this path replaces: savgol_apply centre loop,
+/root/reference/src/savgolFilter.c:763-766 with convolve_ilp :547-580.  (Round 2's whole-lane form and its table went in round 6.)"""
 import ctypes as C
 
 import numpy as np
@@ -9,7 +9,7 @@ import pytest
 
 from oracle import sgo
 
-OFF_W, OFF_PHI, OFF_C, FLOATS = 0, 80, 176, 400
+FLOATS = 400
 f32, f64 = np.float32, np.float64
 
 
@@ -17,132 +17,7 @@ def fma(a, b, c):                       # one rounding, like v_fma_f32 / v_pk_fm
     return (f64(a) * f64(b) + f64(c)).astype(f32)
 
 
-def table_for(sg, n, m, d):
-    L = sg.lib()
-    cfg = sg.SavgolConfig(n, m, d, 1.0, 0)
-    f = L.savgol_create(C.byref(cfg))
-    assert f
-    tab = np.zeros(FLOATS, f32)
-    terms = L.savgol_hip_moment_table(f, tab.ctypes.data_as(C.POINTER(C.c_float)))
-    w = np.array(f.contents.center_weights[:2 * n + 1], f32)
-    L.savgol_destroy(f)
-    return terms, tab, w
-
-
-def geometry(n):
-    """csrc/sg_k1d_host.hpp: moment_off / moment_lo / moment_hi"""
-    off = (n + 3) // 4 * 4 - n
-    return off, (31 + off + 1) // 2 * 2, (off + 2 * n + 1) // 2 * 2
-
-
-def emulate(tab, terms, x, n):
-    """outputs of every 32-sample lane block of x (x has n halo samples each side), kernel order: head taps, block moments
-    (even / odd chains), tail taps.  A lane's window is X[0 .. 32 + 2n + OFF) with X[OFF] = the first sample output 0 reads."""
-    off, lo, hi = geometry(n)
-    bk = hi - lo
-    w = tab[OFF_W:OFF_W + 66]
-    lanes = (len(x) - 2 * n) // 32
-    xp = np.concatenate([np.zeros(off, f32), x, np.zeros(8, f32)])      # X[i] = xp[32 l + i]
-    X = np.stack([xp[32 * l:32 * l + 32 + 2 * n + off + 4] for l in range(lanes)])
-    phi = np.ones((terms, bk), f32)
-    for s in range(1, terms):
-        half = tab[OFF_PHI + (s - 1) * 16:OFF_PHI + (s - 1) * 16 + bk // 2]
-        phi[s, :bk // 2] = half
-        phi[s, bk // 2:] = half[::-1] * (f32(-1) if s & 1 else f32(1))
-    c = np.zeros((terms, 32), f32)
-    for s in range(terms):
-        c[s] = tab[OFF_C + s * 32:OFF_C + (s + 1) * 32]
-    mu = np.zeros((terms, lanes), f32)
-    for s in range(terms):
-        ae, ao = np.zeros(lanes, f32), np.zeros(lanes, f32)
-        for i in range(bk // 2):
-            ae = fma(phi[s, 2 * i], X[:, lo + 2 * i], ae)
-            ao = fma(phi[s, 2 * i + 1], X[:, lo + 2 * i + 1], ao)
-        mu[s] = ae + ao
-    out = np.zeros((lanes, 32), f32)
-    for r in range(32):
-        a = np.zeros(lanes, f32)
-        for i in range(r + off, lo):
-            a = fma(w[i - r - off], X[:, i], a)
-        for s in range(terms):
-            a = fma(c[s, r], mu[s], a)
-        for i in range(hi, r + off + 2 * n + 1):
-            a = fma(w[i - r - off], X[:, i], a)
-        out[:, r] = a
-    return out.reshape(-1)
-
-
-@pytest.mark.parametrize("n", [32, 31, 30, 29, 28, 27, 26, 25, 24])
-@pytest.mark.parametrize("m,d,terms_expected,tol", [(4, 0, 5, 1e-6), (2, 0, 3, 1e-6), (3, 0, 3, 1e-6), (6, 0, 7, 1e-6),
-                                                    (4, 1, 5, 2e-6), (4, 2, 5, 4e-6), (5, 1, 7, 2e-6), (0, 0, 3, 1e-6)])
-def test_table_reproduces_the_filter(sg, n, m, d, terms_expected, tol):
-    terms, tab, w = table_for(sg, n, m, d)
-    assert terms == terms_expected
-    assert np.array_equal(tab[OFF_W:OFF_W + 2 * n + 1], w) and not tab[2 * n + 1:66].any()
-    off, lo, hi = geometry(n)
-    assert lo % 2 == 0 and hi % 2 == 0 and lo >= 31 + off and hi <= off + 2 * n + 1 and 16 <= hi - lo <= 32     # inside every window
-    x = sgo.synth_f32(5, 1, 32 * 64 + 2 * n)[0]
-    got = emulate(tab, terms, x, n)
-    ref = np.convolve(x.astype(f64), w[::-1].astype(f64), "valid")[:len(got)]
-    err = np.max(np.abs(got - ref)) / np.max(np.abs(ref))
-    assert err < tol, f"m={m} d={d}: normwise error {err:.3e}"
-
-
-def test_paths_that_keep_the_plain_sum(sg):
-    assert table_for(sg, 32, 8, 0)[0] == 0            # poly_order > 6
-    assert table_for(sg, 16, 4, 0)[0] == 0 and table_for(sg, 23, 4, 0)[0] == 0      # half windows below 24
-    # a hand-edited table is not a polynomial: the fit must refuse it
-    L = sg.lib()
-    cfg = sg.SavgolConfig(32, 4, 0, 1.0, 0)
-    f = L.savgol_create(C.byref(cfg))
-    f.contents.center_weights[10] += 1e-4
-    tab = np.zeros(FLOATS, f32)
-    assert L.savgol_hip_moment_table(f, tab.ctypes.data_as(C.POINTER(C.c_float))) == 0
-    L.savgol_destroy(f)
-    assert L.savgol_hip_moment_table(None, tab.ctypes.data_as(C.POINTER(C.c_float))) == -1
-
-
-def test_every_moment_table_is_compatible_with_the_1e6_bar(sg):
-    """the fit accepts a polynomial that reproduces each fp32 tap to 3e-7 of the largest one; 32 such taps
-    could add up.  So bound what actually reaches an output, for EVERY filter savgol_create builds at half windows 24..32
-    (every poly_order, every derivative): the kernel replaces the taps on the lanes' common block by sum_s c_s(r) phi_s(t), so
-    output r carries the error  E_r = sum_t |sum_s c_s(r) phi_s(t) - w[lo + t - r - off]|  per unit of input amplitude, against
-    sum |w| -- the largest output unit-amplitude input can produce.  E_r / sum|w| must leave the fp32 rounding of the remaining
-    2n+1-term sum (measured 3-5e-7, test above and the GPU suite) inside 1e-6: the bound asserted here is 3e-7, the worst table
-    measures well under it (printed with -s)."""
-    worst = (0.0, None)
-    covered = 0
-    for n in range(24, 33):
-        off, lo, hi = geometry(n)
-        bk = hi - lo
-        for m in range(0, 11):
-            for d in range(0, min(m, 4) + 1):
-                if 2 * n + m + 1 >= 76:
-                    continue
-                terms, tab, w = table_for(sg, n, m, d)
-                if terms == 0:
-                    assert m > 6 or (m - d) > 6 or True          # higher orders keep the plain sum (checked in the test below)
-                    continue
-                covered += 1
-                phi = np.ones((terms, bk), f64)
-                for s in range(1, terms):
-                    half = tab[OFF_PHI + (s - 1) * 16:OFF_PHI + (s - 1) * 16 + bk // 2].astype(f64)
-                    phi[s, :bk // 2] = half
-                    phi[s, bk // 2:] = half[::-1] * (-1.0 if s & 1 else 1.0)
-                c = np.stack([tab[OFF_C + s * 32:OFF_C + (s + 1) * 32].astype(f64) for s in range(terms)])       # [s][r]
-                w_eff = c.T @ phi                                                                                   # [r][t]
-                sum_abs = np.sum(np.abs(w.astype(f64)))
-                for r in range(32):
-                    true = w[lo - r - off:hi - r - off].astype(f64)
-                    e = float(np.sum(np.abs(w_eff[r] - true)) / sum_abs)
-                    if e > worst[0]:
-                        worst = (e, (n, m, d, r, terms))
-    print(f"moment tables checked: {covered}; worst block error / sum|w| = {worst[0]:.3e} at (n, m, d, r, terms) = {worst[1]}")
-    assert covered >= 9 * 20
-    assert worst[0] <= 1.5e-7, worst               # measured 7.5e-8: half of what the comment above budgets
-
-
-# ---- round 5: the half-lane form (csrc/sg_k1d_momenth.hpp; table layout in csrc/sg_k1d_host.hpp) ----
+# ---- the half-lane form (csrc/sg_k1d_momenth.hpp; table layout in csrc/sg_k1d_host.hpp) ----
 H_OFF_W, H_OFF_PHI, H_OFF_C = 0, 132, 276
 
 
@@ -218,3 +93,55 @@ def test_half_lane_table_reproduces_the_filter(sg, n, m, d, terms_expected, tol)
     ref = np.convolve(x.astype(f64), w[::-1].astype(f64), "valid")[:len(got)]
     err = np.max(np.abs(got - ref)) / np.max(np.abs(ref))
     assert err < tol, f"n={n} m={m} d={d}: normwise error {err:.3e}"
+
+
+def test_paths_that_keep_the_plain_sum(sg):
+    assert table_h(sg, 32, 8, 0)[0] == 0            # poly_order > 6
+    assert table_h(sg, 16, 4, 0)[0] == 0 and table_h(sg, 19, 4, 0)[0] == 0      # half windows below MOMENTH_MIN_N = 20
+    # a hand-edited table is not a polynomial: the fit must refuse it
+    L = sg.lib()
+    cfg = sg.SavgolConfig(32, 4, 0, 1.0, 0)
+    f = L.savgol_create(C.byref(cfg))
+    f.contents.center_weights[10] += 1e-4
+    tab = np.zeros(FLOATS, f32)
+    assert L.savgol_hip_momenth_table(f, tab.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    L.savgol_destroy(f)
+    assert L.savgol_hip_momenth_table(None, tab.ctypes.data_as(C.POINTER(C.c_float))) == -1
+
+
+def test_every_moment_table_is_compatible_with_the_1e6_bar(sg):
+    """the fit accepts a polynomial that reproduces each fp32 tap to 3e-7 of the largest one; the taps of a whole block could
+    add up.  So bound what actually reaches an output, for EVERY filter savgol_create builds at half windows 20..32 (every poly_order, every
+    derivative): the kernel replaces the taps on a group's common block by sum_s c_s(r) phi_s(t), so output r carries the error
+    E_r = sum_t |sum_s c_s(r) phi_s(t) - w[lo + t - r - off]|  per unit of input amplitude, against sum |w| -- the largest output a unit-amplitude
+    input can produce.  E_r / sum|w| must leave the fp32 rounding of the remaining sum inside 1e-6: the worst table measures well under the 1.5e-7
+    asserted here (printed with -s)."""
+    worst = (0.0, None)
+    covered = 0
+    for n in range(20, 33):
+        off, lo, hi = geometry_h(n)
+        bk = hi - lo
+        for m in range(0, 11):
+            for d in range(0, min(m, 4) + 1):
+                if 2 * n + m + 1 >= 76:
+                    continue
+                terms, tab, w = table_h(sg, n, m, d)
+                if terms == 0:
+                    continue
+                covered += 1
+                phi = np.ones((terms, bk), f64)
+                for s in range(1, terms):
+                    half = np.array([tab[H_OFF_PHI + ((t // 2) * 6 + s - 1) * 2 + (t & 1)] for t in range(bk // 2)], f64)
+                    phi[s, :bk // 2] = half
+                    phi[s, bk // 2:] = half[::-1] * (-1.0 if s & 1 else 1.0)
+                c = np.stack([tab[H_OFF_C + s * 16:H_OFF_C + (s + 1) * 16].astype(f64) for s in range(terms)])       # [s][r]
+                w_eff = c.T @ phi                                                                                   # [r][t]
+                sum_abs = np.sum(np.abs(w.astype(f64)))
+                for r in range(16):
+                    true = w[lo - r - off:hi - r - off].astype(f64)
+                    e = float(np.sum(np.abs(w_eff[r] - true)) / sum_abs)
+                    if e > worst[0]:
+                        worst = (e, (n, m, d, r, terms))
+    print(f"moment tables checked: {covered}; worst block error / sum|w| = {worst[0]:.3e} at (n, m, d, r, terms) = {worst[1]}")
+    assert covered >= 13 * 18
+    assert worst[0] <= 1.5e-7, worst

@@ -17,7 +17,7 @@ int main()
                 f.config.half_window = (uint8_t)n; f.config.poly_order = (uint8_t)m; f.config.derivative = (uint8_t)d; f.config.time_step = 0.5f;
                 sg_weights_fill(&f);
                 float table[sg::MOMENT_TABLE_FLOATS];
-                fits += sg1d_moment_prepare(n, f.center_weights, table) != 0;
+                fits += sg1d_momenth_prepare(n, f.center_weights, table) != 0;
                 std::vector<char> buf(1);
                 const long need = savgol_export_header(&f, (n & 1) ? "pfx" : nullptr, "T", buf.data(), 1);
                 buf.resize((size_t)need + 1);
