@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def kernel_source_sha(files=None):
     """sha256 over the sources that define the 1-D batch kernels (bench.py compares this with the summary's)."""
-    files = files or ["sg_k1d.hpp", "sg_k1d_host.hpp", "sg_k1d_inst.hip", "sg_k1d_moment.hpp", "sg_k1d_moment.hip", "sg_k1d_momenth.hpp", "sg_k1d_momenth.hip", "sg_k1d_moment64.hpp", "sg_k1d_moment64.hip",
+    files = files or ["sg_k1d.hpp", "sg_k1d_host.hpp", "sg_k1d_inst.hip", "sg_k1d_momenth.hpp", "sg_k1d_momenth.hip", "sg_k1d_moment64.hpp", "sg_k1d_moment64.hip",
                       "sg_k1d_moment_fit.cpp", "sg_pk.hpp", "sg_api_1d.cpp"]
     h = hashlib.sha256()
     for f in files:
