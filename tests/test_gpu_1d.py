@@ -542,6 +542,43 @@ def test_plain_summation_option_and_moment_path_agree(sg, sgo, torch_gpu, n):
     assert np.array_equal(a, b)
 
 
+def test_f64_tolerance_call_picks_the_kernel(sg, sgo, torch_gpu):
+    """savgol_apply[_valid]_batch_f64_tol (round 6): the accuracy the caller states picks the kernel.  rel_tol >= 1e-6 at half
+    windows 24..32 = the block-moment kernel (other bits than the default, <= 1e-6 -- measured ~1e-7 -- of the fp64 oracle); a tighter rel_tol, half
+    windows outside 24..32 and tables that are not a polynomial = the tap-by-tap kernel (the default's bits, 1e-12); the _ex flag is the same choice;
+    NaN / negative tolerances are refused.  Reference loop: /root/reference/src/savgolFilter.c:763-766 on fp64 data (oracle: SURVEY 8c)."""
+    torch = torch_gpu
+    x = torch.empty((5, 30011), dtype=torch.float64, device="cuda")
+    sg.synth(x, channel0=3)
+    xh = x.cpu().numpy()
+    for n, m, d, mode in ((32, 4, 2, 0), (28, 4, 0, 1), (24, 3, 1, 2), (20, 4, 0, 3), (8, 2, 0, 0)):
+        f = sg.Filter(n, m, d, 0.5, mode)
+        ref = sgo.Filter(n, m, d, 0.5, mode).apply_f64(xh)
+        for valid in (False, True):
+            want = ref[:, n:-n] if valid else ref
+            shape = (5, 30011 - 2 * n) if valid else (5, 30011)
+            y0, y6, y9, yf = (torch.empty(shape, dtype=torch.float64, device="cuda") for _ in range(4))
+            f.apply_batch(x, y0, 5, 30011, dtype="f64", valid=valid)
+            f.apply_batch(x, y6, 5, 30011, dtype="f64", valid=valid, rel_tol=1e-6)
+            f.apply_batch(x, y9, 5, 30011, dtype="f64", valid=valid, rel_tol=1e-9)
+            f.apply_batch(x, yf, 5, 30011, dtype="f64", valid=valid, flags=sg.SAVGOL_BATCH_MOMENT_F64)
+            torch.cuda.synchronize()
+            assert normwise(y0.cpu().numpy(), want) < TOL_F64
+            assert torch.equal(y9, y0), (n, valid)                         # a tolerance below 1e-6 keeps the 1e-12 path
+            assert torch.equal(yf, y6), (n, valid)                         # the flag is the same choice
+            e6 = normwise(y6.cpu().numpy(), want)
+            if 24 <= n <= 32:
+                assert not torch.equal(y6, y0), (n, valid)                 # another kernel ...
+                check(e6, 1e-6, ("f64 tolerance call", n, m, d, mode, valid))      # ... inside the tolerance it was given
+            else:
+                assert torch.equal(y6, y0), (n, valid)                     # no block-moment kernel at this half window: the default
+    f = sg.Filter(32, 4, 0, 1.0, 0)
+    y = torch.empty_like(x)
+    for bad in (float("nan"), -1.0):
+        with pytest.raises(RuntimeError, match="rel_tol"):
+            f.apply_batch(x, y, 5, 30011, dtype="f64", rel_tol=bad)
+
+
 @pytest.mark.parametrize("n", [32, 31, 30, 29, 28, 27, 26, 25, 24])
 def test_fp64_block_moment_opt_in(sg, sgo, torch_gpu, n):
     """SAVGOL_BATCH_MOMENT_F64 (round 5, csrc/sg_k1d_moment64.hpp; reference loop src/savgolFilter.c:763-766 on fp64 data, oracle: SURVEY 8c's

@@ -237,6 +237,44 @@ def test_rolling_window_kernel_all_half_windows(sg, sgo, torch_gpu, n):
                 check(normwise(g, t), 2 * fp32_bar(0.0) if dx + dy == 0 and order <= 4 else 8e-6, ("rolling vs tile-sep", n, order, dx, dy, b))
 
 
+@pytest.mark.parametrize("n", list(range(1, 17)))
+def test_pass_order_kernels_every_half_window(sg, sgo, torch_gpu, n):
+    """Round 6: the kernels that run the cancelling pass FIRST, at every half window, against the double oracle under the one
+    rule bar2d() -- no second-derivative constant.
+      * x-dominant frames (deriv_x >= 2, deriv_x > deriv_y) on sg_2d_hf.hip (method 2): rank 1 (order 2 / 3, d = (2,0)), rank 2 with the accumulating
+        second launch (order 4, d = (2,0)), a third derivative (order 4, d = (3,0)) and a mixed one (order 3, d = (2,1)); on a frame with 16-byte aligned rows
+        (vector strips) and on one whose width and pitch are odd (the scalar path), VALID / CONSTANT / REFLECT.
+      * y-dominant frames on the tile kernel staged transposed (method 3, d = (0,2)) and on the vertical-first rolling kernel (method 2).
+    The reference's dense loop: /root/reference/src/savgol2d.c:374-393, 417-453."""
+    torch = torch_gpu
+    rng = np.random.default_rng(4242 + n)
+    for rows, cols, stride in ((150 + 2 * n, 520, 520), (97 + 2 * n, 301, 303)):
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        x = np.zeros((2, rows, stride), np.float32)
+        for k in range(2):
+            x[k, :, :cols] = (np.sin(0.07 * xx + k) * np.cos(0.04 * yy) + 0.002 * xx + rng.normal(0, 0.1, (rows, cols))).astype(np.float32)
+        d = torch.from_numpy(x).cuda()
+        cases = [(2, 2, 0, 2), (3, 2, 0, 2), (4, 2, 0, 2), (4, 3, 0, 2), (3, 2, 1, 2), (3, 0, 2, 2), (3, 0, 2, 3), (4, 0, 2, 3)]
+        for order, dx, dy, method in cases:
+            if order > 2 * n:
+                continue
+            f = sg.Filter2D(n, n, order, dx, dy, 0.5, 2.0)
+            o = sgo.Filter2D(n, n, order, dx, dy, 0.5, 2.0)
+            for b in range(3):
+                got = torch.full_like(d, -5.0)
+                f.apply_batch(d, got, rows, cols, 2, in_stride=stride, out_stride=stride, boundary=b, method=method)
+                g = got.cpu().numpy()
+                sel = np.zeros((rows, stride), bool)
+                if b == 0:
+                    sel[n:rows - n, n:cols - n] = True
+                else:
+                    sel[:, :cols] = True
+                for k in range(2):
+                    assert np.all(g[k][~sel] == -5.0), (n, order, dx, dy, b, method)
+                    hi = o.apply_f64acc(x[k], cols, b)
+                    check(normwise(g[k][sel], hi[sel]), bar2d(o, x[k], cols, b, hi, sel), ("pass order", n, order, dx, dy, b, method, cols, k))
+
+
 def test_rolling_window_kernel_small_and_odd_frames(sg, sgo, torch_gpu):
     """Frames smaller than the window (padded modes), one-row / one-column frames, unaligned strides and bases."""
     torch = torch_gpu
