@@ -261,26 +261,73 @@ static bool frames_overlap(const float *a, long long a_pitch, int a_stride, cons
 // Kernels whose x factor cancels harder than their y factor (sg2d_x_dominant: d^2/dx^2, the Hessian's xx frame, ...) run the HORIZONTAL pass first
 // (sg_2d_hf.hip): one launch per term, the later ones accumulating.  1 = not covered (no definite parity): the caller falls back to the
 // vertical-first kernels, nothing has been launched.
-static int roll_passes_hf(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
+// What each term's x factor must SUM to (sg_2d_hf.hip, convert()): the horizontal-first kernel applies its taps to centred samples, s_k - c, and adds
+// c * sigma_t back -- with sigma_t taken from the REFERENCE's dense fp32 table instead of the rounded factor taps: least squares over the window rows y of
+//      scale * sum_x W[y][x]  ~=  sum_t sigma_t G_t(y)          (G_t = the fp32 column factors as the kernel mirrors them)
+// so that a constant (or slowly varying) part of the input comes out as the reference's own table maps it.  A failed solve gives zeros (the centred pass alone).
+static void hf_term_sums(int n, int terms, const float *factors, const Savgol2DFilter *dense, float *sigma)
+{
+    const int ws = 2 * n + 1, nx = dense->config.half_window_x, ny = dense->config.half_window_y, ww = 2 * nx + 1;
+    double rs[2 * SAVGOL2D_MAX_HALF_WINDOW + 1] = {0.0}, G[SEP_MAX_TERMS][2 * SAVGOL2D_MAX_HALF_WINDOW + 1];
+    for (int t = 0; t < terms; ++t) sigma[t] = 0.0f;
+    if (terms < 1 || terms > SEP_MAX_TERMS || ny > n || nx > n) return;
+    for (int y = 0; y <= 2 * ny; ++y) {
+        double acc = 0.0;
+        for (int x = 0; x < ww; ++x) acc += (double)dense->weights[y * ww + x];
+        rs[(n - ny) + y] = acc * (double)dense->scale;
+    }
+    for (int t = 0; t < terms; ++t) {
+        const float *g = factors + (size_t)t * 2 * (ws + 1) + (ws + 1);
+        float sy = 1.0f;
+        if (!vector_parity(g, n, &sy)) return;
+        for (int y = 0; y < ws; ++y) G[t][y] = y <= n ? (double)((y == n && sy < 0.0f) ? 0.0f : g[y]) : (double)sy * (double)g[2 * n - y];
+    }
+    double A[SEP_MAX_TERMS][SEP_MAX_TERMS + 1];
+    for (int t = 0; t < terms; ++t) {
+        for (int u = 0; u < terms; ++u) { double d = 0.0; for (int y = 0; y < ws; ++y) d += G[t][y] * G[u][y]; A[t][u] = d; }
+        double d = 0.0;
+        for (int y = 0; y < ws; ++y) d += G[t][y] * rs[y];
+        A[t][terms] = d;
+    }
+    for (int c = 0; c < terms; ++c) {                                  // Gaussian elimination with partial pivoting (<= 4 x 4)
+        int piv = c;
+        for (int r = c + 1; r < terms; ++r) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+        if (std::fabs(A[piv][c]) < 1e-300) return;
+        if (piv != c) for (int j = 0; j <= terms; ++j) { const double tmp = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = tmp; }
+        for (int r = c + 1; r < terms; ++r) { const double fct = A[r][c] / A[c][c]; for (int j = c; j <= terms; ++j) A[r][j] -= fct * A[c][j]; }
+    }
+    double sol[SEP_MAX_TERMS];
+    for (int i = terms - 1; i >= 0; --i) {
+        double v = A[i][terms];
+        for (int j = i + 1; j < terms; ++j) v -= A[i][j] * sol[j];
+        sol[i] = v / A[i][i];
+    }
+    for (int t = 0; t < terms; ++t) sigma[t] = (float)sol[t];
+}
+
+static int roll_passes_hf(int n, int terms, const Job2D &job, const float *factors, float scale, const Savgol2DFilter *dense, unsigned images, int cu_count, hipStream_t st)
 {
     const size_t tstride = (size_t)2 * (2 * n + 2);
     for (int t = 0; t < terms; ++t) {
         float s;
         if (!vector_parity(factors + t * tstride, n, &s) || !vector_parity(factors + t * tstride + (2 * n + 2), n, &s)) return 1;
     }
+    float sigma[SEP_MAX_TERMS] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (dense && terms <= SEP_MAX_TERMS) hf_term_sums(n, terms, factors, dense, sigma);
     Job2D j = job;
     for (int t = 0; t < terms; ++t) {
-        const int rc = sg2d_launch_rolling_hf(n, j, factors + t * tstride, scale, images, cu_count, st);
+        const int rc = sg2d_launch_rolling_hf(n, j, factors + t * tstride, scale, t < SEP_MAX_TERMS ? sigma[t] : 0.0f, images, cu_count, st);
         if (rc != 0) return t == 0 ? rc : -1;
         j.accumulate = 1;
     }
     return 0;
 }
 
-static int roll_passes(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st, bool hfirst = false)
+static int roll_passes(int n, int terms, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st,
+                       const Savgol2DFilter *hfirst_dense = nullptr)
 {
-    if (hfirst && !job.accumulate) {
-        const int rc = roll_passes_hf(n, terms, job, factors, scale, images, cu_count, st);
+    if (hfirst_dense && !job.accumulate) {       // x-dominant kernel: horizontal pass first; the filter brings the dense table the term sums are fitted to
+        const int rc = roll_passes_hf(n, terms, job, factors, scale, hfirst_dense, images, cu_count, st);
         if (rc != 1) return rc;
     }
     int rc = sg2d_launch_rolling(n, terms, job, factors, scale, images, cu_count, st);
@@ -353,7 +400,7 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
                 job.out = d_out + (long long)i0 * out_pitch;
                 if (method != 3 || !square) {            // rolling-window kernel where it applies, else the tile kernel (square windows only)
                     const int rc = roll_passes(nmax, terms, job, factors, f->scale, (unsigned)ni, ctx->cu_count, st,
-                                               sg2d_x_dominant(f->config.deriv_x, f->config.deriv_y));
+                                               sg2d_x_dominant(f->config.deriv_x, f->config.deriv_y) ? f : nullptr);
                     if (rc == 0) continue;
                 }
                 if (!square) { all_rolled = false; break; }      // no rolling kernel of this rank at this half window: the dense kernel below
@@ -623,7 +670,11 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
             bool done = false;
             if (sg2d_x_dominant(specs[o].dx, specs[o].dy)) {
                 job.out = plan.out[o];
-                done = roll_passes_hf(n, plan.terms[o], job, fo, plan.scale[o], (unsigned)images, ctx->cu_count, st) == 0;
+                cfg.deriv_x = (uint8_t)specs[o].dx; cfg.deriv_y = (uint8_t)specs[o].dy;
+                bool owned = false;
+                const Savgol2DFilter *dense = rect_filter_cached(&cfg, &owned);       // the reference's dense table of this frame (cached per configuration)
+                done = dense && roll_passes_hf(n, plan.terms[o], job, fo, plan.scale[o], dense, (unsigned)images, ctx->cu_count, st) == 0;
+                if (owned) savgol2d_destroy(const_cast<Savgol2DFilter *>(dense));
             }
             if (!done) {
                 odx[rest.outputs] = specs[o].dx; ody[rest.outputs] = specs[o].dy;

@@ -160,14 +160,14 @@ inline int sg2d_launch_rolling2(int n, int terms, const Job2D &job, const float 
 
 // sg_2d_hf.hip: ONE term of a kernel with the HORIZONTAL pass first (kernels whose x factor cancels harder than their y factor: deriv_x >= 2,
 // deriv_x > deriv_y); job.accumulate: out += result.  Built in three half-window groups (Makefile).  0 = launched, 1 = not covered, -1 = error.
-int sg2d_launch_rolling_hf_g0(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
-int sg2d_launch_rolling_hf_g1(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
-int sg2d_launch_rolling_hf_g2(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st);
-inline int sg2d_launch_rolling_hf(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
+int sg2d_launch_rolling_hf_g0(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling_hf_g1(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling_hf_g2(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st);
+inline int sg2d_launch_rolling_hf(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st)
 {
-    if (sg2d_launch_rolling_hf_g0(n, job, factors, scale, images, cu_count, st) == 0) return 0;
-    if (sg2d_launch_rolling_hf_g1(n, job, factors, scale, images, cu_count, st) == 0) return 0;
-    return sg2d_launch_rolling_hf_g2(n, job, factors, scale, images, cu_count, st);
+    if (sg2d_launch_rolling_hf_g0(n, job, factors, scale, sigma, images, cu_count, st) == 0) return 0;
+    if (sg2d_launch_rolling_hf_g1(n, job, factors, scale, sigma, images, cu_count, st) == 0) return 0;
+    return sg2d_launch_rolling_hf_g2(n, job, factors, scale, sigma, images, cu_count, st);
 }
 // which pass order suits a kernel in fp32 (sg_2d_hf.hip's header, tools/emulate_2d_passes.py): the pass that cancels harder goes first
 inline bool sg2d_x_dominant(int deriv_x, int deriv_y) { return deriv_x >= 2 && deriv_x > deriv_y; }

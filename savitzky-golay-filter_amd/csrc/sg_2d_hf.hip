@@ -43,6 +43,7 @@ template <int N>
 struct HfTaps {
     f32x2 g[Hf<N>::NP], q[Hf<N>::NP];      // taps 0..N (the mirrored half follows from the parity); q already times the output scale
     f32x2 sy, sx;                           // +1 / -1
+    f32x2 sig;                              // what this term's x factor must sum to (both halves equal): see convert()
 };
 
 // MODE 1: the strip's 256 input columns are inside the frame, all SW output columns are stored, rows 16-byte aligned; 0: remapped scalar loads, masked stores
@@ -77,12 +78,18 @@ __device__ __forceinline__ void hf_item(const Job2D &job, const HfTaps<N> &taps,
         wave_lds_sync();                                     // the previous row's window reads are ordered before this write
         *reinterpret_cast<f32x4 *>(wr) = win[s];
         wave_lds_sync();
+        // CENTRED (round 6, R6.8): sum_k q_k s_k = sum_k q_k (s_k - c) + c sum_k q_k for ANY c.  With c = a sample of the lane's own window the
+        // differences are as small as the data's local variation, so an offset or a ramp under the signal no longer meets the cancelling taps at full
+        // size; and the last term takes sum_k q_k not from the rounded taps but from the REFERENCE's dense table (sig, fitted on the host: what this
+        // term must sum to for the rows of  sum_t G_t(y) sig_t  to equal the row sums of W) -- the systematic part of the taps' rounding.  Emulated
+        // (tools/emulate_2d_passes.py --centre): 1.2-2.4e-7 of the output whatever the offset, where the plain pass (and the reference's own loop) grow with it.
+        const f32x2 cc = f32x2{win[s].x, win[s].x};
         f32x2 e[2 * R::NQ + 1];
 #pragma unroll
         for (int q = 0; q < R::NQ; ++q) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(rd + 4 * q);
-            e[2 * q] = f32x2{v.x, v.y};
-            e[2 * q + 1] = f32x2{v.z, v.w};
+            e[2 * q] = f32x2{v.x, v.y} - cc;
+            e[2 * q + 1] = f32x2{v.z, v.w} - cc;
         }
         e[2 * R::NQ] = f32x2{0.0f, 0.0f};
         f32x2 pr[2 * N + 3];                                 // pr[j] = window floats (D+j, D+j+1)
@@ -110,6 +117,8 @@ __device__ __forceinline__ void hf_item(const Job2D &job, const HfTaps<N> &taps,
             else { pk_fma_sgpr<(k & 1)>(r[0], taps.q[k >> 1], f[0][k]); pk_fma_sgpr<(k & 1)>(r[1], taps.q[k >> 1], f[1][k]); }
             return true;
         });
+        r[0] = __builtin_elementwise_fma(taps.sig, cc, r[0]);
+        r[1] = __builtin_elementwise_fma(taps.sig, cc, r[1]);
         win[s] = f32x4{r[0].x, r[0].y, r[1].x, r[1].y};
     };
     // the vertical pass of the output row whose first h row sits in slot u0
@@ -223,8 +232,9 @@ __global__ __launch_bounds__(64 * Hf<N>::WPB, hf_min_waves(N)) void sg2d_rolling
 
 // ---- host ----
 template <int N>
-static bool hf_fill_taps(HfTaps<N> &taps, const float *factors, float scale)
+static bool hf_fill_taps(HfTaps<N> &taps, const float *factors, float scale, float sigma)
 {
+    taps.sig = f32x2{sigma, sigma};
     const float *q = factors, *g = q + (2 * N + 2);
     float sy, sx;
     if (!vector_parity(g, N, &sy) || !vector_parity(q, N, &sx)) return false;
@@ -283,24 +293,25 @@ static int hf_launch(const Job2D &job, const HfTaps<N> &taps, unsigned images, i
 }
 
 template <int N>
-static int hf_dispatch(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
+static int hf_dispatch(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st)
 {
     if (n == N) {
         HfTaps<N> taps;
         memset(&taps, 0, sizeof(taps));
-        if (!hf_fill_taps<N>(taps, factors, scale)) return 1;
+        if (!hf_fill_taps<N>(taps, factors, scale, sigma)) return 1;
         return job.accumulate ? hf_launch<N, true>(job, taps, images, cu_count, st) : hf_launch<N, false>(job, taps, images, cu_count, st);
     }
-    if constexpr (N < SG_HF_MAX_N) return hf_dispatch<N + 1>(n, job, factors, scale, images, cu_count, st);
+    if constexpr (N < SG_HF_MAX_N) return hf_dispatch<N + 1>(n, job, factors, scale, sigma, images, cu_count, st);
     else return 1;
 }
 
-// ONE term (factors: Q[0..2N], pad, G[0..2N], pad) of a kernel, horizontal pass first; job.accumulate: out += result.
+// ONE term (factors: Q[0..2N], pad, G[0..2N], pad) of a kernel, horizontal pass first; job.accumulate: out += result.  sigma: what this term's scaled x
+// factor sums to in the reference's dense table (sg_2d.hip: hf_term_sums).
 // 0 = launched, 1 = not covered by this object (half window outside SG_HF_MIN_N..SG_HF_MAX_N, no definite parity), -1 = error.
-int SG_HF_FN(int n, const Job2D &job, const float *factors, float scale, unsigned images, int cu_count, hipStream_t st)
+int SG_HF_FN(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st)
 {
     if (n < SG_HF_MIN_N || n > SG_HF_MAX_N) return 1;
-    return hf_dispatch<SG_HF_MIN_N>(n, job, factors, scale, images, cu_count, st);
+    return hf_dispatch<SG_HF_MIN_N>(n, job, factors, scale, sigma, images, cu_count, st);
 }
 
 }  // namespace sg

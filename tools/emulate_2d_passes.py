@@ -9,6 +9,10 @@ to fp32, folded symmetric pairs, fused multiply-adds (emulated: exact product in
   hfirst   : horizontal pass first
   vfirst_hl: vertical pass accumulates in fp32 but keeps an error-free low word for the LDS row (hi + lo), horizontal pass on both
   vfirst_64: vertical pass in double, rounded to hi + lo floats
+
+    python tools/emulate_2d_passes.py --centre
+the horizontal-first pass on data with a ramp under the signal (R6.8): plain; centred (taps applied to s_k - c, c = the window's centre sample);
+centred + c * sum(rounded taps); centred + c * sigma*, sigma* fitted to the row sums of the reference's dense table (what sg_2d_hf.hip ships).
 """
 import os
 import sys
@@ -117,6 +121,68 @@ def run(n, order, dx, dy, seed=0):
     out["rank"] = r
     return out
 
+
+f64 = np.float64
+E = sys.modules[__name__]
+
+
+def fold_center(x, taps, axis, n, scale, center, sigma_star=None):
+    """folded pass on (x - c), c = the window's own centre sample, + c * sum(taps_fp32)"""
+    t=(np.asarray(taps,f64)*scale).astype(f32)
+    sigma=float(2.0*np.sum(t[:n].astype(f64))+f64(t[n]))      # the sum of the kernel as the folded pass applies it
+    L=x.shape[axis]-2*n
+    sl=lambda k: np.take(x, range(k,k+L), axis=axis)
+    c=sl(n)
+    acc=None
+    for k in range(n+1):
+        a=(sl(k).astype(f64)-c.astype(f64)).astype(f32)
+        if k<n:
+            b=(sl(2*n-k).astype(f64)-c.astype(f64)).astype(f32)
+            f=(a.astype(f64)+b.astype(f64)).astype(f32)
+        else:
+            f=a
+        tk=np.full(f.shape,t[k],f32)
+        acc=(tk.astype(f64)*f.astype(f64)).astype(f32) if acc is None else fma32(tk,f,acc)
+    if center=='sigma':
+        acc=fma32(np.full(acc.shape,f32(sigma),f32), c, acc)
+    if center=='star':
+        acc=fma32(np.full(acc.shape,f32(sigma_star),f32), c, acc)
+    return acc
+def run_centre(n,order,dx,dy,seed=0,ramp=0.002):
+    rng=np.random.default_rng(4242+n+seed)
+    rows,cols=150+2*n,520
+    yy,xx=np.mgrid[0:rows,0:cols]
+    img=(np.sin(0.07*xx)*np.cos(0.04*yy)+ramp*xx+rng.normal(0,0.1,(rows,cols))).astype(f32)
+    o=sgo.Filter2D(n,n,order,dx,dy,0.5,2.0)
+    hi=o.apply_f64acc(img,cols,0)[n:rows-n,n:cols-n]
+    ref=o.apply(img,cols,0)[n:rows-n,n:cols-n]
+    G,Q,r=factors(o,n); sc=float(o.scale)
+    res={}
+    W=np.asarray(o.W,f64).reshape(2*n+1,2*n+1)
+    rowsum=W.sum(axis=1)*sc
+    for name in ('plain','center','sigma','star'):
+        acc=0.0
+        for t in range(r):
+            g32=np.asarray(G[t],f64).astype(f32).astype(f64)
+            star=float(np.dot(rowsum,g32)/np.dot(g32,g32))
+            if name=='plain': h=conv_fold32(img,Q[t],1,n,sc)
+            else: h=fold_center(img,Q[t],1,n,sc,name,star)
+            acc=acc+conv_fold32(h,G[t],0,n).astype(f64)
+        res[name]=normwise(np.asarray(acc).astype(f32),hi)
+    # exact-tap check: how far is the factorised kernel (fp32 taps, exact arithmetic) from the oracle?
+    acc=0.0
+    for t in range(r):
+        acc=acc+conv64(conv64(img,Q[t],1,n,1.0)*1.0,G[t],0,n)*sc if False else acc
+    res['ref']=normwise(ref,hi)
+    return res
+
+
+if __name__ == "__main__" and "--centre" in sys.argv:
+    for n, order in ((3, 2), (5, 2), (6, 2), (7, 3), (10, 4), (16, 3)):
+        for ramp in (0.002, 0.02, 0.2):
+            r = run_centre(n, order, 2, 0, ramp=ramp)
+            print(f"n={n:2d} order={order} d=(2,0) ramp {ramp:5.3f}/px: " + "  ".join(f"{k} {v:.2e}" for k, v in r.items()), flush=True)
+    sys.exit(0)
 
 if __name__ == "__main__":
     for n, order, dx, dy in ((3, 2, 2, 0), (3, 2, 0, 2), (7, 4, 2, 0), (7, 4, 0, 2), (7, 3, 2, 0), (7, 3, 0, 2), (7, 3, 1, 1), (5, 6, 0, 2), (5, 6, 2, 0), (12, 3, 2, 0), (16, 4, 2, 0)):
