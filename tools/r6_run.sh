@@ -1,8 +1,6 @@
 # Scratch script of round 6's GPU calls (rewritten per call: `gpurun -- 'bash tools/r6_run.sh'`).
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r6
-ONLY=image bash tools/run_profiles_r6.sh > gpurun_out/r6_prof_image.log 2>&1
-cd "${GRAFT_REPO_ROOT:-.}"
-rm -f gpurun_out/r6/parity.jsonl
-SAVGOL_PARITY_LOG=$PWD/gpurun_out/r6/parity.jsonl timeout 2700 python -m pytest tests -q -m gpu 2>&1 | tail -40 > gpurun_out/r6/gputests.txt
-python tools/parity_margins.py gpurun_out/r6/parity.jsonl > gpurun_out/r6/parity_margins.txt 2>&1
-grep -E "passed|failed" gpurun_out/r6/gputests.txt; grep -c OVER gpurun_out/r6/parity_margins.txt; head -1 gpurun_out/r6/parity_margins.txt; ls gpurun_out/r6_prof | grep image
+timeout 900 python -m pytest tests/test_gpu_stream.py -q -m gpu 2>&1 | tail -4 > gpurun_out/r6/gputests_stream.txt
+L=savitzky-golay-filter_amd/lib/libsavgol_hip.so
+for n in 16 8 24 32; do timeout 300 python tools/ab_stream.py $L tools/ab/lib_momexp.so --fma 0 --n $n --m 2 --d 1; done > gpurun_out/r6/stream_chunk8_ab.txt 2>&1
+cat gpurun_out/r6/gputests_stream.txt | grep -E "passed|failed"; grep -v amdgpu gpurun_out/r6/stream_chunk8_ab.txt | tail -12
