@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORY (rounds 4-5): several switches these calls set (SAVGOL_HIP_ROLL_XCD / _TILE_CAP / _BOX, _STREAM_XCD / _TILE / _DMA_GROUP, _MOMENT_FORM, ...) and the round-2 moment objects
+# were removed in round 6 (profiles/EXPERIMENTS.md, "Round 6"): the functions below document what produced the r04_* / r05_* files, they no longer all run.
 # tools/experiments.sh NAME -- the GPU calls behind profiles/EXPERIMENTS.md, rounds 4 and 5, one function each (rounds 1-3 ran ~60 one-off
 # scripts under tools/r3/; their recipes are the command column of profiles/README.md).  Run on the GPU box from the repository root:
 #     gpurun --timeout 1500 -- 'bash tools/experiments.sh tile2d_knobs'

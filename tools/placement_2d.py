@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The 2-D frame-stack launch (savgol2d_apply_batch_f32, method 2) over FRESH ALLOCATIONS inside one process, several switches of the library side
 by side -- tools/placement_1d.py's question for config 4.
-    python tools/placement_2d.py lib.so lib.so@SAVGOL_HIP_ROLL_XCD_CHUNK_BANDS=256 ... [--images 64 --size 4096 --n 7 --boundary 1 --allocations 10]"""
+    python tools/placement_2d.py lib.so lib.so@SAVGOL_HIP_ROLL_TILE=0 tools/ab/lib_variant.so ... [--images 64 --size 4096 --n 7 --boundary 1 --allocations 10]"""
 import argparse
 import ctypes as C
 import os

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The stream block push over FRESH ALLOCATIONS inside one process (old buffers kept alive, so new physical pages back the new ones), several
 switches of the library side by side: which part of the box-to-box spread is the physical placement of the two buffers, and does any tile order
-escape it?   python tools/placement_stream.py lib.so lib.so@SAVGOL_HIP_STREAM_DMA_GROUP=64 ... [--allocations 10 --fma 1]"""
+escape it?   python tools/placement_stream.py lib.so lib.so@SAVGOL_HIP_STREAM_MOMENT=0 tools/ab/lib_variant.so ... [--allocations 10 --fma 1]"""
 import argparse
 import ctypes as C
 import os

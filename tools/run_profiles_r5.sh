@@ -1,4 +1,5 @@
 # Round 5 evidence run (one gpurun call): the driver-format bench line, five fresh-process rocprofv3 kernel traces of the headline
+# HISTORY: round 5's evidence run (--f64-moment is now the default config-5 call; see tools/run_profiles_r6.sh).
 # (VERDICT r02 next #1a), and the FETCH / WRITE / SQ counter passes of the four dominant kernels (next #1b) -- counters in their own
 # runs with --kernel-trace only, the program directly after `--`, as MI355X_MICROARCH.md prescribes.
 #   gpurun --timeout 3000 -- 'bash tools/run_profiles_r5.sh'   then   python tools/summarise_profiles_r5.py
