@@ -265,21 +265,34 @@ static bool frames_overlap(const float *a, long long a_pitch, int a_stride, cons
 // c * sigma_t back -- with sigma_t taken from the REFERENCE's dense fp32 table instead of the rounded factor taps: least squares over the window rows y of
 //      scale * sum_x W[y][x]  ~=  sum_t sigma_t G_t(y)          (G_t = the fp32 column factors as the kernel mirrors them)
 // so that a constant (or slowly varying) part of the input comes out as the reference's own table maps it.  A failed solve gives zeros (the centred pass alone).
-static void hf_term_sums(int n, int terms, const float *factors, const Savgol2DFilter *dense, float *sigma)
+// columns = true: the transposed roles (the tile kernel on y-dominant kernels, whose FIRST pass runs down the columns): what each term's y factor must sum
+// to, fitted to the table's column sums in the basis of the x factors.
+// tile = true: the tile kernel (sg_2d_sep.hip) -- taps as stored, not mirrored, and the scale left to its store.  false = no fit (sigma zeroed).
+static bool hf_term_sums(int n, int terms, const float *factors, const Savgol2DFilter *dense, float *sigma, bool columns = false, bool tile = false)
 {
     const int ws = 2 * n + 1, nx = dense->config.half_window_x, ny = dense->config.half_window_y, ww = 2 * nx + 1;
     double rs[2 * SAVGOL2D_MAX_HALF_WINDOW + 1] = {0.0}, G[SEP_MAX_TERMS][2 * SAVGOL2D_MAX_HALF_WINDOW + 1];
     for (int t = 0; t < terms; ++t) sigma[t] = 0.0f;
-    if (terms < 1 || terms > SEP_MAX_TERMS || ny > n || nx > n) return;
-    for (int y = 0; y <= 2 * ny; ++y) {
-        double acc = 0.0;
-        for (int x = 0; x < ww; ++x) acc += (double)dense->weights[y * ww + x];
-        rs[(n - ny) + y] = acc * (double)dense->scale;
+    if (terms < 1 || terms > SEP_MAX_TERMS || ny > n || nx > n) return false;
+    const double sc = tile ? 1.0 : (double)dense->scale;
+    if (!columns) {
+        for (int y = 0; y <= 2 * ny; ++y) {
+            double acc = 0.0;
+            for (int x = 0; x < ww; ++x) acc += (double)dense->weights[y * ww + x];
+            rs[(n - ny) + y] = acc * sc;
+        }
+    } else {
+        for (int x = 0; x < ww; ++x) {
+            double acc = 0.0;
+            for (int y = 0; y <= 2 * ny; ++y) acc += (double)dense->weights[y * ww + x];
+            rs[(n - nx) + x] = acc * sc;
+        }
     }
     for (int t = 0; t < terms; ++t) {
-        const float *g = factors + (size_t)t * 2 * (ws + 1) + (ws + 1);
+        const float *g = factors + (size_t)t * 2 * (ws + 1) + (columns ? 0 : (ws + 1));          // the basis: G_t (rows) or Q_t (columns)
         float sy = 1.0f;
-        if (!vector_parity(g, n, &sy)) return;
+        if (tile) { for (int y = 0; y < ws; ++y) G[t][y] = (double)g[y]; continue; }
+        if (!vector_parity(g, n, &sy)) return false;
         for (int y = 0; y < ws; ++y) G[t][y] = y <= n ? (double)((y == n && sy < 0.0f) ? 0.0f : g[y]) : (double)sy * (double)g[2 * n - y];
     }
     double A[SEP_MAX_TERMS][SEP_MAX_TERMS + 1];
@@ -292,7 +305,7 @@ static void hf_term_sums(int n, int terms, const float *factors, const Savgol2DF
     for (int c = 0; c < terms; ++c) {                                  // Gaussian elimination with partial pivoting (<= 4 x 4)
         int piv = c;
         for (int r = c + 1; r < terms; ++r) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
-        if (std::fabs(A[piv][c]) < 1e-300) return;
+        if (std::fabs(A[piv][c]) < 1e-300) return false;
         if (piv != c) for (int j = 0; j <= terms; ++j) { const double tmp = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = tmp; }
         for (int r = c + 1; r < terms; ++r) { const double fct = A[r][c] / A[c][c]; for (int j = c; j <= terms; ++j) A[r][j] -= fct * A[c][j]; }
     }
@@ -303,6 +316,7 @@ static void hf_term_sums(int n, int terms, const float *factors, const Savgol2DF
         sol[i] = v / A[i][i];
     }
     for (int t = 0; t < terms; ++t) sigma[t] = (float)sol[t];
+    return true;
 }
 
 static int roll_passes_hf(int n, int terms, const Job2D &job, const float *factors, float scale, const Savgol2DFilter *dense, unsigned images, int cu_count, hipStream_t st)
@@ -410,6 +424,9 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
                 memset(&plan, 0, sizeof(plan));
                 plan.outputs = 1; plan.terms[0] = terms; plan.scale[0] = f->scale; plan.out[0] = job.out;
                 plan.transposed = sg2d_y_dominant(f->config.deriv_x, f->config.deriv_y) ? 1 : 0;
+                if (plan.transposed || sg2d_x_dominant(f->config.deriv_x, f->config.deriv_y)) {     // a derivative kernel's cancelling pass runs first, on centred samples
+                    plan.centre = hf_term_sums(nx, terms, factors, f, plan.first_sum, plan.transposed != 0, true) ? 1 : 0;
+                }
                 if (sg2d_launch_separable(nx, job, plan, d_f, (unsigned)ni, ctx->cu_count, st) != 0) { sg_set_error("%s: no separable kernel for n=%d", who, nx); return -1; }
             }
             if (all_rolled) return hip_ok(hipGetLastError(), who) ? 0 : -1;
@@ -717,6 +734,15 @@ static int enqueue_derivatives(const char *who, int nx, int ny, int order, const
             memset(&one, 0, sizeof(one));
             one.outputs = 1; one.terms[0] = plan.terms[o]; one.scale[0] = plan.scale[o]; one.out[0] = plan.out[o];
             one.transposed = sg2d_y_dominant(odx[o], ody[o]) ? 1 : 0;       // the tile kernel's pass order (sg_2d_sep.hip)
+            if (!sum_into_one && (one.transposed || sg2d_x_dominant(odx[o], ody[o]))) {
+                cfg.deriv_x = (uint8_t)odx[o]; cfg.deriv_y = (uint8_t)ody[o];
+                bool owned = false;
+                const Savgol2DFilter *dense = rect_filter_cached(&cfg, &owned);
+                if (dense) {
+                    one.centre = hf_term_sums(n, plan.terms[o], fo, dense, one.first_sum, one.transposed != 0, true) ? 1 : 0;
+                    if (owned) savgol2d_destroy(const_cast<Savgol2DFilter *>(dense));
+                }
+            }
             const float *d_f = ctx_table(ctx, fo, sizeof(float) * (size_t)plan.terms[o] * 2 * (ws + 1), 0x6d000000u + (unsigned)n);
             if (!d_f) return -1;
             if (sg2d_launch_separable(n, job, one, d_f, (unsigned)images, ctx->cu_count, st) != 0) { sg_set_error("%s: no separable kernel for n=%d", who, n); return -1; }

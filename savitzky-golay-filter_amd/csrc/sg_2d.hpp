@@ -92,6 +92,8 @@ struct SepPlan {
     float  scale[SEP_MAX_OUTPUTS];
     float *out[SEP_MAX_OUTPUTS];        // same row stride / image pitch for all
     int    transposed;                  // 1: vertical pass first (every output y-dominant: deriv_y >= 2, deriv_y > deriv_x), see sg_2d_sep.hip
+    int    centre;                      // 1: the first pass runs on centred samples (s - c) and adds c * first_sum[t] back (derivative kernels; sg_2d_hf.hip, R6.8)
+    float  first_sum[SEP_MAX_TERMS];    // what term t's first-pass factor sums to in the reference's dense table (unscaled), single-output plans
 };
 inline bool sg2d_y_dominant(int deriv_x, int deriv_y) { return deriv_y >= 2 && deriv_y > deriv_x; }
 

@@ -195,8 +195,17 @@ __global__ __launch_bounds__(256) void sg2d_separable_kernel(const Job2D job, co
                     f32x2 A[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) A[j] = f32x2{0.0f, 0.0f};
-                    WinConv<N, 16>::template quads<0>([&](int q) { return *reinterpret_cast<const float4 *>(src + 4 * q); }, A, Wq,
-                                                      f32x2{0.0f, 0.0f});
+                    // derivative kernels (plan.centre): the taps meet centred samples, s - c with c = the sample in the middle of the segment's 16 + 2N
+                    // inputs, and c times what the factor sums to in the reference's dense table is added back -- an offset, a ramp or a slow swing
+                    // under the signal then never meets the cancelling taps (and their fp32 rounding) at full size (sg_2d_hf.hip, EXPERIMENTS R6.8)
+                    const float c = plan.centre ? src[N + 8] : 0.0f;
+                    WinConv<N, 16>::template quads<0>([&](int q) { const float4 v = *reinterpret_cast<const float4 *>(src + 4 * q);
+                                                                    return make_float4(v.x - c, v.y - c, v.z - c, v.w - c); }, A, Wq, f32x2{0.0f, 0.0f});
+                    if (plan.centre) {
+                        const float back = c * plan.first_sum[t - tbase];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) A[j] = A[j] + f32x2{back, back};
+                    }
                     float *dst = hbuf + r * S::PH + seg * 16;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)

@@ -245,6 +245,8 @@ def test_pass_order_kernels_every_half_window(sg, sgo, torch_gpu, n):
         second launch (order 4, d = (2,0)), a third derivative (order 4, d = (3,0)) and a mixed one (order 3, d = (2,1)); on a frame with 16-byte aligned rows
         (vector strips) and on one whose width and pitch are odd (the scalar path), VALID / CONSTANT / REFLECT.
       * y-dominant frames on the tile kernel staged transposed (method 3, d = (0,2)) and on the vertical-first rolling kernel (method 2).
+      * the tile kernel (method 3) on x- and y-dominant kernels: its first pass runs on centred samples (SepPlan.centre).
+    The frames carry a ramp along x (both) and along y (the second): what a plain cancelling pass amplifies.
     The reference's dense loop: /root/reference/src/savgol2d.c:374-393, 417-453."""
     torch = torch_gpu
     rng = np.random.default_rng(4242 + n)
@@ -252,9 +254,10 @@ def test_pass_order_kernels_every_half_window(sg, sgo, torch_gpu, n):
         yy, xx = np.mgrid[0:rows, 0:cols]
         x = np.zeros((2, rows, stride), np.float32)
         for k in range(2):
-            x[k, :, :cols] = (np.sin(0.07 * xx + k) * np.cos(0.04 * yy) + 0.002 * xx + rng.normal(0, 0.1, (rows, cols))).astype(np.float32)
+            x[k, :, :cols] = (np.sin(0.07 * xx + k) * np.cos(0.04 * yy) + 0.002 * xx + 0.003 * k * yy + rng.normal(0, 0.1, (rows, cols))).astype(np.float32)
         d = torch.from_numpy(x).cuda()
-        cases = [(2, 2, 0, 2), (3, 2, 0, 2), (4, 2, 0, 2), (4, 3, 0, 2), (3, 2, 1, 2), (3, 0, 2, 2), (3, 0, 2, 3), (4, 0, 2, 3)]
+        cases = [(2, 2, 0, 2), (3, 2, 0, 2), (4, 2, 0, 2), (4, 3, 0, 2), (3, 2, 1, 2), (3, 0, 2, 2), (3, 0, 2, 3), (4, 0, 2, 3),
+                 (3, 2, 0, 3), (4, 2, 0, 3), (4, 3, 0, 3), (4, 0, 3, 3), (3, 1, 2, 3)]      # the tile kernel's centred first pass, either order
         for order, dx, dy, method in cases:
             if order > 2 * n:
                 continue

@@ -1,6 +1,6 @@
 # Scratch script of round 6's GPU calls (rewritten per call: `gpurun -- 'bash tools/r6_run.sh'`).
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r6
-timeout 900 python -m pytest tests/test_gpu_stream.py -q -m gpu 2>&1 | tail -4 > gpurun_out/r6/gputests_stream.txt
-L=savitzky-golay-filter_amd/lib/libsavgol_hip.so
-for n in 16 8 24 32; do timeout 300 python tools/ab_stream.py $L tools/ab/lib_momexp.so --fma 0 --n $n --m 2 --d 1; done > gpurun_out/r6/stream_chunk8_ab.txt 2>&1
-cat gpurun_out/r6/gputests_stream.txt | grep -E "passed|failed"; grep -v amdgpu gpurun_out/r6/stream_chunk8_ab.txt | tail -12
+rm -f gpurun_out/r6/parity_all.log
+SAVGOL_PARITY_LOG=gpurun_out/r6/parity_all.log timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -6 > gpurun_out/r6/gputests_all.txt
+ONLY=image bash tools/run_profiles_r6.sh > gpurun_out/r6/prof_image.log 2>&1
+cd "${GRAFT_REPO_ROOT:-.}"; tail -3 gpurun_out/r6/gputests_all.txt
