@@ -6,8 +6,8 @@
 // mirror then clamp (REFLECT) (:428-445); VALID writes only the interior of a same-size frame (:410-414).
 //
 // Method 1 = the dense window in the SAME summation order and rounding as the reference -> bit-identical outputs:
-// sg_2d_dense.hip for square windows (packed math, input-row stationary), otherwise
-// sg2d_direct_kernel below (LDS tile + halo, one pixel per lane; 225 taps at n=7 make it VALU/LDS bound).
+// sg_2d_dense.hip (packed math, input-row stationary; square and, since round 6, rectangular windows -- the one-pixel-per-lane
+// kernel that used to serve those is gone; sg2d_direct2_kernel below keeps its tile form for the rectangular Laplacian).
 // Kernels 2 and 3 (method 2 / auto): W is exactly low rank, W(x,y) = sum_t G_t(y) Q_t(x) with r <= 4 terms, so the
 // frame is filtered as r column passes and r row passes: 2 r (2n+1) FMAs per pixel instead of (2n+1)^2, back in
 // HBM-bound territory; fp32 rounding only (1e-7 level) against the reference.  sg_2d_roll.hip (half windows <= 8:
@@ -28,54 +28,6 @@
 namespace sg {
 
 constexpr int T2_W = 64, T2_H = 16;                 // outputs per block: 64 wide, 16 tall (4 per thread)
-
-// LDS: weights [wh*ww] (padded to a multiple of 4) then the input tile [(T2_H+2ny)][(T2_W+2nx)]
-__global__ __launch_bounds__(256) void sg2d_direct_kernel(const Job2D job, const float *__restrict__ W)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int nx = job.nx, ny = job.ny, ww = 2 * nx + 1, wh = 2 * ny + 1;
-    const int wpad = (ww * wh + 3) & ~3;
-    float *wl = lds;
-    float *tile = lds + wpad;
-    const int tw = T2_W + 2 * nx, th = T2_H + 2 * ny;
-
-    const int tid = threadIdx.x;
-    const int bx = blockIdx.x % job.tiles_x, by = blockIdx.x / job.tiles_x;
-    const long long img = blockIdx.y;
-    const float *in = job.in + img * job.in_pitch;
-    float *out = job.out + img * job.out_pitch;
-    const int x0 = bx * T2_W, y0 = by * T2_H;             // output tile origin (frame coordinates)
-
-    for (int i = tid; i < ww * wh; i += 256) wl[i] = W[i];
-    for (int i = tid; i < tw * th; i += 256) {
-        const int r = i / tw, c = i - r * tw;
-        const int iy = fix_index(y0 + r - ny, job.rows, job.boundary);
-        const int ix = fix_index(x0 + c - nx, job.cols, job.boundary);
-        tile[i] = in[(long long)iy * job.in_stride + ix];
-    }
-    __syncthreads();
-
-    const int lx = tid & 63, ly = tid >> 6;               // thread -> column lx, rows ly + 4k
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int wy = 0; wy < wh; ++wy) {
-        const float *wrow = wl + wy * ww;
-        const float *t0 = tile + (ly + wy) * tw + lx;
-        for (int wx = 0; wx < ww; ++wx) {
-            const float w = wrow[wx];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = __fadd_rn(acc[k], __fmul_rn(w, t0[(4 * k) * tw + wx]));
-        }
-    }
-    const int ox = x0 + lx;
-    // which outputs exist: VALID = interior only, else the whole frame
-    const int xlo = job.boundary == SAVGOL2D_BOUNDARY_VALID ? nx : 0, xhi = job.boundary == SAVGOL2D_BOUNDARY_VALID ? job.cols - nx : job.cols;
-    const int ylo = job.boundary == SAVGOL2D_BOUNDARY_VALID ? ny : 0, yhi = job.boundary == SAVGOL2D_BOUNDARY_VALID ? job.rows - ny : job.rows;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int oy = y0 + ly + 4 * k;
-        if (ox >= xlo && ox < xhi && oy >= ylo && oy < yhi) out[(long long)oy * job.out_stride + ox] = __fmul_rn(acc[k], job.scale);
-    }
-}
 
 // Two dense windows over one read of the tile, each summed in the reference's order and scaled, then added: the reference's Laplacian
 // (savgol2d_laplacian, src/savgol2d.c:560-618: output = xx frame, temp = yy frame, output += temp) bit for bit, with no temporary frame
@@ -384,9 +336,6 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
     }
     DeviceCtx *ctx = ctx_get();
     if (!ctx) return -1;
-    const float *d_w = ctx_table(ctx, f->weights, sizeof(float) * (size_t)f->window_area, 0x2d000000u + (unsigned)(nx * 64 + ny));
-    if (!d_w) return -1;
-
     Job2D job;
     memset(&job, 0, sizeof(job));
     job.rows = rows; job.cols = cols; job.in_stride = in_stride; job.out_stride = out_stride;
@@ -394,8 +343,6 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
     job.nx = nx; job.ny = ny;
     job.boundary = (boundary == SAVGOL2D_BOUNDARY_VALID || boundary == SAVGOL2D_BOUNDARY_REFLECT) ? boundary : SAVGOL2D_BOUNDARY_CONSTANT;
     job.scale = f->scale;
-    job.tiles_x = (cols + T2_W - 1) / T2_W;
-    job.tiles_y = (rows + T2_H - 1) / T2_H;
     // method: 1 = dense window (bit-identical to the reference), 2 = separable passes (3 = its tile kernel only), 0 = separable when available
     if (method != 1) {
         float factors[SEP_MAX_TERMS * 2 * (2 * SAVGOL2D_MAX_HALF_WINDOW + 2)];
@@ -433,17 +380,15 @@ static int enqueue_2d(const char *who, const Savgol2DFilter *f, const float *d_i
         }
         if (method >= 2) { sg_set_error("%s: no separable kernel for this %dx%d window (rank > %d, or a rectangular window beyond the rolling kernel's ranks)", who, 2 * nx + 1, 2 * ny + 1, SEP_MAX_TERMS); return -1; }
     }
-    const size_t lds = sizeof(float) * (size_t)(((f->window_area + 3) & ~3) + (T2_W + 2 * nx) * (T2_H + 2 * ny));
     for (size_t i0 = 0; i0 < images; i0 += 65535) {
         const size_t ni = images - i0 < 65535 ? images - i0 : 65535;
         job.in = d_in + (long long)i0 * in_pitch;
         job.out = d_out + (long long)i0 * out_pitch;
-        {
-            const int rc = sg2d_launch_dense_rolling(job, f->weights, ctx, (unsigned)ni, st);
-            if (rc < 0) return -1;
-            if (rc == 0) continue;
+        const int rc = sg2d_launch_dense_rolling(job, f->weights, ctx, (unsigned)ni, st);
+        if (rc != 0) {
+            if (rc > 0) sg_set_error("%s: no dense kernel for a %dx%d window", who, 2 * nx + 1, 2 * ny + 1);
+            return -1;
         }
-        hipLaunchKernelGGL(sg2d_direct_kernel, dim3((unsigned)(job.tiles_x * job.tiles_y), (unsigned)ni), dim3(256), lds, st, job, d_w);
     }
     return hip_ok(hipGetLastError(), who) ? 0 : -1;
 }

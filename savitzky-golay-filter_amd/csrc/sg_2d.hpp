@@ -174,8 +174,8 @@ inline int sg2d_launch_rolling_hf(int n, const Job2D &job, const float *factors,
 // which pass order suits a kernel in fp32 (sg_2d_hf.hip's header, tools/emulate_2d_passes.py): the pass that cancels harder goes first
 inline bool sg2d_x_dominant(int deriv_x, int deriv_y) { return deriv_x >= 2 && deriv_x > deriv_y; }
 
-// sg_2d_dense.hip: the bit-exact dense kernel on packed math, square windows with half window <= DENSE_ROLL_MAX_N.
-// 0 = launched, 1 = not covered (the caller uses sg2d_direct_kernel of sg_2d.hip), -1 = error.  h_w = the kernel on the host.
+// sg_2d_dense.hip: the bit-exact dense kernel on packed math, square and rectangular windows with half windows <= DENSE_ROLL_MAX_N.
+// 0 = launched, 1 = not covered, -1 = error.  h_w = the kernel on the host, [2ny+1][2nx+1].
 constexpr int DENSE_ROLL_MAX_N = 16;
 struct DeviceCtx;
 int sg2d_launch_dense_rolling(const Job2D &job, const float *h_w, DeviceCtx *ctx, unsigned images, hipStream_t st);

@@ -193,6 +193,36 @@ def test_dense_packed_kernel_bit_exact_every_half_window(sg, sgo, torch_gpu, n):
                     assert same_bits(g[k], want), (n, rows, cols, order, dx, dy, b, k)
 
 
+@pytest.mark.parametrize("nx,ny", [(2, 1), (1, 2), (1, 16), (16, 1), (7, 3), (3, 7), (4, 6), (12, 5), (5, 12), (16, 15), (15, 16), (9, 16), (8, 2)])
+def test_dense_packed_kernel_rectangular_windows_bit_exact(sg, sgo, torch_gpu, nx, ny):
+    """Method 1 on RECTANGULAR windows (the reference tests 5 x 3: /root/reference/test/iterative/test_savgol2d.c:508-543; its loop:
+    src/savgol2d.c:374-393) runs the packed dense kernel with a run-time count of window rows (sg_2d_dense.hip, RT = true): the reference's
+    bits on frames with interior strips, edge strips, several row bands, and on small / odd / misaligned frames; nothing outside the output region."""
+    torch = torch_gpu
+    rng = np.random.default_rng(900 + 17 * nx + ny)
+    for (images, rows, cols, stride, off) in ((2, 140 + ny, 617, 624, 0), (1, 2 * ny + 3, 2 * nx + 5, 2 * nx + 6, 1), (1, 600, 40, 40, 0), (1, 3, 5, 8, 0)):
+        flat = np.zeros(images * rows * stride + 4, np.float32)
+        x = flat[off:off + images * rows * stride].reshape(images, rows, stride)
+        x[:, :, :cols] = rng.normal(0, 1, (images, rows, cols)).astype(np.float32)
+        dflat = torch.from_numpy(flat).cuda()
+        d = dflat[off:off + images * rows * stride]
+        for order, dx, dy in ((2, 0, 0), (2, 1, 0), (2, 0, 2)):
+            f = sg.Filter2D(nx, ny, order, dx, dy, 0.5, 2.0)
+            o = sgo.Filter2D(nx, ny, order, dx, dy, 0.5, 2.0)
+            for b in range(3):
+                if b == 0 and (rows <= 2 * ny or cols <= 2 * nx):
+                    continue
+                out = torch.full((images * rows * stride + 4,), -5.0, device="cuda")
+                f.apply_batch(d, out[off:off + images * rows * stride], rows, cols, images, in_stride=stride, out_stride=stride,
+                              boundary=b, method=1)
+                got = out.cpu().numpy()
+                assert np.all(got[:off] == -5.0) and np.all(got[off + images * rows * stride:] == -5.0)
+                g = got[off:off + images * rows * stride].reshape(images, rows, stride)
+                for k in range(images):
+                    want = o.apply(x[k], cols, b, out=np.full((rows, stride), -5.0, np.float32))
+                    assert same_bits(g[k], want), (nx, ny, rows, cols, order, dx, dy, b, k)
+
+
 @pytest.mark.parametrize("n", range(1, 17))
 def test_rolling_window_kernel_all_half_windows(sg, sgo, torch_gpu, n):
     """The rolling-window path (sg_2d_roll.hip, every half window 1..16): 16-byte aligned frames wide and tall enough for interior

@@ -7,7 +7,37 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
+def unpacked(blob):
+    """The file with every zstd-compressed bundle (`--offload-compress`: magic CCOB, version 2 / 3 header, then the zstd frame) replaced by the
+    plain __CLANG_OFFLOAD_BUNDLE__ it holds -- appended, the scan below does not care where a bundle sits."""
+    if blob.find(b"CCOB") < 0:
+        return blob
+    import ctypes
+    z = ctypes.CDLL("libzstd.so.1")
+    z.ZSTD_decompress.restype = ctypes.c_size_t
+    z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    out, pos = [blob], 0
+    while True:
+        pos = blob.find(b"CCOB", pos)
+        if pos < 0:
+            return b"".join(out)
+        version, method = struct.unpack_from("<HH", blob, pos + 4)
+        if version >= 3:
+            total, raw = struct.unpack_from("<QQ", blob, pos + 8)
+            head = 32
+        else:
+            total, raw = struct.unpack_from("<II", blob, pos + 8)
+            head = 24
+        if method == 1 and head < total <= len(blob) - pos and raw < (1 << 31):
+            dst = ctypes.create_string_buffer(raw)
+            got = z.ZSTD_decompress(dst, raw, blob[pos + head:pos + total], total - head)
+            if got == raw:
+                out.append(dst.raw)
+        pos += 4
+
+
 def code_objects(blob):
+    blob = unpacked(blob)
     pos = 0
     while True:
         pos = blob.find(MAGIC, pos)
