@@ -325,6 +325,16 @@ int savgol2d_apply_rowband_edges_f32(const Savgol2DFilter *filter,
                                      const float *d_halo_up, const float *d_halo_down, int halo_stride, size_t halo_image_pitch,
                                      float *d_out, int out_stride, size_t out_image_pitch,
                                      size_t images, Savgol2DBoundary boundary, int method, void *stream);
+/* The same on two streams (round 6): the strips are gathered and filtered on `halo_stream` -- the stream the halos arrive on; call this after
+ * enqueueing the exchange there.  They read the band and the halos and write library scratch only, so they run BESIDE the band launch still
+ * going on `stream`; only the copy of the finished half_window_y rows per edge into d_out is ordered behind everything enqueued on `stream`
+ * so far (the band launch), through an event the call records itself.  No wait between the two streams is needed from the caller.
+ * halo_stream == stream is savgol2d_apply_rowband_edges_f32. */
+int savgol2d_apply_rowband_edges_streams_f32(const Savgol2DFilter *filter,
+                                             const float *d_band, int band_rows, int cols, int in_stride, size_t in_image_pitch,
+                                             const float *d_halo_up, const float *d_halo_down, int halo_stride, size_t halo_image_pitch,
+                                             float *d_out, int out_stride, size_t out_image_pitch,
+                                             size_t images, Savgol2DBoundary boundary, int method, void *halo_stream, void *stream);
 /* (savgol2d_rowband_exchange_rccl is declared in savgol_hip_rccl.h -- that library is the only part that links librccl) */
 
 /* ---------------------------------------------------------------- bench utilities ----- *

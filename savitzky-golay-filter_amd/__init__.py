@@ -156,6 +156,7 @@ SIGNATURES = {
     "savgol2d_rowband_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "savgol2d_apply_rowband_f32": (C.c_int, [_F2, _vp, C.c_int, C.c_int, C.c_int, _sz, _vp, _vp, C.c_int, _sz, _vp, C.c_int, _sz, _sz, C.c_int, C.c_int, _vp]),
     "savgol2d_apply_rowband_edges_f32": (C.c_int, [_F2, _vp, C.c_int, C.c_int, C.c_int, _sz, _vp, _vp, C.c_int, _sz, _vp, C.c_int, _sz, _sz, C.c_int, C.c_int, _vp]),
+    "savgol2d_apply_rowband_edges_streams_f32": (C.c_int, [_F2, _vp, C.c_int, C.c_int, C.c_int, _sz, _vp, _vp, C.c_int, _sz, _vp, C.c_int, _sz, _sz, C.c_int, C.c_int, _vp, _vp]),
     # savgol_hip.h: bench utilities
     "savgol_hip_stream_copy": (C.c_int, [_vp, _vp, _sz, _vp]),
     "savgol_hip_stream_read": (C.c_int, [_vp, _sz, _vp, _vp]),

@@ -97,8 +97,10 @@ class RowBand:
 
     def apply_c(self, filter2d, local, boundary=1, method=0, stream=None, comm=None):
         """The same through the C ABI (csrc/sg_2d_rowband.hip), exchange overlapped with the band: post the halo sends / receives,
-        enqueue the band itself (savgol2d_apply_batch_f32: it reads no halo), wait for the halos, then the edge strips
-        (savgol2d_apply_rowband_edges_f32).  `local`: [images, own, cols] fp32 on the GPU.
+        enqueue the band itself (savgol2d_apply_batch_f32: it reads no halo), then the edge strips: with the C exchange they are gathered and
+        filtered on the exchange's stream, beside the band, and only the copy of their finished rows waits for the band
+        (savgol2d_apply_rowband_edges_streams_f32); with torch.distributed's exchange, after it (savgol2d_apply_rowband_edges_f32).
+        `local`: [images, own, cols] fp32 on the GPU.
         comm: an rccl.Comm -- the halos then travel through savgol2d_rowband_exchange_rccl (csrc/sg_rowband_rccl.hip: one pack launch and
         one ncclSend / ncclRecv pair per neighbour) on a side stream of its own, no torch.distributed call on the data path; without it
         the exchange is torch.distributed's batch_isend_irecv."""
@@ -139,12 +141,15 @@ class RowBand:
                                           _stream(stream)) != 0:
                 raise RuntimeError(last_error())
         if done is not None:
-            (stream or torch.cuda.current_stream()).wait_event(done)
+            rc = L.savgol2d_apply_rowband_edges_streams_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols,
+                                                            _addr(up) if up is not None else None, _addr(dn) if dn is not None else None,
+                                                            cols, self.ny * cols, _addr(out), cols, own * cols, images, boundary, method,
+                                                            self._xstream.cuda_stream, _stream(stream))
         else:
             up, dn = self.finish_exchange(handle)
-        rc = L.savgol2d_apply_rowband_edges_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols,
-                                                _addr(up) if up is not None else None, _addr(dn) if dn is not None else None,
-                                                cols, self.ny * cols, _addr(out), cols, own * cols, images, boundary, method, _stream(stream))
+            rc = L.savgol2d_apply_rowband_edges_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols,
+                                                    _addr(up) if up is not None else None, _addr(dn) if dn is not None else None,
+                                                    cols, self.ny * cols, _addr(out), cols, own * cols, images, boundary, method, _stream(stream))
         if rc != 0:
             raise RuntimeError(last_error())
         return out

@@ -641,7 +641,8 @@ def test_randomized_derivative_frames(sg, sgo, torch_gpu):
 def test_randomized_row_bands_and_rectangular_windows(sg, sgo, torch_gpu):
     """40 random draws of (nx, ny, order, derivative, frame size, stride, images, boundary, method, world size): the frame stack
     filtered whole against the double oracle (rectangular windows included), then split into `world` row bands through
-    savgol2d_rowband_plan / savgol2d_apply_rowband_f32 with the halo rows cut out of the input -- stitched bands == whole frames, bit
+    savgol2d_rowband_plan / savgol2d_apply_rowband_f32 (every other draw: the band + savgol2d_apply_rowband_edges_streams_f32 on two streams)
+    with the halo rows cut out of the input -- stitched bands == whole frames, bit
     for bit (2.5e-7 of the input's maximum for the additive rolling form, whose re-seed phase follows the band's row 0)."""
     import ctypes as C
     torch = torch_gpu
@@ -689,9 +690,23 @@ def test_randomized_row_bands_and_rectangular_windows(sg, sgo, torch_gpu):
             lo, hi_ = lo.value, hi_.value
             hu = d[:, lo - ny:lo, :cols].contiguous() if up.value else None
             hd = d[:, hi_:hi_ + ny, :cols].contiguous() if dn.value else None
-            rc = L.savgol2d_apply_rowband_f32(f.ptr, d[:, lo:].data_ptr(), hi_ - lo, cols, stride, rows * stride, hu.data_ptr() if up.value else None,
-                                              hd.data_ptr() if dn.value else None, cols, ny * cols, parts[:, lo:].data_ptr(), stride, rows * stride,
-                                              images, b, method, None)
+            if done % 2 == 0:
+                rc = L.savgol2d_apply_rowband_f32(f.ptr, d[:, lo:].data_ptr(), hi_ - lo, cols, stride, rows * stride, hu.data_ptr() if up.value else None,
+                                                  hd.data_ptr() if dn.value else None, cols, ny * cols, parts[:, lo:].data_ptr(), stride, rows * stride,
+                                                  images, b, method, None)
+            else:
+                # the split form on two streams: the band on the compute stream, the strips gathered and filtered on a side stream beside it,
+                # their finished rows copied in behind the band (savgol2d_apply_rowband_edges_streams_f32 orders that itself)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())             # the frames and the halo rows are there
+                rc = 0
+                if not (b == 0 and hi_ - lo - 2 * ny <= 0):
+                    rc = L.savgol2d_apply_batch_f32(f.ptr, d[:, lo:].data_ptr(), hi_ - lo, cols, stride, rows * stride, parts[:, lo:].data_ptr(), stride,
+                                                    rows * stride, images, b, method, None)
+                assert rc == 0, sg.last_error()
+                rc = L.savgol2d_apply_rowband_edges_streams_f32(f.ptr, d[:, lo:].data_ptr(), hi_ - lo, cols, stride, rows * stride,
+                                                                hu.data_ptr() if up.value else None, hd.data_ptr() if dn.value else None, cols, ny * cols,
+                                                                parts[:, lo:].data_ptr(), stride, rows * stride, images, b, method, side.cuda_stream, None)
             assert rc == 0, sg.last_error()
         torch.cuda.synchronize()
         ph = parts.cpu().numpy()
