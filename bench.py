@@ -156,6 +156,24 @@ def timed(fn, reps=5, warm=1):
     return float(np.median(ts))
 
 
+def timed_back_to_back(fn, k=8, reps=3, warm=1):
+    """ms per call of k calls enqueued in a row between one pair of events (median of reps) -- how the steps of a job follow each other, and
+    how the headline's timed region is taken; timed() synchronises after every call, and a 1-2 ms kernel that starts on an idle chip pays the
+    clock ramp every time (config 4 on 16 ... 64 frames: median 27-28 us per frame alone, 24.5 in a row or on 512 frames)"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(k):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / k)
+    return float(np.median(ts))
+
+
 def roofline(alg_bytes, ms, launches_ms=None, **more):
     """`ms` = the average launch duration (what `achieved` is computed from); launches_ms = every timed launch, for the spread"""
     ach = alg_bytes / (ms * 1e-3) / 1e9
@@ -636,6 +654,7 @@ def bench_rowband_ring_of_one(sg, a):
         scratch = torch.empty((2, Nimg, n, size), dtype=torch.float32, device="cuda")
         f2 = sg.Filter2D(n, n, 3)
         main = torch.cuda.current_stream()
+        # (normal priority: a high-priority side stream gets the exchange through in 45 us but costs the band 0.38 ms -- EXPERIMENTS R6.11)
         xs = torch.cuda.Stream()
 
         def exchange(stream):
@@ -660,7 +679,9 @@ def bench_rowband_ring_of_one(sg, a):
         ms_x = timed(lambda: exchange(main), reps=7, warm=2)
         ms_b = timed(band_kernel, reps=5, warm=1)
         ms_e = timed(edges, reps=7, warm=2)
-        ms_step = timed(step, reps=5, warm=1)
+        ms_step_alone = timed(step, reps=5, warm=1)
+        ms_b_row = timed_back_to_back(band_kernel)
+        ms_step = timed_back_to_back(step)               # steps as a job issues them: one after the other
         torch.cuda.synchronize()
         res = {"workload": f"BASELINE config 4 shape as ONE row band: {Nimg} frames x {size}x{size} fp32, n=7, order 3, CONSTANT left / right, the {n}-row halos "
                            "through savgol2d_rowband_exchange_rccl_peers on a one-rank communicator (ring of one: vertically periodic frames)",
@@ -668,10 +689,11 @@ def bench_rowband_ring_of_one(sg, a):
                "edge_strips": "savgol2d_apply_rowband_edges_streams_f32: both strips of every frame as one batch, gathered and filtered on the exchange's stream beside "
                               "the band; only the copy of their finished rows waits for the band",
                "exchange_ms": round(ms_x, 4), "halo_bytes_per_side": Nimg * n * size * 4, "band_ms": round(ms_b, 4), "edge_strips_ms": round(ms_e, 4),
-               "step_ms": round(ms_step, 4), "serial_sum_ms": round(ms_x + ms_b + ms_e, 4),
-               "overlap_ms": round(ms_x + ms_b + ms_e - ms_step, 4),
-               "exchange_hidden_frac": round(max(0.0, min(1.0, (ms_x + ms_b + ms_e - ms_step) / ms_x)), 3) if ms_x > 0 else None,
-               "exchange_and_strips_hidden_frac": round(max(0.0, min(1.0, (ms_x + ms_b + ms_e - ms_step) / (ms_x + ms_e))), 3) if ms_x + ms_e > 0 else None,
+               "step_ms": round(ms_step, 4), "step_ms_is": "8 steps enqueued in a row / 8 (the parts above and step_alone_ms: one call, then a synchronise)",
+               "band_in_a_row_ms": round(ms_b_row, 4), "step_alone_ms": round(ms_step_alone, 4), "serial_sum_ms": round(ms_x + ms_b + ms_e, 4),
+               "overlap_ms": round(ms_x + ms_b + ms_e - ms_step_alone, 4),
+               "exchange_hidden_frac": round(max(0.0, min(1.0, (ms_x + ms_b + ms_e - ms_step_alone) / ms_x)), 3) if ms_x > 0 else None,
+               "exchange_and_strips_hidden_frac": round(max(0.0, min(1.0, (ms_x + ms_b + ms_e - ms_step_alone) / (ms_x + ms_e))), 3) if ms_x + ms_e > 0 else None,
                "Mpix_per_s": round(Nimg * size * size / ms_step / 1e3, 1),
                "roofline_frac_of_step": round(8.0 * Nimg * size * size / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if not a.no_cpu:
