@@ -357,13 +357,15 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     // split so that a launch stays below 2^24 blocks of four tiles (sg::MAX_TILES_PER_LAUNCH)
     size_t max_ch = (size_t)sg::MAX_TILES_PER_LAUNCH / ((size_t)job.tiles_per_channel + 2);
     if (inplace) {
-        // in place: channel groups whose stash (one slot of 2 NA samples per ODD tile + 4 NA per channel) stays below 192 MiB -- inside what the scratch pool
-        // keeps (256 MiB), so it is neither handed back to the driver nor mapped again from call to call (round 5: a 1 GiB stash per 1024-channel chunk cost
-        // 14 ms a call on most boxes and 98 on one).  The groups follow each other on the stream; config 5's chunk is 6 groups (round 6's first version
-        // stashed a slot per tile under a 64 MiB cap: 32 groups of 0.19 ms launches, +22 %).
+        // in place: channel groups whose stash (one slot of 2 NA samples per ODD tile + 4 NA per channel) stays below 3/4 of what the scratch pool keeps
+        // (192 of 256 MiB by default; SAVGOL_HIP_SCRATCH_KEEP_MB moves both), so it is neither handed back to the driver nor mapped again from call to call
+        // (round 5: a 1 GiB stash per 1024-channel chunk cost 14 ms a call on most boxes and 98 on one).  The groups follow each other on the stream; config 5's
+        // chunk is 6 groups (round 6's first version stashed a slot per tile under a 64 MiB cap: 32 groups of 0.19 ms launches, +22 %).
         const int NA0 = (n + E - 1) / E * E;
         const size_t per_ch = ((size_t)(job.tiles_per_channel / 2) * (size_t)(2 * NA0) + (size_t)(4 * NA0)) * sizeof(T);
-        const size_t group = per_ch ? ((size_t)192 << 20) / per_ch : max_ch;
+        size_t cap = (size_t)(sg::scratch_keep_bytes() / 4 * 3);
+        if (cap < ((size_t)64 << 20)) cap = (size_t)64 << 20;
+        const size_t group = per_ch ? cap / per_ch : max_ch;
         if (group >= 1 && group < max_ch) max_ch = group;
     }
     // the tile launch of the chosen kernel family: one tile per wave, blocks dispatched in order (see sg1d_center_kernel)

@@ -74,6 +74,16 @@ const float *ctx_table(DeviceCtx *ctx, const void *host, size_t bytes, uint64_t 
     return dev;
 }
 
+uint64_t scratch_keep_bytes()
+{
+    static const uint64_t keep = [] {
+        uint64_t k = 256ull << 20;
+        if (const char *e = getenv("SAVGOL_HIP_SCRATCH_KEEP_MB")) { const long long v = atoll(e); if (v >= 0) k = (uint64_t)v << 20; }
+        return k;
+    }();
+    return keep;
+}
+
 void *scratch_alloc(DeviceCtx *ctx, size_t bytes, hipStream_t st, const char *what)
 {
     {
@@ -91,8 +101,7 @@ void *scratch_alloc(DeviceCtx *ctx, size_t bytes, hipStream_t st, const char *wh
             // (threshold UINT64_MAX): the staged strided path's 2 x channels x ld x 4 bytes -- GiBs -- then stayed invisible to
             // PyTorch's allocator and to the caller's own hipMalloc.  savgol_hip_trim_scratch() / savgol_hip_synchronize()
             // return the rest.  SAVGOL_HIP_SCRATCH_KEEP_MB overrides.
-            uint64_t keep = 256ull << 20;
-            if (const char *e = getenv("SAVGOL_HIP_SCRATCH_KEEP_MB")) { const long long v = atoll(e); if (v >= 0) keep = (uint64_t)v << 20; }
+            uint64_t keep = scratch_keep_bytes();
             (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
             ctx->pool = pool;
         }

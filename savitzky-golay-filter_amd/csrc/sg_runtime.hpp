@@ -77,6 +77,7 @@ void *ctx_pinned(DeviceCtx *ctx, size_t bytes);
 // UINT64_MAX, which would hide GiBs of peak scratch from the caller's allocator; it is the default pool that is broken, not releasing,
 // so the threshold is 256 MiB now (SAVGOL_HIP_SCRATCH_KEEP_MB) and scratch_trim() / savgol_hip_trim_scratch() /
 // savgol_hip_synchronize() hand back the rest.
+uint64_t scratch_keep_bytes();                    // the pool's release threshold: 256 MiB, or SAVGOL_HIP_SCRATCH_KEEP_MB
 void *scratch_alloc(DeviceCtx *ctx, size_t bytes, hipStream_t st, const char *what);   // nullptr + error text on failure
 bool scratch_free(void *p, hipStream_t st, const char *what);
 int scratch_trim(DeviceCtx *ctx);                 // 0 / -1
