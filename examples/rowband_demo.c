@@ -5,7 +5,8 @@
  *
  * A stack of frames is filtered (a) whole, by savgol2d_apply_batch_f32, and (b) as `world` row bands, each by
  * savgol2d_apply_rowband_f32 with the halo rows its neighbours would have sent -- copied device to device here, where a
- * multi-GPU host would run savgol2d_rowband_exchange_rccl (libsavgol_hip_rccl.so).  The stitched bands must equal the whole
+ * multi-GPU host would run savgol2d_rowband_exchange_rccl (libsavgol_hip_rccl.so); with three bands through the split form of a
+ * multi-GPU step: savgol2d_apply_batch_f32 on the band, savgol2d_apply_rowband_edges_streams_f32 on a second stream.  The stitched bands must equal the whole
  * frames: bit for bit with method 1 (and method 2 where the kernel is not the additive rolling form), for VALID, CONSTANT and
  * REFLECT, bands of unequal height included.  Exit code 0 = all checks passed.
  */
@@ -42,6 +43,8 @@ int main(void)
     CHECK(hipMalloc((void **)&d_parts, sizeof(float) * frame * images) == hipSuccess);
     CHECK(hipMemcpy(d_in, h, sizeof(float) * frame * images, hipMemcpyHostToDevice) == hipSuccess);
 
+    hipStream_t side;
+    CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess);
     const int configs[][5] = {{7, 7, 3, 0, 0}, {3, 3, 2, 1, 0}, {5, 5, 4, 0, 0}, {4, 6, 3, 0, 0}};     /* nx, ny, order, dx, dy */
     int checks = 0;
     for (unsigned c = 0; c < sizeof configs / sizeof configs[0]; ++c) {
@@ -68,9 +71,22 @@ int main(void)
                             if (down) CHECK(hipMemcpy2D(halo_down + (size_t)k * ny * cols, sizeof(float) * cols, d_in + k * frame + (size_t)hi * stride,
                                                         sizeof(float) * stride, sizeof(float) * cols, ny, hipMemcpyDeviceToDevice) == hipSuccess);
                         }
-                        CHECK(savgol2d_apply_rowband_f32(f, d_in + (size_t)lo * stride, hi - lo, cols, stride, frame, up ? halo_up : NULL, down ? halo_down : NULL,
-                                                         cols, (size_t)ny * cols, d_parts + (size_t)lo * stride, stride, frame, images,
-                                                         (Savgol2DBoundary)boundary, method, NULL) == 0);
+                        if (world != 3) {
+                            CHECK(savgol2d_apply_rowband_f32(f, d_in + (size_t)lo * stride, hi - lo, cols, stride, frame, up ? halo_up : NULL, down ? halo_down : NULL,
+                                                             cols, (size_t)ny * cols, d_parts + (size_t)lo * stride, stride, frame, images,
+                                                             (Savgol2DBoundary)boundary, method, NULL) == 0);
+                        } else {
+                            /* the split form a multi-GPU step uses: the band on the compute stream (it reads no halo); the edge strips gathered and
+                             * filtered on the stream the halos arrived on, beside the band; their finished rows copied in behind it */
+                            CHECK(hipStreamSynchronize(NULL) == hipSuccess);      /* the device-to-device halo copies above are the "exchange": done before `side` reads them */
+                            if (!(boundary == SAVGOL2D_BOUNDARY_VALID && hi - lo - 2 * ny <= 0))
+                                CHECK(savgol2d_apply_batch_f32(f, d_in + (size_t)lo * stride, hi - lo, cols, stride, frame, d_parts + (size_t)lo * stride, stride, frame,
+                                                               images, (Savgol2DBoundary)boundary, method, NULL) == 0);
+                            CHECK(savgol2d_apply_rowband_edges_streams_f32(f, d_in + (size_t)lo * stride, hi - lo, cols, stride, frame, up ? halo_up : NULL,
+                                                                           down ? halo_down : NULL, cols, (size_t)ny * cols, d_parts + (size_t)lo * stride, stride,
+                                                                           frame, images, (Savgol2DBoundary)boundary, method, side, NULL) == 0);
+                            CHECK(hipStreamSynchronize(side) == hipSuccess);      /* the next rank's hipMemcpy2D re-uses d_halo */
+                        }
                     }
                     CHECK(hipDeviceSynchronize() == hipSuccess);
                     CHECK(hipMemcpy(whole, d_whole, sizeof(float) * frame * images, hipMemcpyDeviceToHost) == hipSuccess);
