@@ -9,7 +9,7 @@
 // live in registers and shift down by one when a row completes; the input row crosses lanes once, through a
 // wave-private LDS row; the 2N+1 taps of one W row at a time come in through scalar loads.  v_pk_mul_f32 +
 // v_pk_add_f32: two pixels per instruction, the reference's two roundings per tap -> bit-identical output at half the
-// instruction count of the one-pixel-per-lane kernel in sg_2d.hip.
+// instruction count of a one-pixel-per-lane kernel (the form rounds 1-5 kept for rectangular windows).
 //
 // Square windows: everything static (template N).  RECTANGULAR windows (reference test: 5 x 3, test/iterative/test_savgol2d.c:508-543): the geometry
 // along x is the template's (N = half_window_x), the number of window ROWS is a run-time count wwy <= CW (two builds: CW = 9 and 33).  The chain of
@@ -296,7 +296,7 @@ static int dispatch_dense(int n, bool rect, const Job2D &job, const float *d_w, 
     else return 1;
 }
 
-// 0 = launched, 1 = not covered (a half window > DENSE_ROLL_MAX_N: the caller uses sg2d_direct_kernel), -1 = error.
+// 0 = launched, 1 = not covered (a half window > DENSE_ROLL_MAX_N: none that savgol2d_create accepts), -1 = error.
 // h_w = the filter's [2ny+1][2nx+1] kernel on the host; it is uploaded once per distinct content with rows padded to an even
 // number of floats, so that a row's taps are aligned pairs.
 int sg2d_launch_dense_rolling(const Job2D &job, const float *h_w, DeviceCtx *ctx, unsigned images, hipStream_t st)

@@ -16,8 +16,8 @@
 //                   column pass (one lane = one column x RY consecutive rows, same inner product on a
 //                               window gathered down the column) accumulated in registers over the terms
 //   3. scaled results -> HBM, 256-B rows per wave-instruction.
-// Square windows only (N = nx = ny, compile-time so every tap index is a literal); other shapes and
-// ranks above 4 use the direct kernel.
+// Square windows only (N = nx = ny, compile-time so every tap index is a literal); other shapes run the rolling kernels on
+// zero-padded factors, ranks above 4 the dense kernel (sg_2d_dense.hip).
 #include <hip/hip_runtime.h>
 
 #include <cmath>

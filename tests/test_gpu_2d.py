@@ -1,6 +1,6 @@
 """GPU parity tests of the 2-D path through the C ABI.
 
-The direct kernel keeps the reference's summation order and rounding, so the bar against the reference's
+The dense kernel (method 1) keeps the reference's summation order and rounding, so the bar against the reference's
 golden frames is BIT-EXACT (kernels too: they are host tables).  The separable method is checked against
 the double-accumulation oracle within TOL_SEP (normwise)."""
 import ctypes as C
