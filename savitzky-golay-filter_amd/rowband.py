@@ -137,9 +137,16 @@ class RowBand:
         else:
             handle = self.start_exchange(local)
         if not (boundary == 0 and own - 2 * self.ny <= 0):
-            if L.savgol2d_apply_batch_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols, _addr(out), cols, own * cols, images, boundary, method,
-                                          _stream(stream)) != 0:
-                raise RuntimeError(last_error())
+            # With the C exchange the band goes out as TWO launches, a short head (1 / 16 of the frames) and the rest: RCCL's send / recv kernel finds no
+            # registers beside a band launch that fills every wave slot and would sit until it has left the chip; in the gap between the two launches it
+            # becomes resident, and then runs -- and finishes -- beside the second one (rocprofv3 timeline: profiles/r06_rowband_timeline.txt, R6.11)
+            head = max(1, images // 16) if (done is not None and images >= 8) else 0
+            for first, count in ((0, head), (head, images - head)):
+                if count <= 0:
+                    continue
+                if L.savgol2d_apply_batch_f32(filter2d.ptr, _addr(local[first:]), own, cols, cols, own * cols, _addr(out[first:]), cols, own * cols, count, boundary,
+                                              method, _stream(stream)) != 0:
+                    raise RuntimeError(last_error())
         if done is not None:
             rc = L.savgol2d_apply_rowband_edges_streams_f32(filter2d.ptr, _addr(local), own, cols, cols, own * cols,
                                                             _addr(up) if up is not None else None, _addr(dn) if dn is not None else None,

@@ -722,6 +722,33 @@ def test_randomized_row_bands_and_rectangular_windows(sg, sgo, torch_gpu):
         done += 1
 
 
+class _GlooComm:
+    """Stands in for rccl.Comm in RowBand.apply_c (ranks that share one GPU cannot form an RCCL communicator): the same call on the same
+    stream, the halos through gloo with host staging.  What it exercises is apply_c's C-exchange branch: the side stream, the band as head +
+    rest, savgol2d_apply_rowband_edges_streams_f32."""
+
+    def rowband_exchange(self, local, ny, up, dn, scratch, peers=None, stream=None):
+        import torch as _torch
+        import torch.distributed as _dist
+        rank = _dist.get_rank()
+        with _torch.cuda.stream(stream):
+            first, last = local[:, :ny].contiguous().cpu(), local[:, -ny:].contiguous().cpu()
+        ops, got = [], {}
+        if up is not None:
+            got["up"] = _torch.empty_like(first)
+            ops += [_dist.P2POp(_dist.isend, first, rank - 1), _dist.P2POp(_dist.irecv, got["up"], rank - 1)]
+        if dn is not None:
+            got["dn"] = _torch.empty_like(last)
+            ops += [_dist.P2POp(_dist.isend, last, rank + 1), _dist.P2POp(_dist.irecv, got["dn"], rank + 1)]
+        for w in _dist.batch_isend_irecv(ops):
+            w.wait()
+        with _torch.cuda.stream(stream):
+            if up is not None:
+                up.copy_(got["up"].cuda())
+            if dn is not None:
+                dn.copy_(got["dn"].cuda())
+
+
 def _apply_c_worker(rank, world, port, rows, cols, images, n, out_dir):
     import os as _os
     import sys as _sys
@@ -745,6 +772,11 @@ def _apply_c_worker(rank, world, port, rows, cols, images, n, out_dir):
             out = band.apply_c(f, local, boundary=b, method=method)
             _torch.cuda.synchronize()
             np.save(_os.path.join(out_dir, f"c{b}_{method}_r{rank}.npy"), out.cpu().numpy())
+            # the C-exchange branch (side stream, band as head + rest, two-stream edge strips) on 8 copies of the frames
+            out8 = band.apply_c(f, local.repeat(4, 1, 1), boundary=b, method=method, comm=_GlooComm())
+            _torch.cuda.synchronize()
+            assert all(_torch.equal(out8[2 * k:2 * k + 2], out8[:2]) for k in range(1, 4)), (b, method)
+            np.save(_os.path.join(out_dir, f"x{b}_{method}_r{rank}.npy"), out8[:2].cpu().numpy())
     _dist.barrier()
     _dist.destroy_process_group()
 
@@ -768,12 +800,13 @@ def test_row_bands_apply_c_two_ranks_sharing_the_gpu(sg, torch_gpu, tmp_path):
         for method in (1, 2):
             whole = torch.zeros_like(x)
             f.apply_batch(x, whole, rows, cols, images, boundary=b, method=method)
-            got = np.concatenate([np.load(tmp_path / f"c{b}_{method}_r{r}.npy") for r in range(world)], axis=1)
             wh = whole.cpu().numpy()
-            if b == 0:                                    # VALID: the untouched border is whatever the buffers held (empty vs zeros): compare the written region
-                assert np.array_equal(got[:, n:rows - n, n:cols - n], wh[:, n:rows - n, n:cols - n]), (b, method)
-            else:
-                assert np.array_equal(got, wh), (b, method)
+            for tag in ("c", "x"):                        # c: gloo exchange, one stream; x: apply_c's C-exchange branch (see _GlooComm)
+                got = np.concatenate([np.load(tmp_path / f"{tag}{b}_{method}_r{r}.npy") for r in range(world)], axis=1)
+                if b == 0:                                # VALID: the untouched border is whatever the buffers held (empty vs zeros): compare the written region
+                    assert np.array_equal(got[:, n:rows - n, n:cols - n], wh[:, n:rows - n, n:cols - n]), (tag, b, method)
+                else:
+                    assert np.array_equal(got, wh), (tag, b, method)
 
 
 def test_overlapping_frames_are_refused(sg, torch_gpu):
