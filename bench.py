@@ -174,6 +174,17 @@ def timed_back_to_back(fn, k=8, reps=3, warm=1):
     return float(np.median(ts))
 
 
+def sustain(fn, seconds=0.25):
+    """keep the chip busy with fn() for `seconds` before a short kernel is timed: after a phase of sparse launches (config 3's per-tick latency loop:
+    one 3 us kernel per 13 us) the memory and fabric clocks have stepped down and take tens of milliseconds of load to come back -- the same block
+    push on the same buffers reads 0.67 / 0.57 (fused / bit-exact) in the first 20 ms and 0.72 / 0.64 from then on (tools/placement_stream_offset.py, R6.13)"""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(32):
+            fn()
+        torch.cuda.synchronize()
+
+
 def roofline(alg_bytes, ms, launches_ms=None, **more):
     """`ms` = the average launch duration (what `achieved` is computed from); launches_ms = every timed launch, for the spread"""
     ach = alg_bytes / (ms * 1e-3) / 1e9
@@ -469,14 +480,17 @@ def bench_stream(sg, a):
     e1.record(); torch.cuda.synchronize()
     tick_us = e0.elapsed_time(e1)
     # (c) block push: T ticks in one launch -- the fused-multiply-add bank (SAVGOL_STREAMBANK_FMA) and the reference-order one
-    ceil = copy_ceiling(sg, x, out)
     bank2 = sg.StreamBank(S, n, 2, 1, 1e-3, fma=True)
     # blocks follow each other in a stream job, and so they are timed: eight pushes in a row per measurement (the main line of --workload stream
-    # times its K steps the same way); one 0.39 ms launch between two synchronises pays the clock ramp of an idle chip (3-6 %)
+    # times its K steps the same way); one 0.39 ms launch between two synchronises pays the clock ramp of an idle chip (3-6 %).  The copy
+    # ceiling and the pushes are both taken on a chip that has been kept busy for a quarter of a second (sustain())
+    sustain(lambda: bank2.push_block(x, T, out))
+    ceil = copy_ceiling(sg, x, out)
     ms = timed_back_to_back(lambda: bank2.push_block(x, T, out), k=8, reps=5, warm=1)
     pick = [0, 1, S // 2, S - 1]
     got_fma = out[:, pick].cpu().numpy() if not a.no_cpu else None
     bank2r = sg.StreamBank(S, n, 2, 1, 1e-3)
+    sustain(lambda: bank2r.push_block(x, T, out), 0.1)
     ms_ref = timed_back_to_back(lambda: bank2r.push_block(x, T, out), k=8, reps=5, warm=1)
     got_ref = out[:, pick].cpu().numpy() if not a.no_cpu else None
     samples = S * T
@@ -1003,6 +1017,8 @@ def run_stream(r):
     x = torch.empty((T, S), dtype=torch.float32, device=dev); sg.synth(x, channel0=lo)
     y = torch.empty_like(x)
     bank = sg.StreamBank(S, 16, 2, 1, 1e-3, fma=True)       # SAVGOL_STREAMBANK_FMA; the reference-order bank is timed beside it under "latency"
+    # a step is 0.39 ms: W warm-up steps do not bring the memory clocks back up after the set-up phase; a quarter of a second of the same pushes does (R6.13)
+    sustain(lambda: bank.push_block(x, T, y))
     ceil = copy_ceiling(sg, x, y)
 
     def step(events):
