@@ -567,8 +567,8 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 // additive form, half windows 8 .. 12 (A/B builds override).  End of round 5, after the x-stationary horizontal unit had freed 2N + 3 register pairs
 // (tools/placement_2d.py, 32 frames of 4096^2, ms over six buffer pairs; profiles/r05_2d_tile_rows.txt): n = 8: 10 rows 0.900, 14 rows 0.862, 16 rows 0.889;
 // n = 9: 10 / 12 / 14 rows 0.992 / 0.967 / 0.949; n = 10: 8 / 10 / 12 rows 1.073 / 1.017 / 1.016; n = 11, 12: 8-12-row tiles 1.38-1.62 against the walk's
-// 1.27 / 1.30 at THREE waves per SIMD (67-127 spilled registers); round 6: at two waves per SIMD (roll_tile_waves) 12-row tiles hold no scratch and are 5 %
-// ahead of the walk (64 frames: 2.344 / 2.406 against 2.469 / 2.546 ms, tools/ab_2d.py, profiles/r06_2d_tiles_n11_16.txt)
+// 1.27 / 1.30 at THREE waves per SIMD (67-127 spilled registers).  Two waves per SIMD with taller tiles at n <= 10 (round 6): n = 7 28 / 32 rows 1.68 against
+// 1.585, n = 8 20 / 24 rows 1.95 / 1.81 against 1.64, n = 9 24 rows 1.85-1.87 against 1.82-1.86, n = 10 24 / 28 / 32 rows 1.95-1.96 against 1.99-2.02: left alone
 #ifndef SG_ROLL_TR8
 #define SG_ROLL_TR8 14
 #endif
@@ -578,11 +578,16 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #ifndef SG_ROLL_TR10
 #define SG_ROLL_TR10 10     /* round 6: 12 rows spill 4 registers now that nothing else does; 10 rows were level (1.017 against 1.016 ms) */
 #endif
+// Half windows 11 .. 16 at TWO waves per SIMD (256 registers): the taller the tile, the fewer halo rows per output row, up to what the registers hold
+// (4 (TR + 2N) + ~45; 20 rows spill at n = 16, 18 at n = 14).  64 frames of 4096^2, ms, tools/ab_2d.py (profiles/r06_2d_tiles_n11_16.txt):
+//   n = 11: walk 2.47, 12 rows 2.28-2.35, 16: 2.13, 20: 2.08, 22 / 24: 2.10        n = 12: walk 2.55, 12: 2.38-2.43, 16: 2.24, 20: 2.17-2.19, 22: 2.20, 24: 2.17 (spills)
+//   n = 13: walk 2.78, 8: 2.95, 12: 2.64, 14: 2.56, 16: 2.52, 18: 2.46             n = 14: walk 2.84, 12: 2.91, 14: 2.80, 16: 2.68, 18: 3.10 (spills)
+//   n = 15: walk 3.12, 8: 2.97-3.03, 12: 2.72-2.78, 14: 2.74, 16: 2.61, 18: 2.52, 20: 2.60      n = 16: walk 3.11-3.18, 12: 2.93-2.97, 14: 2.80, 16: 2.88, 18: 2.74, 20: 2.80 (spills)
 #ifndef SG_ROLL_TR11
-#define SG_ROLL_TR11 12     /* round 6: at TWO waves per SIMD the 12-row tiles hold no scratch: 2.34 against the walk's 2.47 ms per 64 frames */
+#define SG_ROLL_TR11 20
 #endif
 #ifndef SG_ROLL_TR12
-#define SG_ROLL_TR12 12     /* 2.41 against 2.55 */
+#define SG_ROLL_TR12 20
 #endif
 #ifndef SG_ROLL_TR13
 #define SG_ROLL_TR13 0           // A/B builds: tile rows for every half window 13 .. 16 (0 = the table in roll_tile_rows)
@@ -598,9 +603,7 @@ constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
     // n = 10 additive 2.14 vs 2.31 (8 rows; 10 spill: 2.16), one term 1.91 vs 2.13 (10 rows, 20 bytes of scratch; 8 rows 2.04)
     if (box && nt == 2 && nout == 1 && (n == 9 || n == 10)) return n == 9 ? SG_ROLL_TR9 : SG_ROLL_TR10;
     if (box && nt == 2 && nout == 1 && (n == 11 || n == 12)) return n == 11 ? SG_ROLL_TR11 : SG_ROLL_TR12;
-    // half windows 13 .. 16 as 8-row tiles at two waves per SIMD against the walk (64 frames of 4096^2, ms; profiles/r06_2d_tiles_n11_16.txt):
-    // n = 13: 2.95 / 2.76, 14: 3.10 / 2.85, 15: 2.96 / 3.12, 16: 3.22 / 3.15 -- only 15 gains (its walk runs five rows ahead)
-    if (box && nt == 2 && nout == 1 && n >= 13) return SG_ROLL_TR13 ? SG_ROLL_TR13 : (n == 15 ? 8 : 0);
+    if (box && nt == 2 && nout == 1 && n >= 13) return SG_ROLL_TR13 ? SG_ROLL_TR13 : (n == 14 ? 16 : 18);
     if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && (n == 9 || n == 10)) return 10;
     if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt <= 2 && n <= 7) return SG_ROLL_TILE_ROWS;
     // the fused two- / three-output forms with one term per frame (gradient of order <= 2, Hessian of order <= 3): the three Hessian frames
@@ -612,7 +615,10 @@ constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
 #define SG_ROLL_TILE_WAVES 3
 #endif
 // (the general two-term form at n = 6, 7 spills 36-52 bytes at 3 waves per SIMD)
-constexpr int roll_tile_waves(int n, int nt = 2, bool box = true, int nout = 1) { return (nout >= 2 || (!box && nt == 2 && n >= 6) || n >= 11) ? 2 : SG_ROLL_TILE_WAVES; }
+#ifndef SG_ROLL_W2_FROM
+#define SG_ROLL_W2_FROM 11       /* tiles of half windows >= this run at TWO waves per SIMD (256 registers: taller tiles) */
+#endif
+constexpr int roll_tile_waves(int n, int nt = 2, bool box = true, int nout = 1) { return (nout >= 2 || (!box && nt == 2 && n >= 6) || n >= SG_ROLL_W2_FROM) ? 2 : SG_ROLL_TILE_WAVES; }
 
 // waves per block: the waves of a block walk neighbouring strips row for row, so a block's loads of one row step are one
 // contiguous run of the frame row
