@@ -589,6 +589,26 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #ifndef SG_ROLL_TR12
 #define SG_ROLL_TR12 20
 #endif
+#ifndef SG_ROLL_TRG11
+#define SG_ROLL_TRG11 0          /* A/B builds: one-term general form (derivative frames), tile rows for every half window 11 .. 16 (0 = the table in roll_tile_rows) */
+#endif
+// one-term general form (derivative frames), half windows 8 .. 10, d = (0,2), 64 frames, ms: three waves per SIMD with 12 / 10 / 10 rows (rounds 4-5) 1.67 / 1.88 / 1.95;
+// TWO waves per SIMD: 16 rows 1.63 / 1.71 / 1.80, 20 rows 1.56 / 1.67 / 1.70-1.73, 24 rows 1.53 / 1.66 / 1.72, 28 rows 1.52 / 1.65 / 1.71
+#ifndef SG_ROLL_TRG8
+#define SG_ROLL_TRG8 24
+#endif
+#ifndef SG_ROLL_TRG9
+#define SG_ROLL_TRG9 24
+#endif
+#ifndef SG_ROLL_TRG10
+#define SG_ROLL_TRG10 20
+#endif
+#ifndef SG_ROLL_TRN2
+#define SG_ROLL_TRN2 0           /* A/B builds: the fused two-output form (gradient) with one term per frame, tile rows for every half window >= 8 (0 = the table in roll_tile_rows) */
+#endif
+#ifndef SG_ROLL_W2G_FROM
+#define SG_ROLL_W2G_FROM 8       /* the one-term general form runs two waves per SIMD from this half window on */
+#endif
 #ifndef SG_ROLL_TR13
 #define SG_ROLL_TR13 0           // A/B builds: tile rows for every half window 13 .. 16 (0 = the table in roll_tile_rows)
 #endif
@@ -598,17 +618,24 @@ constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
     // half window 8: 16 + 16 rows do not fit three waves per SIMD, 10 + 16 do (with 20 bytes of scratch): 6.92 vs 7.61 ms per 256 frames
     // (12 rows 6.93, 8 rows 7.21; profiles/r04_2d_tile_experiments.txt)
     if (box && nt == 2 && nout == 1 && n == 8) return SG_ROLL_TR8;
-    if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && n == 8) return 12;     // one term: 1.65 vs 1.97 ms per 64 frames (10 rows: 1.70)
+    if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && n == 8) return SG_ROLL_TRG8;
     // half windows 9, 10 (64 frames, ms, tile vs walk): n = 9 additive 1.97 vs 2.25, one term 1.85 vs 2.09 (10 rows; 8 rows 2.05 / 1.95);
     // n = 10 additive 2.14 vs 2.31 (8 rows; 10 spill: 2.16), one term 1.91 vs 2.13 (10 rows, 20 bytes of scratch; 8 rows 2.04)
     if (box && nt == 2 && nout == 1 && (n == 9 || n == 10)) return n == 9 ? SG_ROLL_TR9 : SG_ROLL_TR10;
     if (box && nt == 2 && nout == 1 && (n == 11 || n == 12)) return n == 11 ? SG_ROLL_TR11 : SG_ROLL_TR12;
     if (box && nt == 2 && nout == 1 && n >= 13) return SG_ROLL_TR13 ? SG_ROLL_TR13 : (n == 14 ? 16 : 18);
-    if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && (n == 9 || n == 10)) return 10;
+    if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && (n == 9 || n == 10)) return n == 9 ? SG_ROLL_TRG9 : SG_ROLL_TRG10;
+    // one-term general form (derivative frames d = (0,1), (1,0), (0,2), ...) at two waves per SIMD, d = (0,2), 64 frames, ms (profiles/r06_2d_tiles_n11_16.txt):
+    // n = 11: walk 2.03, 16 rows 1.84, 20 rows 1.76; 12: 2.05 / 1.91 / 1.85; 13: 2.16 / 2.03 / 1.97; 14: 2.26 / 2.12 / 2.07; 15: 2.30-2.32, 12 / 14 / 16 rows 2.46 / 2.33 / 2.30
+    // (20 spill); 16: 2.31-2.36, 12 / 14 / 16 rows 2.57 / 2.41 / 2.46: the walk stays at 15 and 16
+    if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt == 1 && n >= 11) return SG_ROLL_TRG11 ? SG_ROLL_TRG11 : (n <= 14 ? 20 : 0);
     if (SG_ROLL_TILE_GENERAL && !box && nout == 1 && nt <= 2 && n <= 7) return SG_ROLL_TILE_ROWS;
     // the fused two- / three-output forms with one term per frame (gradient of order <= 2, Hessian of order <= 3): the three Hessian frames
     // of 64 x 4096^2 at n = 7 in 3.54 ms instead of 4.02 (2 waves per SIMD: 178 registers)
     if (SG_ROLL_TILE_GENERAL && !box && nout >= 2 && nt == 1 && n <= 7) return SG_ROLL_TILE_ROWS;
+    // the same form at half windows 8 .. 12 (gradient of order <= 2, 64 frames, ms, tools/ab_2d_gradient.py; the tile's frames are the walk's bits):
+    // n = 8: walk 2.71, 16 rows 2.51, 20 rows 2.63; 9: 3.16 / 2.73 / 2.75; 10: 3.11 / 2.91 / 2.93; 11: 3.54 / 3.19 / 3.22; 12: 3.51 / 3.21 / 3.42 (spills)
+    if (SG_ROLL_TILE_GENERAL && !box && nout == 2 && nt == 1 && n >= 8) return SG_ROLL_TRN2 ? SG_ROLL_TRN2 : (n <= 12 ? 16 : 0);
     return 0;
 }
 #ifndef SG_ROLL_TILE_WAVES
@@ -618,7 +645,10 @@ constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
 #ifndef SG_ROLL_W2_FROM
 #define SG_ROLL_W2_FROM 11       /* tiles of half windows >= this run at TWO waves per SIMD (256 registers: taller tiles) */
 #endif
-constexpr int roll_tile_waves(int n, int nt = 2, bool box = true, int nout = 1) { return (nout >= 2 || (!box && nt == 2 && n >= 6) || n >= SG_ROLL_W2_FROM) ? 2 : SG_ROLL_TILE_WAVES; }
+constexpr int roll_tile_waves(int n, int nt = 2, bool box = true, int nout = 1)
+{
+    return (nout >= 2 || (!box && nt == 2 && n >= 6) || (!box && nt == 1 && n >= SG_ROLL_W2G_FROM) || n >= SG_ROLL_W2_FROM) ? 2 : SG_ROLL_TILE_WAVES;
+}
 
 // waves per block: the waves of a block walk neighbouring strips row for row, so a block's loads of one row step are one
 // contiguous run of the frame row
