@@ -530,6 +530,41 @@ def test_fused_gradient_hessian_laplacian_batch(sg, sgo, torch_gpu):
     assert same_bits(lap[0].cpu().numpy()[:, :cols], ref32[:, :cols]), "rectangular laplacian vs the reference's xx + yy"
 
 
+@pytest.mark.parametrize("n", range(8, 17))
+def test_fused_gradient_at_large_half_windows(sg, sgo, torch_gpu, n):
+    """savgol2d_gradient_batch_f32 at half windows 8 .. 16 on frames with 16-byte aligned rows: the fused two-output form runs 16-row tiles on two
+    waves per SIMD at n = 8 .. 12 (round 6; interior strips, both edge strips, several row tiles) and the strip walk above; both frames against the
+    double oracle under the one rule, all three boundary modes, nothing outside the output region.  Reference: savgol2d_gradient,
+    /root/reference/src/savgol2d.c:462-501."""
+    torch = torch_gpu
+    rng = np.random.default_rng(808 + n)
+    L = sg.lib()
+    images, rows, cols, stride = 2, 120 + 2 * n, 520, 520
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    x = np.zeros((images, rows, stride), np.float32)
+    for k in range(images):
+        x[k, :, :cols] = (np.sin(0.07 * xx + k) * np.cos(0.04 * yy) + 0.002 * xx + rng.normal(0, 0.1, (rows, cols))).astype(np.float32)
+    d = torch.from_numpy(x).cuda()
+    pitch = rows * stride
+    for order in (2, 3):
+        for b in range(3):
+            gx, gy = torch.full_like(d, -3.0), torch.full_like(d, -3.0)
+            assert L.savgol2d_gradient_batch_f32(n, n, order, d.data_ptr(), rows, cols, stride, pitch, gx.data_ptr(), gy.data_ptr(), stride, pitch, images,
+                                                 0.5, 2.0, b, None) == 0, sg.last_error()
+            sel = np.zeros((rows, stride), bool)
+            if b == 0:
+                sel[n:rows - n, n:cols - n] = True
+            else:
+                sel[:, :cols] = True
+            for name, got, (dx, dy) in (("gx", gx, (1, 0)), ("gy", gy, (0, 1))):
+                g = got.cpu().numpy()
+                o = sgo.Filter2D(n, n, order, dx, dy, 0.5, 2.0)
+                for k in range(images):
+                    assert np.all(g[k][~sel] == -3.0), (n, order, b, name)
+                    hi = o.apply_f64acc(x[k], cols, b)
+                    check(normwise(g[k][sel], hi[sel]), bar2d(o, x[k], cols, b, hi, sel), ("fused gradient", n, order, b, name, k))
+
+
 def test_randomized_2d_configurations(sg, sgo, torch_gpu):
     """200 random (n, order, dx, dy, deltas, boundary, frame size, pitch, base alignment) draws.  Method 1 must equal
     the reference order bit for bit whatever kernel serves it; method 2 / 0 must stay within the forward error bound
