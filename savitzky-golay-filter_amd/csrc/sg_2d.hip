@@ -281,8 +281,14 @@ static int roll_passes_hf(int n, int terms, const Job2D &job, const float *facto
     float sigma[SEP_MAX_TERMS] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (dense && terms <= SEP_MAX_TERMS) hf_term_sums(n, terms, factors, dense, sigma);
     Job2D j = job;
-    for (int t = 0; t < terms; ++t) {
-        const int rc = sg2d_launch_rolling_hf(n, j, factors + t * tstride, scale, t < SEP_MAX_TERMS ? sigma[t] : 0.0f, images, cu_count, st);
+    int t = 0;
+    if (terms >= 2 && terms <= SEP_MAX_TERMS && !job.accumulate &&
+        sg2d_launch_rolling_hf(n, j, factors, scale, sigma[0], factors + tstride, sigma[1], images, cu_count, st) == 0) {      // two terms from one trip of every row through LDS
+        t = 2;
+        j.accumulate = 1;
+    }
+    for (; t < terms; ++t) {
+        const int rc = sg2d_launch_rolling_hf(n, j, factors + t * tstride, scale, t < SEP_MAX_TERMS ? sigma[t] : 0.0f, nullptr, 0.0f, images, cu_count, st);
         if (rc != 0) return t == 0 ? rc : -1;
         j.accumulate = 1;
     }

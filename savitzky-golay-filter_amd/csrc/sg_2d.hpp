@@ -91,11 +91,11 @@ struct SepPlan {
     int    terms[SEP_MAX_OUTPUTS];      // factors are stored output after output, term after term
     float  scale[SEP_MAX_OUTPUTS];
     float *out[SEP_MAX_OUTPUTS];        // same row stride / image pitch for all
-    int    transposed;                  // 1: vertical pass first (every output y-dominant: deriv_y >= 2, deriv_y > deriv_x), see sg_2d_sep.hip
+    int    transposed;                  // 1: vertical pass first (every output y-dominant: deriv_y >= 1, deriv_y > deriv_x), see sg_2d_sep.hip
     int    centre;                      // 1: the first pass runs on centred samples (s - c) and adds c * first_sum[t] back (derivative kernels; sg_2d_hf.hip, R6.8)
     float  first_sum[SEP_MAX_TERMS];    // what term t's first-pass factor sums to in the reference's dense table (unscaled), single-output plans
 };
-inline bool sg2d_y_dominant(int deriv_x, int deriv_y) { return deriv_y >= 2 && deriv_y > deriv_x; }
+inline bool sg2d_y_dominant(int deriv_x, int deriv_y) { return deriv_y >= 1 && deriv_y > deriv_x; }
 
 // Row bands of the strip kernels (sg_2d_roll.hip, sg_2d_dense.hip): an item = one strip x one band, `nwaves` resident
 // waves take items round robin.  Every band pays 2n warm-up rows (weighted `warm`: they cost full work in the dense
@@ -162,17 +162,20 @@ inline int sg2d_launch_rolling2(int n, int terms, const Job2D &job, const float 
 
 // sg_2d_hf.hip: ONE term of a kernel with the HORIZONTAL pass first (kernels whose x factor cancels harder than their y factor: deriv_x >= 2,
 // deriv_x > deriv_y); job.accumulate: out += result.  Built in three half-window groups (Makefile).  0 = launched, 1 = not covered, -1 = error.
-int sg2d_launch_rolling_hf_g0(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st);
-int sg2d_launch_rolling_hf_g1(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st);
-int sg2d_launch_rolling_hf_g2(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st);
-inline int sg2d_launch_rolling_hf(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st)
+int sg2d_launch_rolling_hf_g0(int n, const Job2D &job, const float *factors, float scale, float sigma, const float *factors2, float sigma2, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling_hf_g1(int n, const Job2D &job, const float *factors, float scale, float sigma, const float *factors2, float sigma2, unsigned images, int cu_count, hipStream_t st);
+int sg2d_launch_rolling_hf_g2(int n, const Job2D &job, const float *factors, float scale, float sigma, const float *factors2, float sigma2, unsigned images, int cu_count, hipStream_t st);
+// factors2 / sigma2: a second term in the same launch (NULL: one term); 1 = not covered (the caller launches the terms one by one)
+inline int sg2d_launch_rolling_hf(int n, const Job2D &job, const float *factors, float scale, float sigma, const float *factors2, float sigma2, unsigned images, int cu_count,
+                                  hipStream_t st)
 {
-    if (sg2d_launch_rolling_hf_g0(n, job, factors, scale, sigma, images, cu_count, st) == 0) return 0;
-    if (sg2d_launch_rolling_hf_g1(n, job, factors, scale, sigma, images, cu_count, st) == 0) return 0;
-    return sg2d_launch_rolling_hf_g2(n, job, factors, scale, sigma, images, cu_count, st);
+    if (sg2d_launch_rolling_hf_g0(n, job, factors, scale, sigma, factors2, sigma2, images, cu_count, st) == 0) return 0;
+    if (sg2d_launch_rolling_hf_g1(n, job, factors, scale, sigma, factors2, sigma2, images, cu_count, st) == 0) return 0;
+    return sg2d_launch_rolling_hf_g2(n, job, factors, scale, sigma, factors2, sigma2, images, cu_count, st);
 }
-// which pass order suits a kernel in fp32 (sg_2d_hf.hip's header, tools/emulate_2d_passes.py): the pass that cancels harder goes first
-inline bool sg2d_x_dominant(int deriv_x, int deriv_y) { return deriv_x >= 2 && deriv_x > deriv_y; }
+// which pass order suits a kernel in fp32 (sg_2d_hf.hip's header, tools/emulate_2d_passes.py, tools/gx_margin_probe.py): the pass that cancels harder -- the
+// derivative of higher order, FIRST derivatives included since the end of round 6 -- goes first
+inline bool sg2d_x_dominant(int deriv_x, int deriv_y) { return deriv_x >= 1 && deriv_x > deriv_y; }
 
 // sg_2d_dense.hip: the bit-exact dense kernel on packed math, square and rectangular windows with half windows <= DENSE_ROLL_MAX_N.
 // 0 = launched, 1 = not covered, -1 = error.  h_w = the kernel on the host, [2ny+1][2nx+1].

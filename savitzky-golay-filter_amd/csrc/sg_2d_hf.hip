@@ -12,9 +12,9 @@
 // Structure: the strip walk of sg_2d_roll.hip with the roles of the two stores swapped.  A wave owns a 256-column strip and walks down a band
 // of rows; every input row goes through a wave-private LDS row ONCE, as it arrives (each lane writes its 4 columns, reads back the 4 + 2N
 // columns of its window), the lane computes  h = Q (*)x row  for its 4 columns, and the REGISTER RING holds the last 2N+1 rows of h.  The
-// vertical pass  out = G (*)y h  then reads the ring with literal slots and stores straight from registers.  One term per launch; kernels of
-// rank > 1 run one launch per term, the later ones accumulating (out += ...: 8 + 12 B per pixel and term instead of 8 -- these are
-// derivative frames of order >= 4, not a BASELINE shape).
+// vertical pass  out = G (*)y h  then reads the ring with literal slots and stores straight from registers.  One or TWO terms per launch (two: half windows
+// <= 8, x factors of the same parity -- the x-derivative frame of an order-3 gradient is x and x^3: both rings are fed from one trip of the row through
+// LDS and one set of folded pairs); further terms run one launch each, accumulating (out += ...: 8 + 12 B per pixel and term instead of 8).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -39,16 +39,17 @@ struct Hf {
     static_assert(U % PR == 0 && P >= LEAD, "prefetched output rows: slot = row % PR must carry over from one group of U rows to the next");
 };
 
-template <int N>
+template <int N, int NT>
 struct HfTaps {
-    f32x2 g[Hf<N>::NP], q[Hf<N>::NP];      // taps 0..N (the mirrored half follows from the parity); q already times the output scale
-    f32x2 sy, sx;                           // +1 / -1
-    f32x2 sig;                              // what this term's x factor must sum to (both halves equal): see convert()
+    f32x2 g[NT][Hf<N>::NP], q[NT][Hf<N>::NP];      // taps 0..N (the mirrored half follows from the parity); q already times the output scale
+    f32x2 sy[NT], sx;                               // +1 / -1 (the x parity is common to the terms of one launch)
+    f32x2 sig[NT];                                  // what each term's x factor must sum to (both halves equal): see convert()
 };
+constexpr int HF_TWO_TERMS_MAX_N = 8;               // two rings of h rows: 2 x 4 (2N + 1 + P) registers
 
 // MODE 1: the strip's 256 input columns are inside the frame, all SW output columns are stored, rows 16-byte aligned; 0: remapped scalar loads, masked stores
-template <int N, int MODE, bool ACC>
-__device__ __forceinline__ void hf_item(const Job2D &job, const HfTaps<N> &taps, float *mine, const float *in, float *out, int xload, int yb, int nout,
+template <int N, int MODE, bool ACC, int NT>
+__device__ __forceinline__ void hf_item(const Job2D &job, const HfTaps<N, NT> &taps, float *mine, const float *in, float *out, int xload, int yb, int nout,
                                         int lane, int xlo, int xhi, int ylo, int yhi)
 {
     typedef Hf<N> R;
@@ -70,7 +71,8 @@ __device__ __forceinline__ void hf_item(const Job2D &job, const HfTaps<N> &taps,
     float *const wr = mine + 4 * R::HL + 4 * lane;
     const float *const rd = mine + 4 * lane;
 
-    f32x4 win[R::U];          // slot r % U: row r, raw until its conversion, then h
+    f32x4 win[R::U];          // slot r % U: row r, raw until its conversion, then h (of term 0)
+    f32x4 win2[NT == 2 ? R::U : 1];      // h of term 1
 
     // the horizontal pass of one row: through the LDS row and back, folded taps (the pass of sg_2d_roll.hip's hterm, general form)
     auto convert = [&](auto sc) {
@@ -98,7 +100,7 @@ __device__ __forceinline__ void hf_item(const Job2D &job, const HfTaps<N> &taps,
             const int idx = R::D + j;
             pr[j] = (idx & 1) ? (((idx >> 1) & 1) ? pk_straddle(e[idx >> 1], e[(idx >> 1) + 1]) : pk_middle(e[idx >> 1], e[(idx >> 1) + 1])) : e[idx >> 1];
         }
-        f32x2 f[2][N + 1], r[2];
+        f32x2 f[2][N + 1], r[2], r2[2];
         auto fold = [&](auto kc) {
             constexpr int k = decltype(kc)::value;
             if constexpr (k < N) {
@@ -113,38 +115,54 @@ __device__ __forceinline__ void hf_item(const Job2D &job, const HfTaps<N> &taps,
         static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
             constexpr int k = decltype(kc)::value;
             if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
-            if constexpr (k == 0) { r[0] = pk_mul_sgpr<0>(taps.q[0], f[0][0]); r[1] = pk_mul_sgpr<0>(taps.q[0], f[1][0]); }
-            else { pk_fma_sgpr<(k & 1)>(r[0], taps.q[k >> 1], f[0][k]); pk_fma_sgpr<(k & 1)>(r[1], taps.q[k >> 1], f[1][k]); }
+            if constexpr (k == 0) { r[0] = pk_mul_sgpr<0>(taps.q[0][0], f[0][0]); r[1] = pk_mul_sgpr<0>(taps.q[0][0], f[1][0]); }
+            else { pk_fma_sgpr<(k & 1)>(r[0], taps.q[0][k >> 1], f[0][k]); pk_fma_sgpr<(k & 1)>(r[1], taps.q[0][k >> 1], f[1][k]); }
+            if constexpr (NT == 2) {                         // the second term's taps on the same folded pairs
+                if constexpr (k == 0) { r2[0] = pk_mul_sgpr<0>(taps.q[1][0], f[0][0]); r2[1] = pk_mul_sgpr<0>(taps.q[1][0], f[1][0]); }
+                else { pk_fma_sgpr<(k & 1)>(r2[0], taps.q[1][k >> 1], f[0][k]); pk_fma_sgpr<(k & 1)>(r2[1], taps.q[1][k >> 1], f[1][k]); }
+            }
             return true;
         });
-        r[0] = __builtin_elementwise_fma(taps.sig, cc, r[0]);
-        r[1] = __builtin_elementwise_fma(taps.sig, cc, r[1]);
+        r[0] = __builtin_elementwise_fma(taps.sig[0], cc, r[0]);
+        r[1] = __builtin_elementwise_fma(taps.sig[0], cc, r[1]);
         win[s] = f32x4{r[0].x, r[0].y, r[1].x, r[1].y};
+        if constexpr (NT == 2) {
+            r2[0] = __builtin_elementwise_fma(taps.sig[1], cc, r2[0]);
+            r2[1] = __builtin_elementwise_fma(taps.sig[1], cc, r2[1]);
+            win2[s] = f32x4{r2[0].x, r2[0].y, r2[1].x, r2[1].y};
+        }
     };
-    // the vertical pass of the output row whose first h row sits in slot u0
+    // the vertical pass of the output row whose first h row sits in slot u0: sum over the launch's terms of G_t (*) h_t
     auto vertical = [&](auto u0c) -> f32x4 {
         constexpr int u0 = decltype(u0c)::value;
-        f32x2 v[2], f[2][N + 1];
-        auto fold = [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const f32x4 a = win[(u0 + k) % R::U], b = win[(u0 + 2 * N - k) % R::U];
-            if constexpr (k < N) {
-                f[0][k] = pk_fold(taps.sy, f32x2{b.x, b.y}, f32x2{a.x, a.y});
-                f[1][k] = pk_fold(taps.sy, f32x2{b.z, b.w}, f32x2{a.z, a.w});
-            } else {
-                f[0][N] = f32x2{a.x, a.y};
-                f[1][N] = f32x2{a.z, a.w};
-            }
-        };
-        fold(std::integral_constant<int, 0>{});
-        static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
-            constexpr int k = decltype(kc)::value;
-            if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
+        f32x2 v[2];
+        static_for<NT>([&](auto tc) -> bool {
+            constexpr int t = decltype(tc)::value;
+            f32x2 f[2][N + 1];
+            auto fold = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                f32x4 a, b;
+                if constexpr (t == 0) { a = win[(u0 + k) % R::U]; b = win[(u0 + 2 * N - k) % R::U]; }
+                else                  { a = win2[(u0 + k) % R::U]; b = win2[(u0 + 2 * N - k) % R::U]; }
+                if constexpr (k < N) {
+                    f[0][k] = pk_fold(taps.sy[t], f32x2{b.x, b.y}, f32x2{a.x, a.y});
+                    f[1][k] = pk_fold(taps.sy[t], f32x2{b.z, b.w}, f32x2{a.z, a.w});
+                } else {
+                    f[0][N] = f32x2{a.x, a.y};
+                    f[1][N] = f32x2{a.z, a.w};
+                }
+            };
+            fold(std::integral_constant<int, 0>{});
+            static_for(std::make_integer_sequence<int, N + 1>{}, [&](auto kc) -> bool {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < N) fold(std::integral_constant<int, k + 1>{});
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if constexpr (k == 0) v[c] = pk_mul_sgpr<0>(taps.g[0], f[c][0]);
-                else pk_fma_sgpr<(k & 1)>(v[c], taps.g[k >> 1], f[c][k]);
-            }
+                for (int c = 0; c < 2; ++c) {
+                    if constexpr (k == 0 && t == 0) v[c] = pk_mul_sgpr<0>(taps.g[t][0], f[c][0]);
+                    else pk_fma_sgpr<(k & 1)>(v[c], taps.g[t][k >> 1], f[c][k]);
+                }
+                return true;
+            });
             return true;
         });
         return f32x4{v[0].x, v[0].y, v[1].x, v[1].y};
@@ -200,8 +218,8 @@ __device__ __forceinline__ void hf_item(const Job2D &job, const HfTaps<N> &taps,
 
 constexpr int hf_min_waves(int n) { return n <= 10 ? 2 : 1; }
 
-template <int N, bool ACC>
-__global__ __launch_bounds__(64 * Hf<N>::WPB, hf_min_waves(N)) void sg2d_rolling_hf_kernel(const Job2D job, const HfTaps<N> taps, unsigned strips, unsigned bands,
+template <int N, bool ACC, int NT>
+__global__ __launch_bounds__(64 * Hf<N>::WPB, NT == 2 ? 1 : hf_min_waves(N)) void sg2d_rolling_hf_kernel(const Job2D job, const HfTaps<N, NT> taps, unsigned strips, unsigned bands,
                                                                                               int band_rows, unsigned total_items, int aligned)
 {
     typedef Hf<N> R;
@@ -225,32 +243,34 @@ __global__ __launch_bounds__(64 * Hf<N>::WPB, hf_min_waves(N)) void sg2d_rolling
     float *out = job.out + (long long)img * job.out_pitch;
     const int sx = (int)strip * R::SW;
     if (aligned == 3 && sx - 4 * R::HL >= 0 && sx - 4 * R::HL + 256 <= job.cols && sx >= xlo && sx + R::SW <= xhi)
-        hf_item<N, 1, ACC>(job, taps, mine, in, out, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+        hf_item<N, 1, ACC, NT>(job, taps, mine, in, out, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
     else
-        hf_item<N, 0, ACC>(job, taps, mine, in, out, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
+        hf_item<N, 0, ACC, NT>(job, taps, mine, in, out, sx - 4 * R::HL, yb, nout, lane, xlo, xhi, ylo, yhi);
 }
 
 // ---- host ----
-template <int N>
-static bool hf_fill_taps(HfTaps<N> &taps, const float *factors, float scale, float sigma)
+// term t of the launch's taps; false: no definite parity, or (t = 1) an x parity other than term 0's
+template <int N, int NT>
+static bool hf_fill_taps(HfTaps<N, NT> &taps, int t, const float *factors, float scale, float sigma)
 {
-    taps.sig = f32x2{sigma, sigma};
+    taps.sig[t] = f32x2{sigma, sigma};
     const float *q = factors, *g = q + (2 * N + 2);
     float sy, sx;
     if (!vector_parity(g, N, &sy) || !vector_parity(q, N, &sx)) return false;
+    if (t > 0 && sx != taps.sx.x) return false;
     for (int k = 0; k <= N; ++k) {
         const float gk = (k == N && sy < 0.0f) ? 0.0f : g[k];
         const float qk = (k == N && sx < 0.0f) ? 0.0f : (float)((double)q[k] * (double)scale);
-        if (k & 1) { taps.g[k >> 1].y = gk; taps.q[k >> 1].y = qk; }
-        else       { taps.g[k >> 1].x = gk; taps.q[k >> 1].x = qk; }
+        if (k & 1) { taps.g[t][k >> 1].y = gk; taps.q[t][k >> 1].y = qk; }
+        else       { taps.g[t][k >> 1].x = gk; taps.q[t][k >> 1].x = qk; }
     }
-    taps.sy = f32x2{sy, sy};
+    taps.sy[t] = f32x2{sy, sy};
     taps.sx = f32x2{sx, sx};
     return true;
 }
 
-template <int N, bool ACC>
-static int hf_launch(const Job2D &job, const HfTaps<N> &taps, unsigned images, int cu_count, hipStream_t st)
+template <int N, bool ACC, int NT>
+static int hf_launch(const Job2D &job, const HfTaps<N, NT> &taps, unsigned images, int cu_count, hipStream_t st)
 {
     typedef Hf<N> R;
     int aligned = 0;
@@ -261,7 +281,7 @@ static int hf_launch(const Job2D &job, const HfTaps<N> &taps, unsigned images, i
     static int per_cu = 0;
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_hf_kernel<N, ACC>, 64 * R::WPB, lds) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sg2d_rolling_hf_kernel<N, ACC, NT>, 64 * R::WPB, lds) != hipSuccess || nb < 1) nb = 1;
         per_cu = nb > 4 ? 4 : nb;
     }
     const unsigned nwaves = (unsigned)cu_count * (unsigned)per_cu * R::WPB;
@@ -287,31 +307,43 @@ static int hf_launch(const Job2D &job, const HfTaps<N> &taps, unsigned images, i
         Job2D part = job;
         part.in = job.in + (long long)i0 * job.in_pitch;
         part.out = job.out + (long long)i0 * job.out_pitch;
-        hipLaunchKernelGGL((sg2d_rolling_hf_kernel<N, ACC>), dim3(grid), dim3(64 * R::WPB), lds, st, part, taps, strips, bands, band_rows, (unsigned)total, aligned);
+        hipLaunchKernelGGL((sg2d_rolling_hf_kernel<N, ACC, NT>), dim3(grid), dim3(64 * R::WPB), lds, st, part, taps, strips, bands, band_rows, (unsigned)total, aligned);
     }
     return 0;
 }
 
 template <int N>
-static int hf_dispatch(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st)
+static int hf_dispatch(int n, const Job2D &job, const float *factors, float scale, float sigma, const float *factors2, float sigma2, unsigned images, int cu_count,
+                       hipStream_t st)
 {
     if (n == N) {
-        HfTaps<N> taps;
+        if (factors2) {
+            if constexpr (N <= HF_TWO_TERMS_MAX_N) {
+                if (job.accumulate) return 1;
+                HfTaps<N, 2> taps;
+                memset(&taps, 0, sizeof(taps));
+                if (!hf_fill_taps<N, 2>(taps, 0, factors, scale, sigma) || !hf_fill_taps<N, 2>(taps, 1, factors2, scale, sigma2)) return 1;
+                return hf_launch<N, false, 2>(job, taps, images, cu_count, st);
+            } else return 1;
+        }
+        HfTaps<N, 1> taps;
         memset(&taps, 0, sizeof(taps));
-        if (!hf_fill_taps<N>(taps, factors, scale, sigma)) return 1;
-        return job.accumulate ? hf_launch<N, true>(job, taps, images, cu_count, st) : hf_launch<N, false>(job, taps, images, cu_count, st);
+        if (!hf_fill_taps<N, 1>(taps, 0, factors, scale, sigma)) return 1;
+        return job.accumulate ? hf_launch<N, true, 1>(job, taps, images, cu_count, st) : hf_launch<N, false, 1>(job, taps, images, cu_count, st);
     }
-    if constexpr (N < SG_HF_MAX_N) return hf_dispatch<N + 1>(n, job, factors, scale, sigma, images, cu_count, st);
+    if constexpr (N < SG_HF_MAX_N) return hf_dispatch<N + 1>(n, job, factors, scale, sigma, factors2, sigma2, images, cu_count, st);
     else return 1;
 }
 
 // ONE term (factors: Q[0..2N], pad, G[0..2N], pad) of a kernel, horizontal pass first; job.accumulate: out += result.  sigma: what this term's scaled x
-// factor sums to in the reference's dense table (sg_2d.hip: hf_term_sums).
-// 0 = launched, 1 = not covered by this object (half window outside SG_HF_MIN_N..SG_HF_MAX_N, no definite parity), -1 = error.
-int SG_HF_FN(int n, const Job2D &job, const float *factors, float scale, float sigma, unsigned images, int cu_count, hipStream_t st)
+// factor sums to in the reference's dense table (sg_2d.hip: hf_term_sums).  factors2 / sigma2 (may be NULL): a SECOND term in the same launch (half
+// windows <= 8, both x factors of one parity, not accumulating).
+// 0 = launched, 1 = not covered by this object (half window outside SG_HF_MIN_N..SG_HF_MAX_N, no definite parity, no two-term form), -1 = error.
+int SG_HF_FN(int n, const Job2D &job, const float *factors, float scale, float sigma, const float *factors2, float sigma2, unsigned images, int cu_count,
+             hipStream_t st)
 {
     if (n < SG_HF_MIN_N || n > SG_HF_MAX_N) return 1;
-    return hf_dispatch<SG_HF_MIN_N>(n, job, factors, scale, sigma, images, cu_count, st);
+    return hf_dispatch<SG_HF_MIN_N>(n, job, factors, scale, sigma, factors2, sigma2, images, cu_count, st);
 }
 
 }  // namespace sg

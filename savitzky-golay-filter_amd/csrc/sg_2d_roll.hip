@@ -603,6 +603,9 @@ constexpr int roll_min_waves(int n, int nt, int nout) { return n >= 9 ? 2 : ((nt
 #ifndef SG_ROLL_TRG10
 #define SG_ROLL_TRG10 20
 #endif
+#ifndef SG_ROLL_TRN2T2
+#define SG_ROLL_TRN2T2 0         /* A/B builds: the fused two-output form with TWO terms per frame (gradient of order 3, 4), half windows <= 8: tile rows (0 = the table in roll_tile_rows) */
+#endif
 #ifndef SG_ROLL_TRN2
 #define SG_ROLL_TRN2 0           /* A/B builds: the fused two-output form (gradient) with one term per frame, tile rows for every half window >= 8 (0 = the table in roll_tile_rows) */
 #endif
@@ -633,6 +636,9 @@ constexpr int roll_tile_rows(int n, int nt, int nout, bool box)
     // the fused two- / three-output forms with one term per frame (gradient of order <= 2, Hessian of order <= 3): the three Hessian frames
     // of 64 x 4096^2 at n = 7 in 3.54 ms instead of 4.02 (2 waves per SIMD: 178 registers)
     if (SG_ROLL_TILE_GENERAL && !box && nout >= 2 && nt == 1 && n <= 7) return SG_ROLL_TILE_ROWS;
+    // two terms per frame (the gradient of an order-3 or -4 filter -- the usual cubic), 64 frames, ms, walk / 16-row / 20-row tiles (tools/ab_2d_gradient.py --order 3; the
+    // tile's frames are the walk's bits): n = 2: 2.26 / 2.10 / 2.41; 3: 2.71 / 2.13 / 2.17; 5: 3.08 / 2.64 / 2.79; 7: 3.63 / 3.45 / 3.46; 8: 4.20 / 4.17 / 3.87
+    if (SG_ROLL_TILE_GENERAL && !box && nout == 2 && nt == 2 && n <= 8) return SG_ROLL_TRN2T2 ? SG_ROLL_TRN2T2 : (n == 8 ? 20 : 16);
     // the same form at half windows 8 .. 12 (gradient of order <= 2, 64 frames, ms, tools/ab_2d_gradient.py; the tile's frames are the walk's bits):
     // n = 8: walk 2.71, 16 rows 2.51, 20 rows 2.63; 9: 3.16 / 2.73 / 2.75; 10: 3.11 / 2.91 / 2.93; 11: 3.54 / 3.19 / 3.22; 12: 3.51 / 3.21 / 3.42 (spills)
     if (SG_ROLL_TILE_GENERAL && !box && nout == 2 && nt == 1 && n >= 8) return SG_ROLL_TRN2 ? SG_ROLL_TRN2 : (n <= 12 ? 16 : 0);

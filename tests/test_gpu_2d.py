@@ -530,12 +530,12 @@ def test_fused_gradient_hessian_laplacian_batch(sg, sgo, torch_gpu):
     assert same_bits(lap[0].cpu().numpy()[:, :cols], ref32[:, :cols]), "rectangular laplacian vs the reference's xx + yy"
 
 
-@pytest.mark.parametrize("n", range(8, 17))
-def test_fused_gradient_at_large_half_windows(sg, sgo, torch_gpu, n):
-    """savgol2d_gradient_batch_f32 at half windows 8 .. 16 on frames with 16-byte aligned rows: the fused two-output form runs 16-row tiles on two
-    waves per SIMD at n = 8 .. 12 (round 6; interior strips, both edge strips, several row tiles) and the strip walk above; both frames against the
-    double oracle under the one rule, all three boundary modes, nothing outside the output region.  Reference: savgol2d_gradient,
-    /root/reference/src/savgol2d.c:462-501."""
+@pytest.mark.parametrize("n", range(2, 17))
+def test_fused_gradient_every_half_window(sg, sgo, torch_gpu, n):
+    """savgol2d_gradient_batch_f32 at half windows 2 .. 16 on frames with 16-byte aligned rows, orders 2 (one term per frame) and 3 (two terms -- the
+    usual cubic): the fused two-output form runs 16 / 20-row tiles on two waves per SIMD (one term: n <= 12; two terms: n <= 8; round 6 -- interior
+    strips, both edge strips, several row tiles) and the strip walk above; both frames against the double oracle under the one rule, all three
+    boundary modes, nothing outside the output region.  Reference: savgol2d_gradient, /root/reference/src/savgol2d.c:462-501."""
     torch = torch_gpu
     rng = np.random.default_rng(808 + n)
     L = sg.lib()
