@@ -333,6 +333,13 @@ int enqueue_batch(const char *who, const SavgolFilter *f, const T *d_in, T *d_ou
     if (job.dt_inv != 1.0f) job.flags |= sg::JOB_SCALE;
     if (((uintptr_t)d_in % 16 == 0) && (in_ld % E == 0)) job.flags |= sg::JOB_VEC_IN;
     if (((uintptr_t)d_out % 16 == 0) && (out_ld % E == 0) && (job.out_shift % E == 0)) job.flags |= sg::JOB_VEC_OUT;
+    if (sizeof(T) == 4 && f->config.derivative >= 1) {
+        // fp32 derivative filters run on centred tiles (sg1d_tile_body, JOB_CENTRE): what a constant comes out as is taken from the reference's own table
+        double wsum = 0.0;
+        for (int k = 0; k <= 2 * n; ++k) wsum += (double)f->center_weights[k];
+        job.centre_sum = (float)wsum;
+        job.flags |= sg::JOB_CENTRE;
+    }
 
     if (sizeof(T) == 8) {
         if (!plan->sym) {

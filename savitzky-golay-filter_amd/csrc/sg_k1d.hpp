@@ -523,9 +523,52 @@ __device__ __forceinline__ void sg1d_tile_body(const Job1D &job, const typename 
         }
     }
 
+    // ---- derivative filters (JOB_CENTRE, fp32): centre the tile.  sum_k w_k x_k = sum_k w_k (x_k - c) + c sum_k w_k for any c; with c = the mean of the
+    // tile's body the partial sums / block moments below meet the signal's variation across the tile instead of its offset.  A filter whose
+    // weights sum to ~0 on a signal riding on a large offset stood at 1.1-1.4 x the reference's own error (block moments from half window 20: the
+    // blocks' shares cancel only after each has been rounded at the offset's size; tools/offset_probe_1d.py, R6.16).  Smoothing filters do not
+    // come here (the flag is off: nothing of this runs).  After the in-place slots have been written -- those must hold the raw samples.
+    T centre = T(0);
+    if (job.flags & JOB_CENTRE) {                          // uniform
+        // c = the MEAN of the tile's body (a single sample of a zero-mean signal would double what the sums meet): every lane's partial sum, then an
+        // xor butterfly -- both partners of a step add the same two numbers, so all 64 lanes end with the same bits
+        VT p[VPL + 1];
+        T part = T(0);
+#pragma unroll
+        for (int s = 0; s < VPL + 1; ++s) {
+            if (s < VPL || lane < 2 * HV) {
+                p[s] = *row_vec(s);
+                // slab vectors HV .. HV + TV - 1 are the body: vector index lane + 64 s
+                const int v = lane + 64 * s;
+                if (v >= HV && v < HV + TV) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) part += vget(p[s], e);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        centre = part * (T(1) / T(TW));
+        if (!(centre - centre == T(0))) centre = T(0);     // Inf / NaN in the tile: leave it as it is
+#pragma unroll
+        for (int s = 0; s < VPL + 1; ++s) {
+            if (s < VPL || lane < 2 * HV) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) vset(p[s], e, vget(p[s], e) - centre);
+                *row_vec(s) = p[s];
+            }
+        }
+        wave_lds_sync();
+    }
+
     // ---- the convolution: lane owns outputs [lane*R, lane*R + R) of the tile ----
     T acc[R];
     CV::run(slab + 16 * (lane * (VPL + 1)), taps, acc, job.flags);
+    if (job.flags & JOB_CENTRE) {
+        const T back = centre * (T)job.centre_sum;
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] += back;
+    }
     if (job.flags & JOB_SCALE) {
         const T s = (T)job.dt_inv;
 #pragma unroll

@@ -94,6 +94,7 @@ struct Job1D {
     // tile order (sg1d_tile_body): 0 = each XCD sweeps one contiguous eighth of the tiles; s in 1..31 = chunks of 2^s blocks dealt to the XCDs round
     // robin (the eight fronts stay within 8 * 2^s blocks of each other); >= 32 = launch order.  SAVGOL_HIP_1D_XCD_CHUNK_LOG2, tools/placement_1d.py
     unsigned    xcd_chunk_log2;
+    float       centre_sum;             // JOB_CENTRE: the sum of the reference's centre weights (what a constant input comes out as, before dt_inv)
 };
 // The fused strided (array-of-structs) kernel, sg1d_strided_kernel<N> (reference savgol_apply_strided, src/savgolFilter.c:877-934):
 // sample i of channel c is the float at in + c * in_pitch + i * in_stride (bytes; the field offset is folded into `in`), all
@@ -172,6 +173,8 @@ enum : unsigned {
     JOB_VEC_OUT    = 1u << 10,          // output rows (after out_shift) are 16-B aligned
     JOB_ODD_TAPS   = 1u << 11,          // fp64: taps.wd holds taps 0..n, tap 2n-k = -tap k (odd derivative) instead of +tap k
     JOB_EDGE_NEGATE = 1u << 12,         // edge items: negate the leading-edge outputs (SAVGOL_BATCH_CORRECT_LEADING_EDGE, odd derivatives)
+    JOB_CENTRE     = 1u << 13,          // fp32 derivative filters: the tile's samples are centred on its first body sample before the inner products,
+                                        //   c * centre_sum is added back (sg1d_tile_body; R6.16)
 };
 
 }  // namespace sg

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job
     const int sub = lane >> 5, chunk = lane & 31;                                                 // row of the pair, 16-byte chunk of the row
     const size_t col = (size_t)strip * 128 + (size_t)chunk * 4;
 
+    f32x2 cen = f32x2{0.0f, 0.0f}, backdt = f32x2{0.0f, 0.0f};       // fused bank, derivative filters: what the tile's rows are centred on (set before the first row is fed)
     // source of row pair i: slab row r = history index t0 - 2N + r (history: ring contents, then this call's samples)
     const bool inside = t0 >= 2 * N && t0 + TR <= (long long)job.ticks;                           // uniform: every row is one of this call's samples
     const float *const p0 = job.samples + (size_t)(inside ? t0 - 2 * N + sub : 0) * job.streams + col;
@@ -261,9 +262,11 @@ __global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job
             constexpr int m = r - 2 * N;
             f32x2 a = acc[0][m];
             if constexpr (CH == 2) a = a + acc[1][m];
+
             const long long tt = t0 + m;
             const bool has_out = tt < (long long)job.ticks && job.received0 + (unsigned long long)tt + 1 >= (unsigned long long)R::WS;   // uniform (reference :166-170)
-            const f32x2 y = a * f32x2{job.dt_inv, job.dt_inv};
+            // fused bank: (a + c * sum_k w_k) * dt_inv in one multiply-add (backdt = c * sum_k w_k * dt_inv, zero unless the tile is centred)
+            const f32x2 y = (MOM > 0 || FMA) ? __builtin_elementwise_fma(a, f32x2{job.dt_inv, job.dt_inv}, backdt) : a * f32x2{job.dt_inv, job.dt_inv};
             float *orow = job.out + (size_t)(tt < (long long)job.ticks ? tt : 0) * job.streams;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(orow, 0, has_out ? row_bytes : 0, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), rs, (int)voff, 0, SG_DMA_STORE_AUX);
@@ -272,8 +275,44 @@ __global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job
     // Step g consumes pair g (already in xa, xb), after it has waited for pair g + 1 and issued its LDS reads (their latency hides behind
     // the arithmetic), and ends by issuing DMA g + DP into the ring slot pair g has just left.  A row without an output still issues its
     // store (into an empty descriptor), so the queue arithmetic above is static.
+    // ---- fused bank, derivative filters (job.centre): c = the mean of EIGHT real samples of each stream (a single sample of a zero-mean stream would
+    // double what the sums meet).  A tile whose rows are all real takes its first eight rows out of LDS once their four DMA pairs have landed -- no
+    // memory request of its own: eight extra 8-byte loads per lane and tile cost config 3 12 % (the kernel lives on its request rate); the few tiles of
+    // a bank's first 2N ticks (rows before the first sample: the ring's zeros, feeding only outputs that are not stored) load eight samples spread
+    // from the oldest real one to the tile's last row.
+    if constexpr (MOM > 0 || FMA) {
+        static_assert(DP >= 4 && NI >= 4, "the first four row pairs are in the ring together");
+        if (job.centre) {                                    // uniform; smoothing filters keep cen = 0
+            f32x2 sum = f32x2{0.0f, 0.0f};
+            if (t0 - 2 * N >= -(long long)job.received0) {   // uniform: row 0 is a real sample, and so are the rows behind it
+                wait_vm<(Q::younger(3, 0) > 63 ? 63 : Q::younger(3, 0))>();
+                static_for<8>([&](auto rc) -> bool { sum = sum + row_in(rc); return true; });
+            } else {
+                const long long h0 = -(long long)job.received0;
+                long long h1 = t0 + TR - 1;
+                if (h1 > (long long)job.ticks - 1) h1 = (long long)job.ticks - 1;
+                const int span = (int)(h1 - h0);             // <= 2N + TR - 1
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const long long h = h0 + (span * i) / 7;
+                    const float *src;
+                    if (h >= 0) src = job.samples + (size_t)h * job.streams;
+                    else { int slot = job.wp0 + (int)h; slot = slot < 0 ? slot + R::WS : slot; src = job.ring + (size_t)slot * job.streams; }
+                    sum = sum + *reinterpret_cast<const f32x2 *>(src + (size_t)strip * 128 + 2 * (size_t)lane);
+                }
+            }
+            cen = sum * f32x2{0.125f, 0.125f};
+            if (!(cen.x - cen.x == 0.0f)) cen.x = 0.0f;           // an Inf / NaN among the eight: that stream's tile stays as it is
+            if (!(cen.y - cen.y == 0.0f)) cen.y = 0.0f;
+            backdt = cen * f32x2{job.centre_sum * job.dt_inv, job.centre_sum * job.dt_inv};
+        }
+    }
     wait_vm<(Q::younger(0, 0) > 63 ? 63 : Q::younger(0, 0))>();           // (a smaller count only waits longer: the counter has 6 bits)
     f32x2 xa = row_in(std::integral_constant<int, 0>{}), xb = row_in(std::integral_constant<int, 1>{});
+    // The fused bank's tiles -- block moments and tap-by-tap alike, never the bit-exact bank -- run on CENTRED samples (end of round 6, R6.16): sum_k w_k x_k = sum_k w_k (x_k - c) + c sum_k w_k for any c; with c = the stream's own
+    // first row of the tile the moments and their block offsets meet the signal's variation over 2N + TR ticks instead of its offset -- a derivative
+    // filter (weights summing to ~0: config 3) on a stream riding on a large offset stood at 2.3 x the reference's own error, the blocks' shares
+    // cancelling only after each had been rounded at the offset's size.  sum_k w_k comes from the reference's table (taps.sig).
     static_for<NI>([&](auto gc) -> bool {
         constexpr int g = decltype(gc)::value;
         f32x2 na = xa, nb = xb;
@@ -283,8 +322,13 @@ __global__ __launch_bounds__(64 * WPB) void sg_bank_dma_kernel(const BankJob job
             nb = row_in(std::integral_constant<int, 2 * g + 3>{});
             __builtin_amdgcn_sched_barrier(0);                                                    // keep these reads AHEAD of pair g's arithmetic (left alone, hipcc sinks them to their use)
         }
-        feed(std::integral_constant<int, 2 * g>{}, xa);
-        feed(std::integral_constant<int, 2 * g + 1>{}, xb);
+        if constexpr (MOM > 0 || FMA) {
+            feed(std::integral_constant<int, 2 * g>{}, xa - cen);
+            feed(std::integral_constant<int, 2 * g + 1>{}, xb - cen);
+        } else {
+            feed(std::integral_constant<int, 2 * g>{}, xa);
+            feed(std::integral_constant<int, 2 * g + 1>{}, xb);
+        }
         if constexpr (g + DP < NI) {
             // pair g's slot is free: its two LDS reads were issued a step ago and their data has just been consumed -- but "consumed" is the
             // compiler's business, so drain the LDS queue explicitly before the DMA may overwrite the slot
@@ -492,6 +536,10 @@ int sg_bank_dma_launch_mom(int n, const float *center, const BankJob &job, int /
     if (job.ticks < 64) return 1;
     StreamMomentFit fit;
     if (stream_moment_fit(n, center, &fit) == 0) return 1;
+    // quadratic taps that sum to zero (a second derivative): the outputs are small against the samples, and what the fitted polynomial leaves of the
+    // reference's fp32 taps (<= 3e-7 of the largest) shows in them -- 1.4e-6 of the oracle where the tap-by-tap tiles are at 0.7e-6 and the reference's
+    // own loop at 0.6e-6 (tools/offset_probe_1d.py, R6.16).  Those banks keep the tap-by-tap tiles (7 % slower); config 3's taps are linear.
+    if (job.centre && fit.terms >= 3) return 1;
     return dispatch_bank_dma_mom<SG_DMA_MOM_MIN_N>(n, fit, center, job, st);
 }
 

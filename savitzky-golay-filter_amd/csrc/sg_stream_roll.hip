@@ -416,6 +416,12 @@ int sg_bank_roll_launch(int n, const float *center_weights, const float *ring, c
     memset(&job, 0, sizeof(job));
     job.ring = ring; job.samples = samples; job.out = out;
     job.streams = streams; job.ticks = ticks; job.received0 = received0; job.wp0 = wp0; job.dt_inv = dt_inv;
+    {
+        double wsum = 0.0, wabs = 0.0;
+        for (int k = 0; k <= 2 * n; ++k) { wsum += (double)center_weights[k]; wabs += std::fabs((double)center_weights[k]); }
+        job.centre_sum = (float)wsum;
+        job.centre = (fma && std::fabs(wsum) < 1e-3 * wabs) ? 1 : 0;       // smoothing filters (sum 1) gain nothing and a zero-mean stream would lose
+    }
     // round 5: the LDS-DMA tile form where it covers the call (sg_stream_dma.hip; SAVGOL_HIP_STREAM_DMA=0 for A/B runs against the forms below)
     static const int dma_env = [] { const char *e = getenv("SAVGOL_HIP_STREAM_DMA"); return e ? atoi(e) : 1; }();
     if (dma_env && sg_bank_dma_launch(n, fma, center_weights, job, cu_count, st) == 0) return 0;

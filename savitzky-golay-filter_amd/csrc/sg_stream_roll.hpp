@@ -43,6 +43,8 @@ struct BankJob {
     unsigned     strips, bands;
     int          band_ticks;
     int          aligned;            // rows of samples / ring / out start 8-byte aligned (streams even, bases aligned)
+    float        centre_sum;         // fused bank, LDS-DMA tiles: the sum of the reference's centre weights ...
+    int          centre;             // ... and 1 when that sum is (nearly) zero -- a derivative filter: the tiles then run on centred samples (sg_stream_dma.hip)
 };
 
 struct TileGeom { unsigned strips, bands, group; unsigned long long total; };

@@ -1234,3 +1234,24 @@ def f_keep(sg, n, m, d):
     if key not in _kept_filters:
         _kept_filters[key] = sg.Filter(n, m, d, 1.0, 2)
     return _kept_filters[key].ptr
+
+@pytest.mark.parametrize("n,m", [(5, 3), (8, 3), (16, 2), (21, 4), (25, 4), (32, 4)])
+def test_derivative_filters_on_signals_with_a_large_offset(sg, sgo, torch_gpu, n, m):
+    """End of round 6 (tools/offset_probe_1d.py): a derivative filter's weights sum to ~0, and on a signal riding on an offset 10 ... 1000 x its own
+    size the default fp32 kernels -- three partial sums, block moments from half window 20 -- stood at 1.1-1.4 x the reference's own error: the
+    partial sums / block shares cancel only after each has been rounded at the offset's size.  They now run on CENTRED tiles (sg1d_tile_body,
+    JOB_CENTRE: the tile's mean is subtracted, c x the reference table's tap sum added back).  The rule, on d = 1 and 2, offsets 0 / 10 / 1000, every
+    boundary mode's interior.  Reference loop: /root/reference/src/savgolFilter.c:763-766."""
+    torch = torch_gpu
+    rng = np.random.default_rng(50 + n)
+    L = 20000
+    t = np.arange(L)
+    base = np.sin(0.01 * t)[None, :] * np.linspace(0.5, 1.5, 3)[:, None] + rng.normal(0, 0.1, (3, L))
+    for d in (1, 2):
+        for off in (0.0, 10.0, 1000.0):
+            x = (base + off).astype(np.float32)
+            f, o = sg.Filter(n, m, d, 0.5, 0), sgo.Filter(n, m, d, 0.5, 0)
+            got = f.apply_tensor(torch.from_numpy(x).cuda()).cpu().numpy()[:, n:L - n]
+            hi = o.apply_f64(x)[:, n:L - n]
+            ref = o.apply(x)[:, n:L - n]
+            check(normwise(got, hi), fp32_bar(normwise(ref, hi)), ("derivative filter, offset", n, m, d, off))

@@ -623,3 +623,30 @@ def test_few_streams_long_block_uses_enough_bands(sg, sgo, torch_gpu):
             o = sgo.Stream(f)
             seq = np.array([v for v, ok in (o.push(v) for v in xs) if ok], np.float32)
             assert same_bits(out[2 * n:, j].cpu().numpy(), seq), (S, n, j)
+
+@pytest.mark.parametrize("n,m,d", [(16, 2, 1), (16, 2, 2), (12, 1, 1), (20, 2, 2), (8, 3, 1), (24, 3, 2)])
+def test_fused_bank_on_streams_with_a_large_offset(sg, sgo, torch_gpu, n, m, d):
+    """End of round 6 (tools/offset_probe_1d.py): the fused bank's block push on streams riding on an offset 10 ... 1000 x the signal.  Config 3's own
+    filter (n = 16, m = 2, d = 1) stood at 2.3 x the reference's own error there -- the block moments' shares cancel only after each has been rounded at
+    the offset's size -- and the tap-by-tap tiles at 1.4 x.  The tiles of derivative filters now run on CENTRED samples (each stream's first row of
+    the tile; c x the reference table's tap sum added back), and quadratic taps that sum to zero keep the tap-by-tap tiles.  Reference loop:
+    /root/reference/src/savgol_stream.c:25-38."""
+    torch = torch_gpu
+    rng = np.random.default_rng(70 + n + d)
+    S, T = 256, 1024
+    tt = np.arange(T)
+    sb = np.sin(0.02 * tt)[:, None] * np.linspace(0.5, 1.5, S)[None, :] + rng.normal(0, 0.1, (T, S))
+    for off in (0.0, 10.0, 1000.0):
+        x = (sb + off).astype(np.float32)
+        bank = sg.StreamBank(S, n, m, d, 1.0, fma=True)
+        dx = torch.from_numpy(x).cuda()
+        out = torch.zeros_like(dx)
+        assert bank.push_block(dx, T, out) == T - 2 * n
+        torch.cuda.synchronize()
+        o = sgo.Filter(n, m, d, 1.0, 0)
+        pick = [0, 1, S // 2, S - 1]
+        xh = np.ascontiguousarray(x[:, pick].T)
+        hi = o.apply_f64(xh.astype(np.float64))[:, n:T - n]
+        ref = o.apply(xh)[:, n:T - n]
+        got = out.cpu().numpy()[2 * n:, pick].T
+        check(normwise(got, hi), fp32_bar(normwise(ref, hi)), ("fused bank, offset", n, m, d, off))
