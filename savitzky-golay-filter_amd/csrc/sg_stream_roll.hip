@@ -28,19 +28,53 @@ namespace sg {
 
 // One item: streams s0, s0+1 of every lane, output ticks t0 .. t0+nt-1.  Row r of the band = history index
 // t0 - 2N + r; output tick m needs rows m .. m+2N, row r lives in ring slot r % U.
+// Fused bank, derivative filters (job.centre; sg_stream_dma.hip has the tiles' form and the reasons, R6.16): what an item's rows are centred on -- the mean
+// of eight real samples of each stream, spread from the oldest real one in the item's reach to its last row.  The bit-exact bank and smoothing filters: 0.
+template <int N, bool VEC, bool FMA>
+__device__ __forceinline__ f32x2 bank_item_centre(const BankJob &job, size_t s0, size_t t0, int nt, bool live0, bool live1)
+{
+    typedef SRoll<N> R;
+    f32x2 cen = f32x2{0.0f, 0.0f};
+    if constexpr (FMA) {
+        if (job.centre) {                                    // uniform
+            long long h0 = (long long)t0 - 2 * N;
+            if (h0 < -(long long)job.received0) h0 = -(long long)job.received0;
+            long long h1 = (long long)t0 + nt - 1;
+            if (h1 > (long long)job.ticks - 1) h1 = (long long)job.ticks - 1;
+            const long long span = h1 - h0;
+            f32x2 sum = f32x2{0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long long h = h0 + (span * i) / 7;
+                int slot = job.wp0 + (int)(h < 0 ? h : 0);
+                slot = slot < 0 ? slot + R::WS : slot;
+                const float *row = h >= 0 ? job.samples + (size_t)h * job.streams : job.ring + (size_t)slot * job.streams;
+                if constexpr (VEC) sum = sum + *reinterpret_cast<const f32x2 *>(row + s0);
+                else sum = sum + f32x2{live0 ? row[s0] : 0.0f, live1 ? row[s0 + 1] : 0.0f};
+            }
+            cen = sum * f32x2{0.125f, 0.125f};
+            if (!(cen.x - cen.x == 0.0f)) cen.x = 0.0f;
+            if (!(cen.y - cen.y == 0.0f)) cen.y = 0.0f;
+        }
+    }
+    return cen;
+}
+
 template <int N, bool VEC, bool FMA>
 __device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTaps<N> &taps, size_t s0, size_t t0, int nt)
 {
     typedef SRoll<N> R;
     const bool live0 = s0 < job.streams, live1 = s0 + 1 < job.streams;
+    const f32x2 cen = bank_item_centre<N, VEC, FMA>(job, s0, t0, nt, live0, live1);      // fused bank, derivative filters: what the item's rows are centred on (else 0)
+    const f32x2 backdt = cen * f32x2{job.centre_sum * job.dt_inv, job.centre_sum * job.dt_inv};
     auto load_row = [&](int r) -> f32x2 {
         long long h = (long long)t0 - 2 * N + r;
         if (h >= (long long)job.ticks) h = (long long)job.ticks - 1;            // past the call: loaded, never used
         int slot = job.wp0 + (int)(h < 0 ? h : 0);
         slot = slot < 0 ? slot + R::WS : slot;
         const float *row = h >= 0 ? job.samples + (size_t)h * job.streams : job.ring + (size_t)slot * job.streams;
-        if constexpr (VEC) return *reinterpret_cast<const f32x2 *>(row + s0);
-        else return f32x2{live0 ? row[s0] : 0.0f, live1 ? row[s0 + 1] : 0.0f};
+        if constexpr (VEC) return *reinterpret_cast<const f32x2 *>(row + s0) - cen;
+        else return f32x2{live0 ? row[s0] : 0.0f, live1 ? row[s0 + 1] : 0.0f} - cen;
     };
     f32x2 win[R::U];
 #pragma unroll
@@ -81,7 +115,7 @@ __device__ __forceinline__ void bank_roll_item(const BankJob &job, const SRollTa
             }
             const size_t t = t0 + (size_t)m;
             if (job.received0 + t + 1 >= (unsigned long long)R::WS) {            // uniform: an output exists (reference :166-170)
-                const f32x2 y = acc * f32x2{job.dt_inv, job.dt_inv};
+                const f32x2 y = FMA ? __builtin_elementwise_fma(acc, f32x2{job.dt_inv, job.dt_inv}, backdt) : acc * f32x2{job.dt_inv, job.dt_inv};
                 float *orow = job.out + t * job.streams;
                 if constexpr (VEC) __builtin_nontemporal_store(__builtin_bit_cast(u32x2, y), reinterpret_cast<u32x2 *>(orow + s0));   // written once (round 5: as the LDS-DMA tiles)
                 else { if (live0) orow[s0] = y.x; if (live1) orow[s0 + 1] = y.y; }
@@ -101,14 +135,16 @@ __device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRol
 {
     typedef SRoll<N> R;
     const bool live0 = s0 < job.streams, live1 = s0 + 1 < job.streams;
+    const f32x2 cen = bank_item_centre<N, VEC, FMA>(job, s0, t0, nt, live0, live1);      // fused bank, derivative filters: what the item's rows are centred on (else 0)
+    const f32x2 backdt = cen * f32x2{job.centre_sum * job.dt_inv, job.centre_sum * job.dt_inv};
     auto load_row = [&](int r) -> f32x2 {
         long long h = (long long)t0 - 2 * N + r;
         if (h >= (long long)job.ticks) h = (long long)job.ticks - 1;            // past the call: loaded, never used
         int slot = job.wp0 + (int)(h < 0 ? h : 0);
         slot = slot < 0 ? slot + R::WS : slot;
         const float *row = h >= 0 ? job.samples + (size_t)h * job.streams : job.ring + (size_t)slot * job.streams;
-        if constexpr (VEC) return *reinterpret_cast<const f32x2 *>(row + s0);
-        else return f32x2{live0 ? row[s0] : 0.0f, live1 ? row[s0 + 1] : 0.0f};
+        if constexpr (VEC) return *reinterpret_cast<const f32x2 *>(row + s0) - cen;
+        else return f32x2{live0 ? row[s0] : 0.0f, live1 ? row[s0 + 1] : 0.0f} - cen;
     };
     f32x2 acc[R::WS];                                        // acc[a], a = 1..2N; garbage until a real output reaches it
 #pragma unroll
@@ -165,7 +201,7 @@ __device__ __forceinline__ void bank_accroll_item(const BankJob &job, const SRol
         });
         const long long t = (long long)t0 + r - 2 * N;
         if (r >= 2 * N && job.received0 + (unsigned long long)t + 1 >= (unsigned long long)R::WS) {      // uniform (reference :166-170)
-            const f32x2 y = done * f32x2{job.dt_inv, job.dt_inv};
+            const f32x2 y = FMA ? __builtin_elementwise_fma(done, f32x2{job.dt_inv, job.dt_inv}, backdt) : done * f32x2{job.dt_inv, job.dt_inv};
             float *orow = job.out + (size_t)t * job.streams;
             if constexpr (VEC) __builtin_nontemporal_store(__builtin_bit_cast(u32x2, y), reinterpret_cast<u32x2 *>(orow + s0));
             else { if (live0) orow[s0] = y.x; if (live1) orow[s0 + 1] = y.y; }

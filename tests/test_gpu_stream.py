@@ -626,27 +626,40 @@ def test_few_streams_long_block_uses_enough_bands(sg, sgo, torch_gpu):
 
 @pytest.mark.parametrize("n,m,d", [(16, 2, 1), (16, 2, 2), (12, 1, 1), (20, 2, 2), (8, 3, 1), (24, 3, 2)])
 def test_fused_bank_on_streams_with_a_large_offset(sg, sgo, torch_gpu, n, m, d):
-    """End of round 6 (tools/offset_probe_1d.py): the fused bank's block push on streams riding on an offset 10 ... 1000 x the signal.  Config 3's own
-    filter (n = 16, m = 2, d = 1) stood at 2.3 x the reference's own error there -- the block moments' shares cancel only after each has been rounded at
-    the offset's size -- and the tap-by-tap tiles at 1.4 x.  The tiles of derivative filters now run on CENTRED samples (each stream's first row of
-    the tile; c x the reference table's tap sum added back), and quadratic taps that sum to zero keep the tap-by-tap tiles.  Reference loop:
-    /root/reference/src/savgol_stream.c:25-38."""
+    """End of round 6 (tools/offset_probe_1d.py, tools/tick_offset_probe.py): the fused bank on streams riding on an offset 10 ... 1000 x the signal, against the
+    reference's own stream arithmetic (one chain, /root/reference/src/savgol_stream.c:25-38 = the bit-exact bank on the same samples).  Uncentred, the
+    block-moment tiles sat at 0.5-1.0 of that bar (d = 2: 1.00) and at 2.3 x the reference's BATCH loop; derivative filters now run on CENTRED samples
+    in the LDS-DMA tiles and the walk (200 streams: not whole strips): the mean of eight rows of the tile / item; c x the reference table's tap sum added
+    back; quadratic taps that sum to zero keep the tap-by-tap tiles: 2-9e-7 of the oracle whatever the offset.  The per-tick kernel (the last 48 ticks)
+    is held to the same bar, uncentred (0.33-0.48 of it)."""
     torch = torch_gpu
     rng = np.random.default_rng(70 + n + d)
-    S, T = 256, 1024
+    T = 1024
     tt = np.arange(T)
-    sb = np.sin(0.02 * tt)[:, None] * np.linspace(0.5, 1.5, S)[None, :] + rng.normal(0, 0.1, (T, S))
-    for off in (0.0, 10.0, 1000.0):
-        x = (sb + off).astype(np.float32)
-        bank = sg.StreamBank(S, n, m, d, 1.0, fma=True)
-        dx = torch.from_numpy(x).cuda()
-        out = torch.zeros_like(dx)
-        assert bank.push_block(dx, T, out) == T - 2 * n
-        torch.cuda.synchronize()
-        o = sgo.Filter(n, m, d, 1.0, 0)
-        pick = [0, 1, S // 2, S - 1]
-        xh = np.ascontiguousarray(x[:, pick].T)
-        hi = o.apply_f64(xh.astype(np.float64))[:, n:T - n]
-        ref = o.apply(xh)[:, n:T - n]
-        got = out.cpu().numpy()[2 * n:, pick].T
-        check(normwise(got, hi), fp32_bar(normwise(ref, hi)), ("fused bank, offset", n, m, d, off))
+    for S in (256, 200):                                     # 200 streams: not whole 128-stream strips -> the walk instead of the LDS-DMA tiles
+        sb = np.sin(0.02 * tt)[:, None] * np.linspace(0.5, 1.5, S)[None, :] + rng.normal(0, 0.1, (T, S))
+        for off in (0.0, 10.0, 1000.0):
+            x = (sb + off).astype(np.float32)
+            bank = sg.StreamBank(S, n, m, d, 1.0, fma=True)
+            dx = torch.from_numpy(x).cuda()
+            out = torch.zeros_like(dx)
+            blk = T - 48                                     # the last 48 ticks go through the per-tick kernel, one push each
+            assert bank.push_block(dx, blk, out) == blk - 2 * n
+            o1 = torch.zeros(S, dtype=torch.float32, device="cuda")
+            for t in range(blk, T):
+                assert bank.push(dx[t], o1) == 1
+                out[t] = o1
+            torch.cuda.synchronize()
+            o = sgo.Filter(n, m, d, 1.0, 0)
+            pick = [0, 1, S // 2, S - 1]
+            xh = np.ascontiguousarray(x[:, pick].T)
+            hi = o.apply_f64(xh.astype(np.float64))[:, n:T - n]
+            # the reference's own stream arithmetic (one chain: src/savgol_stream.c:25-38) = the bit-exact bank on the same samples
+            rb = sg.StreamBank(S, n, m, d, 1.0)
+            want = torch.zeros_like(dx)
+            assert rb.push_block(dx, T, want) == T - 2 * n
+            ref = want.cpu().numpy()[2 * n:, pick].T
+            got = out.cpu().numpy()[2 * n:, pick].T
+            nb = blk - 2 * n                                  # outputs of the block push, then of the per-tick pushes
+            check(normwise(got[:, :nb], hi[:, :nb]), fp32_bar(normwise(ref[:, :nb], hi[:, :nb])), ("fused bank, offset, block push", n, m, d, S, off))
+            check(normwise(got[:, nb:], hi[:, nb:]), fp32_bar(normwise(ref[:, nb:], hi[:, nb:])), ("fused bank, offset, per tick", n, m, d, S, off))

@@ -37,7 +37,8 @@ for d in (0, 1, 2):
         bank.push_block(dx, T, out); torch.cuda.synchronize()
         o = sgo.Filter(16, 2, d, 1.0, 0)
         hi = o.apply_f64(x.T.astype(np.float64).copy())[:, 16:T - 16]          # centre outputs j = 16 .. T-17 arrive at ticks 32 .. T-1
-        ref = o.apply(np.ascontiguousarray(x.T))[:, 16:T - 16]
+        rb = sg.StreamBank(S, 16, 2, d, 1.0); want = torch.zeros_like(dx); rb.push_block(dx, T, want); torch.cuda.synchronize()
+        ref = want.cpu().numpy()[32:].T                                        # the reference's own stream arithmetic (one chain) = the bit-exact bank
         got = out.cpu().numpy()[32:].T
         e, er = normwise(got, hi), normwise(ref, hi)
         row.append(f"off {off:g}: ours {e:.1e} ref {er:.1e} ({e / fp32_bar(er):.2f})")
